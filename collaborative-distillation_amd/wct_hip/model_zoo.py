@@ -1,0 +1,142 @@
+"""Layer graphs of the WCT encoder/decoder cascade (host-side description only).
+
+The reference builds ten nn.Module classes per mode (model/model_cd.py:62-743 for
+``16x``, model/model_original.py:11-599 for ``original``).  Every one of them is the
+same VGG-19 prefix / mirrored suffix with different channel widths, so here the graph
+is data: a list of ``Layer`` records that the HIP library (and the test oracle)
+walk.  Nothing in this file computes anything.
+
+Encoder level L  = conv0(1x1 affine, folded) + VGG-19 convs up to relu{L}_1
+                   (model_cd.py:346-349, 403-409, 485-494, 589-603, 724-743)
+Decoder level L  = mirror, nearest x2 upsample after conv51/41/31/21, ReLU after
+                   EVERY conv including the last one (model_cd.py:83-85, 117-122,
+                   159-167, 211-224, 276-294)
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, List, Tuple
+
+import numpy as np
+
+MODES = ("original", "16x")
+
+# channel width of VGG block k (conv{k}_x) per mode
+_WIDTHS = {
+    "16x": {1: 16, 2: 32, 3: 64, 4: 128, 5: 128},
+    "original": {1: 64, 2: 128, 3: 256, 4: 512, 5: 512},
+}
+# the level-1 pruned encoder keeps 24 filters in conv1_1 (model_cd.py:324,
+# SmallDecoder1_16x.conv11 is 24->3, model_cd.py:67)
+_L1_WIDTH = {"16x": 24, "original": 64}
+
+# VGG-19 conv order and which convs are followed by a 2x2 max-pool in the encoder
+_VGG_ORDER = ["conv11", "conv12", "conv21", "conv22", "conv31", "conv32", "conv33",
+              "conv34", "conv41", "conv42", "conv43", "conv44", "conv51"]
+_POOL_AFTER = {"conv12", "conv22", "conv34", "conv44"}
+_LAST_OF_LEVEL = {1: "conv11", 2: "conv21", 3: "conv31", 4: "conv41", 5: "conv51"}
+# decoder: nearest-neighbour x2 after these convs
+_UP_AFTER = {"conv51", "conv41", "conv31", "conv21"}
+
+
+@dataclass(frozen=True)
+class Layer:
+    name: str
+    cin: int
+    cout: int
+    pool_after: bool = False   # encoder: MaxPool2d(2,2) floor mode after ReLU
+    up_after: bool = False     # decoder: UpsamplingNearest2d(2) after ReLU
+
+
+def _block(name: str) -> int:
+    return int(name[4])
+
+
+def feature_channels(mode: str, level: int) -> int:
+    """C of relu{level}_1 for the given mode (128,128,64,32,24 / 512,512,256,128,64)."""
+    if level == 1:
+        return _L1_WIDTH[mode]
+    return _WIDTHS[mode][level]
+
+
+def encoder_layers(mode: str, level: int) -> List[Layer]:
+    assert mode in MODES and 1 <= level <= 5
+    out: List[Layer] = []
+    cin = 3
+    last = _LAST_OF_LEVEL[level]
+    for name in _VGG_ORDER:
+        cout = _WIDTHS[mode][_block(name)]
+        if level == 1:
+            cout = _L1_WIDTH[mode]
+        pool = name in _POOL_AFTER and name != last
+        out.append(Layer(name, cin, cout, pool_after=pool))
+        cin = cout
+        if name == last:
+            break
+    return out
+
+
+def decoder_layers(mode: str, level: int) -> List[Layer]:
+    """Mirror of the encoder: conv XY maps enc.cout -> enc.cin, listed in execution order."""
+    enc = encoder_layers(mode, level)
+    out: List[Layer] = []
+    for i, l in enumerate(reversed(enc)):
+        last = i == len(enc) - 1
+        out.append(Layer(l.name, l.cout, l.cin, up_after=(l.name in _UP_AFTER and not last)))
+    return out
+
+
+def output_size(level: int, H: int, W: int) -> Tuple[int, int, int, int]:
+    """(h, w) of the relu{level}_1 feature and (Ho, Wo) of the decoded image.
+
+    Floor-mode pooling drops odd rows/cols, so a 1080-row image leaves level 5 with
+    67 feature rows and decodes to 1072 rows.
+    """
+    h, w = H, W
+    for _ in range(level - 1):
+        h, w = h // 2, w // 2
+    return h, w, h << (level - 1), w << (level - 1)
+
+
+# ----------------------------------------------------------------------------------
+# weights
+# ----------------------------------------------------------------------------------
+def module_key(kind: str, level: int) -> str:
+    return "%s%d" % ("e" if kind == "enc" else "d", level)
+
+
+def load_npz_weights(path: str) -> Dict[str, np.ndarray]:
+    """Torch-free weight blob: keys ``e5.conv11.weight`` (OIHW f32), ``e5.conv11.bias``,
+    ``e5.conv0.weight`` ([3,3,1,1]), ``e5.conv0.bias``, ``d5.conv51.weight`` ...
+    Produced from the reference checkpoints by tools/make_goldens.py."""
+    with np.load(path) as z:
+        return {k: np.ascontiguousarray(z[k], dtype=np.float32) for k in z.files}
+
+
+#: fixed conv0 of the un-pruned encoders: RGB[0,1] -> BGR*255 - mean  (model_original.py:428-433)
+ORIGINAL_CONV0_W = np.array([[0, 0, 255], [0, 255, 0], [255, 0, 0]], np.float32).reshape(3, 3, 1, 1)
+ORIGINAL_CONV0_B = np.array([-103.939, -116.779, -123.68], np.float32)
+
+
+def synth_weights(mode: str, seed: int) -> Dict[str, np.ndarray]:
+    """Deterministic stand-in weights (He-uniform) for a mode whose checkpoints are not
+    available (``original``: trained_models/original_wct_models/*.t7 are absent from the
+    reference snapshot, README.md:26).  Used by tests, goldens (G6) and bench config 3.
+    Only ``Generator.random`` (uniform doubles) is used so the stream is stable across
+    numpy versions."""
+    rng = np.random.default_rng(seed)
+    w: Dict[str, np.ndarray] = {}
+    for level in range(1, 6):
+        for kind, layers in (("enc", encoder_layers(mode, level)), ("dec", decoder_layers(mode, level))):
+            key = module_key(kind, level)
+            if kind == "enc":
+                w[key + ".conv0.weight"] = ORIGINAL_CONV0_W.copy()
+                w[key + ".conv0.bias"] = ORIGINAL_CONV0_B.copy()
+            for l in layers:
+                a = np.sqrt(6.0 / (9 * l.cin))
+                wt = (rng.random((l.cout, l.cin, 3, 3)) * 2.0 - 1.0) * a
+                if kind == "dec" and l.cout == 3:
+                    wt = wt * (1.0 / 128.0)  # features are O(100) (input x255): keep the decoded image O(1)
+                w["%s.%s.weight" % (key, l.name)] = wt.astype(np.float32)
+                w["%s.%s.bias" % (key, l.name)] = ((rng.random(l.cout) * 0.1) + (0.2 if (kind == "dec" and l.cout == 3) else 0.0)).astype(np.float32)
+    return w

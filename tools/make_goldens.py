@@ -1,0 +1,294 @@
+#!/usr/bin/env python3
+"""Generate the torch-free weight blob and the golden vectors from the REFERENCE itself.
+
+Runs only in the build container (needs /root/reference and torch-CPU).  Nothing of the
+reference's source travels: the outputs are *data* --
+  collaborative-distillation_amd/weights/16x.npz   the ten 16x checkpoints, aux heads dropped
+  tests/golden/*.npz                               inputs + expected outputs (G1..G7)
+
+The reference is imported unmodified with the two shims of SURVEY 8c:
+  * torch.utils.serialization.load_lua (removed in torch>=1.0) is injected as a stub;
+  * empty `torchvision` / `torchvision.transforms` modules are registered (imported, never used
+    by util_wct.py).
+`WCT.py` itself is a script (argparse + .cuda()), so its 9-line styleTransfer()/cascade
+(WCT.py:98-106, 120-125) is restated in `ref_style_transfer` below, on CPU.
+
+usage: PYTHONDONTWRITEBYTECODE=1 python tools/make_goldens.py
+"""
+import os
+import sys
+import types
+
+os.environ.setdefault("PYTHONDONTWRITEBYTECODE", "1")
+sys.dont_write_bytecode = True
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+GOLD = os.path.join(REPO, "tests", "golden")
+sys.path.insert(0, os.path.join(REPO, "collaborative-distillation_amd"))
+from wct_hip import model_zoo  # noqa: E402
+
+
+def import_reference():
+    import torch.utils.serialization as ser
+
+    def _no_lua(*a, **k):
+        raise RuntimeError("load_lua is not available (torch>=1.0)")
+
+    ser.load_lua = _no_lua
+    for name in ("torchvision", "torchvision.transforms"):
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+    sys.modules["torchvision"].transforms = sys.modules["torchvision.transforms"]
+    sys.path.insert(0, os.path.join(REF, "PytorchWCT"))
+    os.chdir(os.path.join(REF, "PytorchWCT"))
+    import util_wct  # noqa
+    return util_wct
+
+
+def ref_args(mode="16x", alpha=1.0):
+    a = types.SimpleNamespace(mode=mode, numpy=False, alpha=alpha)
+    for k in range(1, 6):
+        setattr(a, "e%d" % k, "../trained_models/wct_se_16x_new/%dSE.pth" % k)
+        setattr(a, "d%d" % k, "../trained_models/wct_se_16x_new_sd/%dSD.pth" % k)
+    return a
+
+
+@torch.no_grad()
+def ref_transform(wct, cF, sF, alpha):
+    """util_wct.py:210-223 called the way WCT.py:102-104 does (CPU f32 CHW in), with csF
+    pre-sized because `csF.data.resize_` no longer resizes the caller's tensor."""
+    csF = torch.empty(1, *cF.shape)
+    out = wct.transform(cF, sF, csF, alpha)
+    assert out.shape == (1,) + tuple(cF.shape)
+    return out
+
+
+@torch.no_grad()
+def ref_style_transfer(wct, enc, dec, cImg, sImg, alpha, trace=None):
+    sF = enc(sImg).squeeze(0)
+    cF = enc(cImg).squeeze(0)
+    csF = ref_transform(wct, cF, sF, alpha)
+    img = dec(csF)
+    if trace is not None:
+        trace.append((cF.numpy().copy(), sF.numpy().copy(), csF.squeeze(0).numpy().copy(), img.squeeze(0).numpy().copy()))
+    return img
+
+
+def load_rgb(path, crop=None, origin=None):
+    from PIL import Image
+    im = np.asarray(Image.open(path).convert("RGB"), dtype=np.float32) / 255.0  # ToTensor(): /255, CHW
+    im = np.ascontiguousarray(im.transpose(2, 0, 1))
+    if crop is not None:
+        h, w = crop
+        H, W = im.shape[1:]
+        y0, x0 = ((H - h) // 2, (W - w) // 2) if origin is None else origin
+        im = np.ascontiguousarray(im[:, y0:y0 + h, x0:x0 + w])
+    return im
+
+
+def t(x):
+    return torch.from_numpy(np.ascontiguousarray(x))
+
+
+def main():
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    util_wct = import_reference()
+    wct = util_wct.WCT(ref_args())
+    wct.eval()
+    os.makedirs(GOLD, exist_ok=True)
+
+    # ------------------------------------------------------------------ weights
+    blob = {}
+    for k in range(1, 6):
+        for kind, mod in (("enc", getattr(wct, "e%d" % k)), ("dec", getattr(wct, "d%d" % k))):
+            key = model_zoo.module_key(kind, k)
+            sd = mod.state_dict()
+            layers = model_zoo.encoder_layers("16x", k) if kind == "enc" else model_zoo.decoder_layers("16x", k)
+            names = [l.name for l in layers] + (["conv0"] if kind == "enc" else [])
+            for n in names:
+                blob["%s.%s.weight" % (key, n)] = sd[n + ".weight"].numpy().astype(np.float32)
+                blob["%s.%s.bias" % (key, n)] = sd[n + ".bias"].numpy().astype(np.float32)
+            for l in layers:  # the graph description must agree with the checkpoints
+                assert tuple(sd[l.name + ".weight"].shape) == (l.cout, l.cin, 3, 3), (key, l)
+            unused = [n for n in sd if n.split(".")[0] not in names]
+            assert all("aux" in n for n in unused), unused
+    wpath = os.path.join(REPO, "collaborative-distillation_amd", "weights", "16x.npz")
+    np.savez(wpath, **blob)
+    nparam = sum(v.size for v in blob.values())
+    print("weights: %d tensors, %d params -> %s" % (len(blob), nparam, wpath))
+
+    rng = np.random.default_rng(1234)
+
+    # ------------------------------------------------------------------ G1 per-op
+    g1 = {}
+    seen = set()
+    pad = torch.nn.ReflectionPad2d((1, 1, 1, 1))
+    for k in range(5, 0, -1):
+        for kind in ("enc", "dec"):
+            mod = getattr(wct, ("e%d" if kind == "enc" else "d%d") % k)
+            layers = model_zoo.encoder_layers("16x", k) if kind == "enc" else model_zoo.decoder_layers("16x", k)
+            for l in layers:
+                if (l.cin, l.cout) in seen:
+                    continue
+                seen.add((l.cin, l.cout))
+                x = rng.random((1, l.cin, 13, 11), dtype=np.float32) * 2 - 0.5
+                conv = getattr(mod, l.name)
+                with torch.no_grad():
+                    y = torch.relu(conv(pad(t(x)))).numpy()
+                tag = "conv_%s_%s" % (model_zoo.module_key(kind, k), l.name)
+                g1[tag + ".x"] = x
+                g1[tag + ".y"] = y
+    x = rng.random((1, 5, 13, 11), dtype=np.float32)
+    g1["maxpool.x"] = x
+    g1["maxpool.y"] = torch.nn.MaxPool2d(2, 2)(t(x)).numpy()
+    g1["upsample.x"] = x
+    g1["upsample.y"] = torch.nn.UpsamplingNearest2d(scale_factor=2)(t(x)).numpy()
+    x = rng.random((1, 3, 9, 7), dtype=np.float32)
+    with torch.no_grad():
+        g1["conv0_e5.x"] = x
+        g1["conv0_e5.y"] = wct.e5.conv0(t(x)).numpy()
+    np.savez_compressed(os.path.join(GOLD, "g1_ops.npz"), **g1)
+    print("G1: %d arrays, distinct convs: %s" % (len(g1), sorted(seen)))
+
+    # ------------------------------------------------------------------ G2 per-module
+    g2 = {}
+    x = rng.random((1, 3, 48, 80), dtype=np.float32)
+    g2["img"] = x
+    for k in range(1, 6):
+        with torch.no_grad():
+            f = getattr(wct, "e%d" % k)(t(x))
+            # decoder input: a perturbed feature so it is not tied to the encoder's own output
+            fin = (f * (0.5 + t(rng.random(tuple(f.shape), dtype=np.float32)))).contiguous()
+            y = getattr(wct, "d%d" % k)(fin)
+        g2["e%d.y" % k] = f.numpy()
+        g2["d%d.x" % k] = fin.numpy()
+        g2["d%d.y" % k] = y.numpy()
+    # odd sizes: floor pooling drops rows/cols (135x33 -> L5 128x32 ... SURVEY appendix A)
+    xo = rng.random((1, 3, 45, 37), dtype=np.float32)
+    g2["img_odd"] = xo
+    for k in range(1, 6):
+        with torch.no_grad():
+            g2["e%d.y_odd" % k] = getattr(wct, "e%d" % k)(t(xo)).numpy()
+    np.savez_compressed(os.path.join(GOLD, "g2_modules.npz"), **g2)
+    print("G2: %d arrays" % len(g2))
+
+    # ------------------------------------------------------------------ G3 transform
+    g3 = {}
+
+    def add_case(name, cF, sF, alpha):
+        out = ref_transform(wct, t(cF), t(sF), alpha).numpy()
+        g3[name + ".cF"] = cF
+        g3[name + ".sF"] = sF
+        g3[name + ".alpha"] = np.float64(alpha)
+        g3[name + ".out"] = out
+        assert np.isfinite(out).all(), name
+
+    # full rank, C=24
+    cF = np.maximum(rng.standard_normal((24, 20, 30)).astype(np.float32) + 0.5, 0)
+    sF = np.maximum(rng.standard_normal((24, 17, 23)).astype(np.float32) * 2 + 0.3, 0)
+    add_case("fullrank24", cF, sF, 1.0)
+    add_case("fullrank24_a06", cF, sF, 0.6)
+    # ReLU-sparse with exactly-dead and nearly-dead channels, C=32
+    cF = np.maximum(rng.standard_normal((32, 16, 24)).astype(np.float32), 0)
+    sF = np.maximum(rng.standard_normal((32, 18, 20)).astype(np.float32), 0)
+    cF[3] = 0; cF[17] = 0; sF[3] = 0; sF[9] = 0
+    cF[5] = 0; cF[5, 7, 11] = 0.75       # one active pixel
+    sF[21] = 0; sF[21, 2, 3] = 1.25
+    add_case("dead32", cF, sF, 1.0)
+    # hw < C on the content side, C=128
+    cF = np.maximum(rng.standard_normal((128, 5, 10)).astype(np.float32) + 0.2, 0)
+    sF = np.maximum(rng.standard_normal((128, 24, 30)).astype(np.float32) + 0.2, 0)
+    add_case("hw_lt_C_content", cF, sF, 1.0)
+    # hw < C on the style side
+    cF = np.maximum(rng.standard_normal((128, 20, 26)).astype(np.float32) + 0.2, 0)
+    sF = np.maximum(rng.standard_normal((128, 6, 9)).astype(np.float32) + 0.2, 0)
+    add_case("hw_lt_C_style", cF, sF, 1.0)
+    # correlated channels (ill-conditioned but live), C=64
+    base = rng.standard_normal((8, 22, 22)).astype(np.float32)
+    mix = rng.standard_normal((64, 8)).astype(np.float32)
+    cF = np.maximum(np.einsum("ck,khw->chw", mix, base) + 0.05 * rng.standard_normal((64, 22, 22)).astype(np.float32), 0).astype(np.float32)
+    sF = np.maximum(rng.standard_normal((64, 19, 21)).astype(np.float32) + 0.1, 0)
+    add_case("illcond64", cF, sF, 1.0)
+    np.savez_compressed(os.path.join(GOLD, "g3_transform.npz"), **g3)
+    print("G3: %d arrays" % len(g3))
+
+    # ------------------------------------------------------------------ G4/G5 cascade on real crops
+    g4 = {}
+    content = load_rgb(os.path.join(REF, "PytorchWCT/content/in4.jpg"), crop=(128, 128))
+    style = load_rgb(os.path.join(REF, "PytorchWCT/style/in3.jpg"), crop=(128, 128))
+    for tag, c, s in (("a", content, style),
+                      ("b", load_rgb(os.path.join(REF, "PytorchWCT/content/in4.jpg"), crop=(120, 136), origin=(200, 150)),
+                       load_rgb(os.path.join(REF, "PytorchWCT/style/in3.jpg"), crop=(96, 112), origin=(100, 300)))):
+        trace = []
+        img = t(c[None])
+        for k in (5, 4, 3, 2, 1):
+            img = ref_style_transfer(wct, getattr(wct, "e%d" % k), getattr(wct, "d%d" % k), img, t(s[None]), 1.0, trace)
+        g4[tag + ".content"] = c
+        g4[tag + ".style"] = s
+        g4[tag + ".final"] = img.squeeze(0).numpy()
+        for k, (cF, sF, csF, out) in zip((5, 4, 3, 2, 1), trace):
+            C = cF.shape[0]
+            X = cF.reshape(C, -1).astype(np.float64)
+            g4["%s.L%d.c_mean" % (tag, k)] = X.mean(1)
+            g4["%s.L%d.c_cov" % (tag, k)] = np.cov(X)
+            g4["%s.L%d.dead" % (tag, k)] = np.int64((X.max(1) == 0).sum())
+            g4["%s.L%d.out" % (tag, k)] = out.astype(np.float32)
+            if k >= 4:
+                g4["%s.L%d.csF" % (tag, k)] = csF.astype(np.float32)
+        print("G4[%s]: final %s range [%.3f, %.3f], dead/level %s" % (
+            tag, g4[tag + ".final"].shape, g4[tag + ".final"].min(), g4[tag + ".final"].max(),
+            [int(g4["%s.L%d.dead" % (tag, k)]) for k in (5, 4, 3, 2, 1)]))
+    np.savez_compressed(os.path.join(GOLD, "g4_cascade.npz"), **g4)
+
+    # ------------------------------------------------------------------ G6 original architecture, generated weights
+    from model.model_original import (Encoder1, Encoder2, Encoder3, Encoder4, Encoder5,
+                                      Decoder1, Decoder2, Decoder3, Decoder4, Decoder5)
+    ow = model_zoo.synth_weights("original", seed=2024)
+    encs = [Encoder1, Encoder2, Encoder3, Encoder4, Encoder5]
+    decs = [Decoder1, Decoder2, Decoder3, Decoder4, Decoder5]
+    mods = {}
+    for k in range(1, 6):
+        for kind, cls in (("enc", encs[k - 1]), ("dec", decs[k - 1])):
+            m = cls(None)
+            key = model_zoo.module_key(kind, k)
+            sd = {n[len(key) + 1:]: t(v) for n, v in ow.items() if n.startswith(key + ".")}
+            m.load_state_dict(sd, strict=True)
+            m.eval()
+            mods[key] = m
+    g6 = {"seed": np.int64(2024)}
+    c = rng.random((1, 3, 64, 64), dtype=np.float32)
+    s = rng.random((1, 3, 48, 80), dtype=np.float32)
+    g6["content"], g6["style"] = c[0], s[0]
+    owct = types.SimpleNamespace(transform=wct.transform)
+    img = t(c)
+    for k in (5, 4, 3, 2, 1):
+        with torch.no_grad():
+            if k == 5:
+                g6["e5.y"] = mods["e5"](t(c)).numpy()
+        img = ref_style_transfer(owct, mods["e%d" % k], mods["d%d" % k], img, t(s), 1.0)
+        g6["L%d.out" % k] = img.squeeze(0).numpy()
+    print("G6: final range [%.3f, %.3f]" % (g6["L1.out"].min(), g6["L1.out"].max()))
+    np.savez_compressed(os.path.join(GOLD, "g6_original.npz"), **g6)
+
+    # ------------------------------------------------------------------ G7 config 1 (512x512, relu1_1 only)
+    r0 = np.random.default_rng(0)
+    c = r0.random((1, 3, 512, 512), dtype=np.float32)
+    s = r0.random((1, 3, 512, 512), dtype=np.float32)
+    out = ref_style_transfer(wct, wct.e1, wct.d1, t(c), t(s), 1.0).squeeze(0).numpy()
+    g7 = {"crop": out[:, 200:264, 300:364].copy(), "mean": np.float64(out.mean(dtype=np.float64)),
+          "std": np.float64(out.std(dtype=np.float64)), "max": np.float64(out.max()),
+          "chan_mean": out.reshape(3, -1).mean(1, dtype=np.float64)}
+    np.savez_compressed(os.path.join(GOLD, "g7_config1.npz"), **g7)
+    print("G7: mean %.6f std %.6f max %.6f" % (g7["mean"], g7["std"], g7["max"]))
+
+    for f in sorted(os.listdir(GOLD)):
+        print("%-24s %8d bytes" % (f, os.path.getsize(os.path.join(GOLD, f))))
+
+
+if __name__ == "__main__":
+    main()
