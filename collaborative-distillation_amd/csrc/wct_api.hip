@@ -1,0 +1,673 @@
+// C ABI of libwct_hip (see include/wct_hip.h): context, module loading, the per-level pipeline and the
+// 5-level cascade.  Host-side C++ only orchestrates launches on the context's HIP stream; all arithmetic is
+// in the kernels of conv3x3.hip / moments.hip / solve.hip / misc.hip.
+#include "../../include/wct_hip.h"
+#include "wct_common.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+namespace {
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+};
+
+struct LayerDev {
+  ConvDesc d{};
+  int pool_after = 0, up_after = 0;
+  float* w_oihw = nullptr;  // device copy of the original weights (first decoder layer only: needed by the fold)
+  float* bias_raw = nullptr;
+  float* wpk = nullptr;
+  float* bias = nullptr;
+};
+
+struct Module {
+  bool loaded = false;
+  std::vector<LayerDev> layers;
+};
+
+struct ProfRec {
+  hipEvent_t e0, e1;
+  std::string name;
+  double flops, bytes;
+};
+
+}  // namespace
+
+struct wct_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  Module mod[2][6];
+  // workspace
+  DevBuf actA, actB, featC, featS, tmpT, wsMom, wsSolve, small, foldW;
+  // profiling
+  bool prof = false;
+  std::vector<ProfRec> recs;
+  std::map<std::string, wct_prof_entry> prof_acc;
+};
+
+namespace {
+
+int fail(wct_ctx* ctx, int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (ctx) ctx->err = buf;
+  return code;
+}
+
+#define HIPCHK(ctx, expr)                                                                          \
+  do {                                                                                             \
+    hipError_t e__ = (expr);                                                                       \
+    if (e__ != hipSuccess)                                                                         \
+      return fail(ctx, e__ == hipErrorOutOfMemory ? WCT_ERR_NOMEM : WCT_ERR_HIP, "%s: %s (%s:%d)", \
+                  #expr, hipGetErrorString(e__), __FILE__, __LINE__);                              \
+  } while (0)
+
+int ensure(wct_ctx* ctx, DevBuf& b, size_t bytes) {
+  if (b.cap >= bytes) return WCT_OK;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  if (b.p) {
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipFree(b.p));
+    b.p = nullptr; b.cap = 0;
+  }
+  const size_t want = (bytes + 255) & ~(size_t)255;
+  HIPCHK(ctx, hipMalloc(&b.p, want));
+  b.cap = want;
+  return WCT_OK;
+}
+
+void release(DevBuf& b) {
+  if (b.p) (void)hipFree(b.p);
+  b.p = nullptr; b.cap = 0;
+}
+
+int pad_cout(int c) {
+  if (c <= 16) return 16;
+  if (c <= 32) return 32;
+  if (c <= 64) return 64;
+  return (c + 127) / 128 * 128;
+}
+
+bool valid_level(int l) { return l >= 1 && l <= 5; }
+
+// ---- profiling wrapper -----------------------------------------------------------------------------
+struct ProfScope {
+  wct_ctx* ctx;
+  bool on;
+  ProfRec r;
+  ProfScope(wct_ctx* c, const char* name, double flops, double bytes) : ctx(c), on(c->prof) {
+    if (!on) return;
+    r.name = name; r.flops = flops; r.bytes = bytes;
+    (void)hipEventCreate(&r.e0); (void)hipEventCreate(&r.e1);
+    (void)hipEventRecord(r.e0, ctx->stream);
+  }
+  ~ProfScope() {
+    if (!on) return;
+    (void)hipEventRecord(r.e1, ctx->stream);
+    ctx->recs.push_back(r);
+  }
+};
+
+void prof_collect(wct_ctx* ctx) {
+  if (ctx->recs.empty()) return;
+  (void)hipStreamSynchronize(ctx->stream);
+  for (auto& r : ctx->recs) {
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, r.e0, r.e1);
+    auto& e = ctx->prof_acc[r.name];
+    if (e.launches == 0) { memset(&e, 0, sizeof e); snprintf(e.name, sizeof e.name, "%s", r.name.c_str()); }
+    e.ms += ms; e.flops += r.flops; e.bytes += r.bytes; e.launches += 1;
+    (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1);
+  }
+  ctx->recs.clear();
+}
+
+// ---- one conv launch, with algorithmic work accounting ---------------------------------------------
+int run_conv(wct_ctx* ctx, const ConvDesc& d, const float* in, float* out, int H, int W) {
+  char name[48];
+  const int ct = d.cout_pad > 128 ? 8 : d.cout_pad / 16;
+  snprintf(name, sizeof name, "conv3x3<ct=%d%s%s%s>", ct, (d.flags & CONV_IN_NCHW3) ? ",in3" : "",
+           (d.flags & CONV_POOL_OUT) ? ",pool" : "", (d.flags & CONV_OUT_NCHW3) ? ",out3" : "");
+  const double px = (double)H * W;
+  const double in_px = (d.flags & CONV_UP_IN) ? px / 4 : px, out_px = (d.flags & CONV_POOL_OUT) ? px / 4 : px;
+  const double flops = 2.0 * 9 * d.cin * d.cout * px;
+  const double bytes = 4.0 * (in_px * d.cin + out_px * d.cout + 9.0 * d.cin * d.cout);
+  ProfScope ps(ctx, name, flops, bytes);
+  HIPCHK(ctx, launch_conv3x3(d, in, out, H, W, ctx->stream));
+  return WCT_OK;
+}
+
+// pack OIHW host weights into [chunk][tap][kq][cout_pad][4]; optional conv0 fold (first encoder conv)
+void pack_weights(const float* w, const float* b, int cout, int cin, int cout_pad, bool in3, const float* c0w,
+                  const float* c0b, std::vector<float>& wpk, std::vector<float>& bias) {
+  bias.assign(cout_pad, 0.f);
+  if (in3) {
+    // [tap][k = cin 0..3][cout_pad];  W'[o][i][t] = sum_c W[o][c][t] * W0[c][i],  b' = b + sum_{c,t} W[o][c][t] b0[c]
+    wpk.assign((size_t)36 * cout_pad, 0.f);
+    for (int o = 0; o < cout; ++o) {
+      double bb = b[o];
+      for (int t = 0; t < 9; ++t)
+        for (int i = 0; i < 3; ++i) {
+          double s = 0.;
+          for (int c = 0; c < 3; ++c) {
+            const double wv = w[((size_t)o * 3 + c) * 9 + t];
+            s += c0w ? wv * c0w[c * 3 + i] : (c == i ? wv : 0.);
+          }
+          wpk[((size_t)t * 4 + i) * cout_pad + o] = (float)s;
+        }
+      if (c0b)
+        for (int c = 0; c < 3; ++c)
+          for (int t = 0; t < 9; ++t) bb += (double)w[((size_t)o * 3 + c) * 9 + t] * c0b[c];
+      bias[o] = (float)bb;
+    }
+    return;
+  }
+  const int chunks = (cin + 15) / 16;
+  wpk.assign((size_t)chunks * 36 * cout_pad * 4, 0.f);
+  for (int o = 0; o < cout; ++o) {
+    bias[o] = b[o];
+    for (int i = 0; i < cin; ++i) {
+      const int chunk = i / 16, kq = (i % 16) / 4, r = i % 4;
+      for (int t = 0; t < 9; ++t)
+        wpk[((((size_t)chunk * 9 + t) * 4 + kq) * cout_pad + o) * 4 + r] = w[((size_t)o * cin + i) * 9 + t];
+    }
+  }
+}
+
+int upload(wct_ctx* ctx, float** dst, const std::vector<float>& v) {
+  HIPCHK(ctx, hipMalloc(reinterpret_cast<void**>(dst), v.size() * sizeof(float)));
+  HIPCHK(ctx, hipMemcpy(*dst, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
+  return WCT_OK;
+}
+
+void free_module(Module& m) {
+  for (auto& l : m.layers) {
+    if (l.w_oihw) (void)hipFree(l.w_oihw);
+    if (l.bias_raw) (void)hipFree(l.bias_raw);
+    if (l.wpk) (void)hipFree(l.wpk);
+    if (l.bias) (void)hipFree(l.bias);
+  }
+  m.layers.clear();
+  m.loaded = false;
+}
+
+size_t max_act_bytes(const Module& m, int H, int W, bool enc) {
+  // largest intermediate NHWC activation of a module run on an H x W image (enc) / h x w feature (dec)
+  size_t best = 0;
+  int h = H, w = W;
+  for (size_t i = 0; i < m.layers.size(); ++i) {
+    const auto& l = m.layers[i];
+    if (enc) {
+      int oh = h, ow = w;
+      if (l.pool_after) { oh = h / 2; ow = w / 2; }
+      best = std::max(best, (size_t)oh * ow * l.d.cout * sizeof(float));
+      h = oh; w = ow;
+    } else {
+      if (i > 0 && m.layers[i - 1].up_after) { h *= 2; w *= 2; }
+      best = std::max(best, (size_t)h * w * l.d.cout * sizeof(float));
+    }
+  }
+  return best;
+}
+
+int encode_impl(wct_ctx* ctx, int level, const float* img, int H, int W, float* feat_nhwc, int* ho, int* wo) {
+  Module& m = ctx->mod[WCT_KIND_ENC][level];
+  if (!m.loaded) return fail(ctx, WCT_ERR_STATE, "encoder %d not loaded", level);
+  if (H < (2 << (level - 1)) || W < (2 << (level - 1)))
+    return fail(ctx, WCT_ERR_INVALID, "image %dx%d too small for level %d (reflect padding needs >= 2 samples at every scale)", H, W, level);
+  const size_t need = max_act_bytes(m, H, W, true);
+  if (int rc = ensure(ctx, ctx->actA, need)) return rc;
+  if (int rc = ensure(ctx, ctx->actB, need)) return rc;
+  const float* cur = img;
+  int h = H, w = W;
+  for (size_t i = 0; i < m.layers.size(); ++i) {
+    const auto& l = m.layers[i];
+    const bool last = i + 1 == m.layers.size();
+    float* dst = last ? feat_nhwc : reinterpret_cast<float*>((i & 1) ? ctx->actB.p : ctx->actA.p);
+    if (int rc = run_conv(ctx, l.d, cur, dst, h, w)) return rc;
+    if (l.pool_after) { h /= 2; w /= 2; }
+    cur = dst;
+  }
+  if (ho) *ho = h;
+  if (wo) *wo = w;
+  return WCT_OK;
+}
+
+// feat NHWC [h*w][C] -> planar image 3 x Ho x Wo.  `first` optionally overrides layer 0 (folded affine).
+int decode_impl(wct_ctx* ctx, int level, const float* feat, int h, int w, const ConvDesc* first, float* img) {
+  Module& m = ctx->mod[WCT_KIND_DEC][level];
+  if (!m.loaded) return fail(ctx, WCT_ERR_STATE, "decoder %d not loaded", level);
+  if (h < 2 || w < 2) return fail(ctx, WCT_ERR_INVALID, "feature %dx%d too small (reflect padding needs >= 2 samples)", h, w);
+  const size_t need = max_act_bytes(m, h, w, false);
+  if (int rc = ensure(ctx, ctx->actA, need)) return rc;
+  if (int rc = ensure(ctx, ctx->actB, need)) return rc;
+  const float* cur = feat;
+  int ch = h, cw = w;
+  for (size_t i = 0; i < m.layers.size(); ++i) {
+    const auto& l = m.layers[i];
+    const bool last = i + 1 == m.layers.size();
+    ConvDesc d = (i == 0 && first) ? *first : l.d;
+    if (i > 0 && m.layers[i - 1].up_after) { ch *= 2; cw *= 2; }
+    float* dst = last ? img : reinterpret_cast<float*>((i & 1) ? ctx->actB.p : ctx->actA.p);
+    if (int rc = run_conv(ctx, d, cur, dst, ch, cw)) return rc;
+    cur = dst;
+  }
+  return WCT_OK;
+}
+
+// layout of ctx->small (doubles): sum_c[512] sumsq_c[512*512] sum_s[512] sumsq_s[512*512] M[512*512] b[512] | info ints
+struct SmallView {
+  double *sum_c, *sumsq_c, *sum_s, *sumsq_s, *M, *b;
+  int* info;
+};
+constexpr size_t SMALL_BYTES = (3 * 512 * 512 + 3 * 512) * sizeof(double) + 64;
+
+int small_view(wct_ctx* ctx, SmallView& v) {
+  if (int rc = ensure(ctx, ctx->small, SMALL_BYTES)) return rc;
+  double* p = reinterpret_cast<double*>(ctx->small.p);
+  v.sum_c = p; p += 512;
+  v.sumsq_c = p; p += 512 * 512;
+  v.sum_s = p; p += 512;
+  v.sumsq_s = p; p += 512 * 512;
+  v.M = p; p += 512 * 512;
+  v.b = p; p += 512;
+  v.info = reinterpret_cast<int*>(p);
+  return WCT_OK;
+}
+
+int moments_impl(wct_ctx* ctx, const float* feat, int C, int h, int w, int x0, int x1, double* sum, double* sumsq) {
+  if (C < 4 || (C & 3) || C > 512) return fail(ctx, WCT_ERR_INVALID, "moments: C=%d must be a multiple of 4 in [4,512]", C);
+  if (h < 1 || x0 < 0 || x1 > w || x1 <= x0) return fail(ctx, WCT_ERR_INVALID, "moments: bad window h=%d w=%d [%d,%d)", h, w, x0, x1);
+  const long npix = (long)h * (x1 - x0);
+  const size_t wsb = moments_workspace_bytes(C, npix);
+  if (int rc = ensure(ctx, ctx->wsMom, wsb)) return rc;
+  ProfScope ps(ctx, "moments", 2.0 * C * C * npix, 4.0 * C * npix);
+  HIPCHK(ctx, launch_moments(feat, C, h, w, x0, x1, sum, sumsq, ctx->wsMom.p, ctx->wsMom.cap, ctx->stream));
+  return WCT_OK;
+}
+
+int solve_impl(wct_ctx* ctx, int C, double n_c, const double* sum_c, const double* sumsq_c, double n_s,
+               const double* sum_s, const double* sumsq_s, double alpha, double* M, double* b, int* info_dev) {
+  if (C < 2 || (C & 1) || C > 512) return fail(ctx, WCT_ERR_INVALID, "solve: C=%d must be even and <= 512", C);
+  if (n_c < 2 || n_s < 2) return fail(ctx, WCT_ERR_INVALID, "solve: unbiased covariance needs >= 2 pixels (n_c=%g n_s=%g)", n_c, n_s);
+  if (int rc = ensure(ctx, ctx->wsSolve, solve_workspace_bytes(C))) return rc;
+  ProfScope ps(ctx, "solve", 0, 0);
+  HIPCHK(ctx, launch_solve(C, n_c, sum_c, sumsq_c, n_s, sum_s, sumsq_s, alpha, 1e-10, nullptr, nullptr, M, b, info_dev,
+                           ctx->wsSolve.p, ctx->wsSolve.cap, ctx->stream));
+  return WCT_OK;
+}
+
+int fold_impl(wct_ctx* ctx, int level, const double* M, const double* b, ConvDesc& out) {
+  Module& m = ctx->mod[WCT_KIND_DEC][level];
+  if (!m.loaded) return fail(ctx, WCT_ERR_STATE, "decoder %d not loaded", level);
+  const LayerDev& l = m.layers[0];
+  const size_t wbytes = (size_t)l.d.cin_chunks * 36 * l.d.cout_pad * 4 * sizeof(float);
+  if (int rc = ensure(ctx, ctx->foldW, wbytes + l.d.cout_pad * sizeof(float))) return rc;
+  float* wpk = reinterpret_cast<float*>(ctx->foldW.p);
+  float* bias = wpk + wbytes / sizeof(float);
+  ProfScope ps(ctx, "fold_affine", 0, 0);
+  HIPCHK(ctx, launch_fold_affine(l.w_oihw, l.bias_raw, l.d.cout, l.d.cin, l.d.cout_pad, M, b, wpk, bias, ctx->stream));
+  out = l.d;
+  out.wpk = wpk;
+  out.bias = bias;
+  return WCT_OK;
+}
+
+int level_impl(wct_ctx* ctx, int level, const float* content, int H, int W, const float* style, int Hs, int Ws,
+               float alpha, float* out, int* Ho, int* Wo) {
+  Module& me = ctx->mod[WCT_KIND_ENC][level];
+  if (!me.loaded) return fail(ctx, WCT_ERR_STATE, "encoder %d not loaded", level);
+  const int C = me.layers.back().d.cout;
+  int h, w, hs, ws;
+  {
+    h = H; w = W; hs = Hs; ws = Ws;
+    for (int i = 1; i < level; ++i) { h /= 2; w /= 2; hs /= 2; ws /= 2; }
+  }
+  if (int rc = ensure(ctx, ctx->featC, (size_t)h * w * C * sizeof(float))) return rc;
+  if (int rc = ensure(ctx, ctx->featS, (size_t)hs * ws * C * sizeof(float))) return rc;
+  SmallView sv;
+  if (int rc = small_view(ctx, sv)) return rc;
+  float* fS = reinterpret_cast<float*>(ctx->featS.p);
+  float* fC = reinterpret_cast<float*>(ctx->featC.p);
+  // sF = encoder(styleImg); cF = encoder(contentImg)        (WCT.py:100-101)
+  if (int rc = encode_impl(ctx, level, style, Hs, Ws, fS, nullptr, nullptr)) return rc;
+  if (int rc = moments_impl(ctx, fS, C, hs, ws, 0, ws, sv.sum_s, sv.sumsq_s)) return rc;
+  if (int rc = encode_impl(ctx, level, content, H, W, fC, nullptr, nullptr)) return rc;
+  if (int rc = moments_impl(ctx, fC, C, h, w, 0, w, sv.sum_c, sv.sumsq_c)) return rc;
+  // csF = wct.transform(cF, sF, csF, alpha)                  (WCT.py:104) -- as an affine map
+  if (int rc = solve_impl(ctx, C, (double)h * w, sv.sum_c, sv.sumsq_c, (double)hs * ws, sv.sum_s, sv.sumsq_s, alpha, sv.M, sv.b, sv.info)) return rc;
+  // Img = decoder(csF)                                       (WCT.py:105) -- M, b folded into the first conv
+  ConvDesc first;
+  if (int rc = fold_impl(ctx, level, sv.M, sv.b, first)) return rc;
+  if (int rc = decode_impl(ctx, level, fC, h, w, &first, out)) return rc;
+  if (Ho) *Ho = h << (level - 1);
+  if (Wo) *Wo = w << (level - 1);
+  return WCT_OK;
+}
+
+}  // namespace
+
+// =====================================================================================================
+extern "C" {
+
+int wct_version(void) { return 1; }
+
+int wct_create(int device, wct_ctx** out) {
+  if (!out) return WCT_ERR_INVALID;
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return WCT_ERR_HIP;
+  if (hipSetDevice(device) != hipSuccess) return WCT_ERR_HIP;
+  wct_ctx* c = new (std::nothrow) wct_ctx();
+  if (!c) return WCT_ERR_NOMEM;
+  c->device = device;
+  *out = c;
+  return WCT_OK;
+}
+
+void wct_destroy(wct_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  prof_collect(ctx);
+  for (int k = 0; k < 2; ++k)
+    for (int l = 0; l < 6; ++l) free_module(ctx->mod[k][l]);
+  for (DevBuf* b : {&ctx->actA, &ctx->actB, &ctx->featC, &ctx->featS, &ctx->tmpT, &ctx->wsMom, &ctx->wsSolve, &ctx->small, &ctx->foldW}) release(*b);
+  delete ctx;
+}
+
+const char* wct_last_error(const wct_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int wct_set_stream(wct_ctx* ctx, void* s) {
+  if (!ctx) return WCT_ERR_INVALID;
+  ctx->stream = reinterpret_cast<hipStream_t>(s);
+  return WCT_OK;
+}
+
+int wct_sync(wct_ctx* ctx) {
+  if (!ctx) return WCT_ERR_INVALID;
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return WCT_OK;
+}
+
+int wct_load_module(wct_ctx* ctx, int kind, int level, int n_layers, const wct_layer* layers, const float* c0w,
+                    const float* c0b) {
+  if (!ctx) return WCT_ERR_INVALID;
+  if ((kind != WCT_KIND_ENC && kind != WCT_KIND_DEC) || !valid_level(level) || n_layers < 1 || !layers)
+    return fail(ctx, WCT_ERR_INVALID, "load_module: bad kind/level/layers (%d, %d, %d)", kind, level, n_layers);
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  for (int i = 0; i < n_layers; ++i) {
+    const wct_layer& L = layers[i];
+    if (!L.weight || !L.bias || L.cin < 1 || L.cout < 1 || L.cin > 512 || L.cout > 512)
+      return fail(ctx, WCT_ERR_INVALID, "load_module: layer %d has bad shape %d->%d or NULL weights", i, L.cin, L.cout);
+    if (i > 0 && layers[i - 1].cout != L.cin) return fail(ctx, WCT_ERR_INVALID, "load_module: layer %d cin %d != previous cout %d", i, L.cin, layers[i - 1].cout);
+    const bool first = i == 0, last = i == n_layers - 1;
+    if (kind == WCT_KIND_ENC && first && L.cin != 3) return fail(ctx, WCT_ERR_INVALID, "encoder must start from 3 channels");
+    if (kind == WCT_KIND_DEC && last && L.cout != 3) return fail(ctx, WCT_ERR_INVALID, "decoder must end in 3 channels");
+    if (!(kind == WCT_KIND_ENC && first) && (L.cin & 3)) return fail(ctx, WCT_ERR_INVALID, "layer %d: cin %d must be a multiple of 4", i, L.cin);
+    if (!(kind == WCT_KIND_DEC && last) && (L.cout & 3)) return fail(ctx, WCT_ERR_INVALID, "layer %d: cout %d must be a multiple of 4", i, L.cout);
+    if (kind == WCT_KIND_ENC && last && L.pool_after) return fail(ctx, WCT_ERR_INVALID, "encoder cannot end in a pool");
+    if (kind == WCT_KIND_DEC && last && L.up_after) return fail(ctx, WCT_ERR_INVALID, "decoder cannot end in an upsample");
+  }
+  Module& m = ctx->mod[kind][level];
+  free_module(m);
+  m.layers.resize(n_layers);
+  for (int i = 0; i < n_layers; ++i) {
+    const wct_layer& L = layers[i];
+    LayerDev& ld = m.layers[i];
+    const bool in3 = kind == WCT_KIND_ENC && i == 0;
+    const bool out3 = kind == WCT_KIND_DEC && i == n_layers - 1;
+    ld.pool_after = L.pool_after; ld.up_after = L.up_after;
+    ld.d.cin = L.cin; ld.d.cout = L.cout;
+    ld.d.cin_chunks = in3 ? 1 : (L.cin + 15) / 16;
+    ld.d.cout_pad = pad_cout(L.cout);
+    ld.d.flags = (in3 ? CONV_IN_NCHW3 : 0) | (out3 ? CONV_OUT_NCHW3 : 0) | (L.pool_after ? CONV_POOL_OUT : 0) |
+                 ((kind == WCT_KIND_DEC && i > 0 && layers[i - 1].up_after) ? CONV_UP_IN : 0);
+    std::vector<float> wpk, bias;
+    pack_weights(L.weight, L.bias, L.cout, L.cin, ld.d.cout_pad, in3, in3 ? c0w : nullptr, in3 ? c0b : nullptr, wpk, bias);
+    if (int rc = upload(ctx, &ld.wpk, wpk)) return rc;
+    if (int rc = upload(ctx, &ld.bias, bias)) return rc;
+    ld.d.wpk = ld.wpk; ld.d.bias = ld.bias;
+    if (kind == WCT_KIND_DEC && i == 0) {
+      std::vector<float> raw(L.weight, L.weight + (size_t)L.cout * L.cin * 9), rb(L.bias, L.bias + L.cout);
+      if (int rc = upload(ctx, &ld.w_oihw, raw)) return rc;
+      if (int rc = upload(ctx, &ld.bias_raw, rb)) return rc;
+    }
+  }
+  m.loaded = true;
+  return WCT_OK;
+}
+
+int wct_feature_shape(const wct_ctx* ctx, int level, int H, int W, int* C, int* h, int* w) {
+  if (!ctx || !valid_level(level) || H < 1 || W < 1) return WCT_ERR_INVALID;
+  const Module& m = ctx->mod[WCT_KIND_ENC][level];
+  if (!m.loaded) return WCT_ERR_STATE;
+  for (int i = 1; i < level; ++i) { H /= 2; W /= 2; }
+  if (C) *C = m.layers.back().d.cout;
+  if (h) *h = H;
+  if (w) *w = W;
+  return WCT_OK;
+}
+
+int wct_encode(wct_ctx* ctx, int level, const float* img, int H, int W, float* feat, int layout) {
+  if (!ctx) return WCT_ERR_INVALID;
+  if (!valid_level(level) || !img || !feat || H < 1 || W < 1) return fail(ctx, WCT_ERR_INVALID, "encode: bad arguments");
+  if (layout == WCT_LAYOUT_NHWC) return encode_impl(ctx, level, img, H, W, feat, nullptr, nullptr);
+  if (layout != WCT_LAYOUT_NCHW) return fail(ctx, WCT_ERR_INVALID, "encode: bad layout %d", layout);
+  int C, h, w;
+  if (int rc = wct_feature_shape(ctx, level, H, W, &C, &h, &w)) return fail(ctx, rc, "encoder %d not loaded", level);
+  if (int rc = ensure(ctx, ctx->tmpT, (size_t)h * w * C * sizeof(float))) return rc;
+  if (int rc = encode_impl(ctx, level, img, H, W, reinterpret_cast<float*>(ctx->tmpT.p), nullptr, nullptr)) return rc;
+  HIPCHK(ctx, launch_nhwc_to_nchw(reinterpret_cast<float*>(ctx->tmpT.p), feat, C, h * w, ctx->stream));
+  return WCT_OK;
+}
+
+int wct_decode(wct_ctx* ctx, int level, const float* feat, int h, int w, int layout, float* img) {
+  if (!ctx) return WCT_ERR_INVALID;
+  if (!valid_level(level) || !img || !feat || h < 1 || w < 1) return fail(ctx, WCT_ERR_INVALID, "decode: bad arguments");
+  Module& m = ctx->mod[WCT_KIND_DEC][level];
+  if (!m.loaded) return fail(ctx, WCT_ERR_STATE, "decoder %d not loaded", level);
+  const float* f = feat;
+  if (layout == WCT_LAYOUT_NCHW) {
+    const int C = m.layers[0].d.cin;
+    if (int rc = ensure(ctx, ctx->tmpT, (size_t)h * w * C * sizeof(float))) return rc;
+    HIPCHK(ctx, launch_nchw_to_nhwc(feat, reinterpret_cast<float*>(ctx->tmpT.p), C, h * w, ctx->stream));
+    f = reinterpret_cast<float*>(ctx->tmpT.p);
+  } else if (layout != WCT_LAYOUT_NHWC) {
+    return fail(ctx, WCT_ERR_INVALID, "decode: bad layout %d", layout);
+  }
+  return decode_impl(ctx, level, f, h, w, nullptr, img);
+}
+
+int wct_moments(wct_ctx* ctx, const float* feat, int C, int h, int w, int x0, int x1, double* sum, double* sumsq) {
+  if (!ctx) return WCT_ERR_INVALID;
+  if (!feat || !sum || !sumsq) return fail(ctx, WCT_ERR_INVALID, "moments: NULL pointer");
+  return moments_impl(ctx, feat, C, h, w, x0, x1, sum, sumsq);
+}
+
+int wct_solve(wct_ctx* ctx, int C, double n_c, const double* sum_c, const double* sumsq_c, double n_s,
+              const double* sum_s, const double* sumsq_s, double alpha, double* M, double* b, int* info) {
+  if (!ctx) return WCT_ERR_INVALID;
+  if (!sum_c || !sumsq_c || !sum_s || !sumsq_s || !M || !b) return fail(ctx, WCT_ERR_INVALID, "solve: NULL pointer");
+  SmallView sv;
+  if (int rc = small_view(ctx, sv)) return rc;
+  if (int rc = solve_impl(ctx, C, n_c, sum_c, sumsq_c, n_s, sum_s, sumsq_s, alpha, M, b, sv.info)) return rc;
+  if (info) {
+    HIPCHK(ctx, hipMemcpyAsync(info, sv.info, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  return WCT_OK;
+}
+
+int wct_apply(wct_ctx* ctx, const float* feat, int C, int h, int w, int layout, const double* M, const double* b, float* out) {
+  if (!ctx) return WCT_ERR_INVALID;
+  if (!feat || !M || !b || !out || h < 2 || w < 2 || C < 4 || (C & 3) || C > 512) return fail(ctx, WCT_ERR_INVALID, "apply: bad arguments");
+  const int cp = pad_cout(C), chunks = (C + 15) / 16;
+  const size_t wfl = (size_t)chunks * 36 * cp * 4;
+  const size_t fbytes = (size_t)h * w * C * sizeof(float);
+  if (int rc = ensure(ctx, ctx->foldW, (wfl + cp) * sizeof(float))) return rc;
+  float* wpk = reinterpret_cast<float*>(ctx->foldW.p);
+  float* bias = wpk + wfl;
+  HIPCHK(ctx, launch_pack_center_tap(M, b, C, cp, wpk, bias, ctx->stream));
+  ConvDesc d{};
+  d.cin = C; d.cout = C; d.cin_chunks = chunks; d.cout_pad = cp; d.flags = CONV_NO_RELU; d.wpk = wpk; d.bias = bias;
+  if (layout == WCT_LAYOUT_NHWC) return run_conv(ctx, d, feat, out, h, w);
+  if (layout != WCT_LAYOUT_NCHW) return fail(ctx, WCT_ERR_INVALID, "apply: bad layout %d", layout);
+  if (int rc = ensure(ctx, ctx->tmpT, 2 * fbytes)) return rc;
+  float* t0 = reinterpret_cast<float*>(ctx->tmpT.p);
+  float* t1 = t0 + (size_t)h * w * C;
+  HIPCHK(ctx, launch_nchw_to_nhwc(feat, t0, C, h * w, ctx->stream));
+  if (int rc = run_conv(ctx, d, t0, t1, h, w)) return rc;
+  HIPCHK(ctx, launch_nhwc_to_nchw(t1, out, C, h * w, ctx->stream));
+  return WCT_OK;
+}
+
+int wct_transform(wct_ctx* ctx, const float* cF, int C, int h, int w, const float* sF, int hs, int ws, float alpha,
+                  int layout, float* out) {
+  if (!ctx) return WCT_ERR_INVALID;
+  if (!cF || !sF || !out || h < 1 || w < 1 || hs < 1 || ws < 1) return fail(ctx, WCT_ERR_INVALID, "transform: bad arguments");
+  if (layout != WCT_LAYOUT_NHWC && layout != WCT_LAYOUT_NCHW) return fail(ctx, WCT_ERR_INVALID, "transform: bad layout %d", layout);
+  SmallView sv;
+  if (int rc = small_view(ctx, sv)) return rc;
+  const float *c = cF, *s = sF;
+  if (layout == WCT_LAYOUT_NCHW) {
+    if (int rc = ensure(ctx, ctx->featC, (size_t)h * w * C * sizeof(float))) return rc;
+    if (int rc = ensure(ctx, ctx->featS, (size_t)hs * ws * C * sizeof(float))) return rc;
+    HIPCHK(ctx, launch_nchw_to_nhwc(cF, reinterpret_cast<float*>(ctx->featC.p), C, h * w, ctx->stream));
+    HIPCHK(ctx, launch_nchw_to_nhwc(sF, reinterpret_cast<float*>(ctx->featS.p), C, hs * ws, ctx->stream));
+    c = reinterpret_cast<float*>(ctx->featC.p);
+    s = reinterpret_cast<float*>(ctx->featS.p);
+  }
+  if (int rc = moments_impl(ctx, c, C, h, w, 0, w, sv.sum_c, sv.sumsq_c)) return rc;
+  if (int rc = moments_impl(ctx, s, C, hs, ws, 0, ws, sv.sum_s, sv.sumsq_s)) return rc;
+  if (int rc = solve_impl(ctx, C, (double)h * w, sv.sum_c, sv.sumsq_c, (double)hs * ws, sv.sum_s, sv.sumsq_s, alpha, sv.M, sv.b, sv.info)) return rc;
+  if (h >= 2 && w >= 2) return wct_apply(ctx, cF, C, h, w, layout, sv.M, sv.b, out);
+  return fail(ctx, WCT_ERR_INVALID, "transform: feature %dx%d too small", h, w);
+}
+
+int wct_decode_affine(wct_ctx* ctx, int level, const float* feat, int h, int w, const double* M, const double* b, float* img) {
+  if (!ctx) return WCT_ERR_INVALID;
+  if (!valid_level(level) || !feat || !M || !b || !img) return fail(ctx, WCT_ERR_INVALID, "decode_affine: bad arguments");
+  ConvDesc first;
+  if (int rc = fold_impl(ctx, level, M, b, first)) return rc;
+  return decode_impl(ctx, level, feat, h, w, &first, img);
+}
+
+int wct_style_transfer_level(wct_ctx* ctx, int level, const float* content, int H, int W, const float* style, int Hs,
+                             int Ws, float alpha, float* out, int* Ho, int* Wo) {
+  if (!ctx) return WCT_ERR_INVALID;
+  if (!valid_level(level) || !content || !style || !out) return fail(ctx, WCT_ERR_INVALID, "style_transfer_level: bad arguments");
+  return level_impl(ctx, level, content, H, W, style, Hs, Ws, alpha, out, Ho, Wo);
+}
+
+int wct_stylize(wct_ctx* ctx, const float* content, int H, int W, const float* style, int Hs, int Ws, float alpha,
+                int num_run, float* out, int* Ho, int* Wo) {
+  if (!ctx) return WCT_ERR_INVALID;
+  if (!content || !style || !out || num_run < 1) return fail(ctx, WCT_ERR_INVALID, "stylize: bad arguments");
+  // `out` doubles as the running image: level L reads it and writes a (possibly smaller) image into a
+  // second buffer; ping-pong between `out` and tmpT.
+  const size_t img_bytes = (size_t)3 * H * W * sizeof(float);
+  if (int rc = ensure(ctx, ctx->tmpT, img_bytes)) return rc;
+  float* bufs[2] = {reinterpret_cast<float*>(ctx->tmpT.p), out};
+  const float* cur = content;
+  int h = H, w = W, which = (5 * num_run) & 1;  // so that the last level writes into `out`
+  for (int run = 0; run < num_run; ++run)
+    for (int level = 5; level >= 1; --level) {
+      int ho, wo;
+      float* dst = bufs[which];
+      if (int rc = level_impl(ctx, level, cur, h, w, style, Hs, Ws, alpha, dst, &ho, &wo)) return rc;
+      cur = dst; h = ho; w = wo; which ^= 1;
+    }
+  if (cur != out) HIPCHK(ctx, hipMemcpyAsync(out, cur, (size_t)3 * h * w * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+  if (Ho) *Ho = h;
+  if (Wo) *Wo = w;
+  return WCT_OK;
+}
+
+size_t wct_workspace_bytes(const wct_ctx* ctx, int H, int W, int Hs, int Ws) {
+  if (!ctx) return 0;
+  size_t act = 0, feat = 0, mom = 0;
+  for (int level = 1; level <= 5; ++level) {
+    const Module& e = ctx->mod[WCT_KIND_ENC][level];
+    const Module& d = ctx->mod[WCT_KIND_DEC][level];
+    if (!e.loaded || !d.loaded) continue;
+    int h = H, w = W, hs = Hs, ws = Ws;
+    for (int i = 1; i < level; ++i) { h /= 2; w /= 2; hs /= 2; ws /= 2; }
+    const int C = e.layers.back().d.cout;
+    act = std::max(act, std::max(max_act_bytes(e, H, W, true), max_act_bytes(e, Hs, Ws, true)));
+    act = std::max(act, max_act_bytes(d, h, w, false));
+    feat = std::max(feat, (size_t)std::max((size_t)h * w, (size_t)hs * ws) * C * sizeof(float));
+    mom = std::max(mom, std::max(moments_workspace_bytes(C, (long)h * w), moments_workspace_bytes(C, (long)hs * ws)));
+  }
+  return 2 * act + 2 * feat + mom + (size_t)3 * H * W * sizeof(float) + SMALL_BYTES + solve_workspace_bytes(512);
+}
+
+int wct_reserve(wct_ctx* ctx, int H, int W, int Hs, int Ws) {
+  if (!ctx) return WCT_ERR_INVALID;
+  size_t act = 0, featc = 0, feats = 0, mom = 0;
+  int cmax = 2;
+  for (int level = 1; level <= 5; ++level) {
+    const Module& e = ctx->mod[WCT_KIND_ENC][level];
+    const Module& d = ctx->mod[WCT_KIND_DEC][level];
+    if (!e.loaded || !d.loaded) continue;
+    int h = H, w = W, hs = Hs, ws = Ws;
+    for (int i = 1; i < level; ++i) { h /= 2; w /= 2; hs /= 2; ws /= 2; }
+    const int C = e.layers.back().d.cout;
+    cmax = std::max(cmax, C);
+    act = std::max(act, std::max(max_act_bytes(e, H, W, true), max_act_bytes(e, Hs, Ws, true)));
+    act = std::max(act, max_act_bytes(d, h, w, false));
+    featc = std::max(featc, (size_t)h * w * C * sizeof(float));
+    feats = std::max(feats, (size_t)hs * ws * C * sizeof(float));
+    mom = std::max(mom, std::max(moments_workspace_bytes(C, (long)h * w), moments_workspace_bytes(C, (long)hs * ws)));
+    const LayerDev& l0 = d.layers[0];
+    if (int rc = ensure(ctx, ctx->foldW, ((size_t)l0.d.cin_chunks * 36 * l0.d.cout_pad * 4 + l0.d.cout_pad) * sizeof(float))) return rc;
+  }
+  if (int rc = ensure(ctx, ctx->actA, act)) return rc;
+  if (int rc = ensure(ctx, ctx->actB, act)) return rc;
+  if (int rc = ensure(ctx, ctx->featC, featc)) return rc;
+  if (int rc = ensure(ctx, ctx->featS, feats)) return rc;
+  if (int rc = ensure(ctx, ctx->wsMom, mom)) return rc;
+  if (int rc = ensure(ctx, ctx->tmpT, (size_t)3 * H * W * sizeof(float))) return rc;
+  if (int rc = ensure(ctx, ctx->wsSolve, solve_workspace_bytes(cmax))) return rc;
+  SmallView sv;
+  return small_view(ctx, sv);
+}
+
+int wct_profile_enable(wct_ctx* ctx, int on) {
+  if (!ctx) return WCT_ERR_INVALID;
+  if (!on) prof_collect(ctx);
+  ctx->prof = on != 0;
+  return WCT_OK;
+}
+
+int wct_profile_reset(wct_ctx* ctx) {
+  if (!ctx) return WCT_ERR_INVALID;
+  prof_collect(ctx);
+  ctx->prof_acc.clear();
+  return WCT_OK;
+}
+
+int wct_profile_read(wct_ctx* ctx, wct_prof_entry* entries, int max_entries, int* n_entries) {
+  if (!ctx || !n_entries) return WCT_ERR_INVALID;
+  prof_collect(ctx);
+  int n = 0;
+  for (auto& kv : ctx->prof_acc) {
+    if (entries && n < max_entries) entries[n] = kv.second;
+    ++n;
+  }
+  *n_entries = n;
+  return WCT_OK;
+}
+
+}  // extern "C"

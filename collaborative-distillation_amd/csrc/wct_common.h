@@ -1,0 +1,56 @@
+// Shared declarations of libwct_hip (gfx950 only).  Internal -- the public C ABI is include/wct_hip.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+// ---- conv3x3 (reflect-pad + 3x3 conv + bias + ReLU, optional fused nearest-x2 input / 2x2 max-pool output)
+enum ConvFlags : int {
+  CONV_IN_NCHW3 = 1,   // input is a planar 3xHxW image (first encoder conv, conv0 folded in)
+  CONV_UP_IN = 2,      // input tensor is stored at (H/2, W/2): nearest x2 fused into the tile load
+  CONV_POOL_OUT = 4,   // write max over 2x2 (floor mode) instead of the full-resolution output
+  CONV_OUT_NCHW3 = 8,  // output is a planar 3xHxW image (last decoder conv)
+  CONV_NO_RELU = 16,   // affine only (used by wct_apply: centre-tap 1x1)
+};
+
+struct ConvDesc {
+  int cin, cout;       // logical channels
+  int cin_chunks;      // ceil(cin/16)  (1 for CONV_IN_NCHW3)
+  int cout_pad;        // multiple of 16
+  int flags;
+  const float* wpk;    // device, packed [chunk][tap][kq][cout_pad][4]  (IN_NCHW3: [tap][4][cout_pad])
+  const float* bias;   // device, [cout_pad]
+};
+
+// Launch one conv layer.  (H, W) = spatial size the convolution runs at (after the fused upsample,
+// before the fused pool).  `in` is NHWC [inH*inW][cin] (or planar 3xHxW), `out` NHWC or planar.
+hipError_t launch_conv3x3(const ConvDesc& d, const float* in, float* out, int H, int W, hipStream_t s);
+
+// ---- layout
+hipError_t launch_nhwc_to_nchw(const float* in, float* out, int C, int npix, hipStream_t s);
+hipError_t launch_nchw_to_nhwc(const float* in, float* out, int C, int npix, hipStream_t s);
+
+// ---- moments: raw sums  sum[c] = SUM_p x[p][c],  sumsq[a][b] = SUM_p x[p][a] x[p][b]   (fp64)
+size_t moments_workspace_bytes(int C, long npix);
+// window = rows [0,h) x cols [x0,x1) of an NHWC map of width wfull
+hipError_t launch_moments(const float* feat_nhwc, int C, int h, int wfull, int x0, int x1, double* sum,
+                          double* sumsq, void* workspace, size_t workspace_bytes, hipStream_t s);
+
+// ---- solve: (n, sum, sumsq) x2 -> M (C x C), b (C)   csF = M cF + b   (util_wct.py:62-131, 219)
+size_t solve_workspace_bytes(int C);
+hipError_t launch_solve(int C, double n_c, const double* sum_c, const double* sumsq_c, double n_s,
+                        const double* sum_s, const double* sumsq_s, double alpha, double rel_thresh,
+                        float* M_f32, float* b_f32, double* M_f64, double* b_f64, int* info,
+                        void* workspace, size_t workspace_bytes, hipStream_t s);
+
+// ---- fold csF = M x + b into a decoder's first conv:  W' = W o M, b' = bias + W o b
+//      w_oihw: device [cout][cin][3][3] fp32 (original weights), out: packed weights + bias for ConvDesc
+hipError_t launch_fold_affine(const float* w_oihw, const float* bias, int cout, int cin, int cout_pad,
+                              const double* M, const double* b, float* wpk_out, float* bias_out,
+                              hipStream_t s);
+// pack [cout][cin][3][3] (+ bias) into the conv kernel's layout (device side, used for the apply conv)
+hipError_t launch_pack_center_tap(const double* M, const double* b, int C, int cout_pad, float* wpk_out,
+                                  float* bias_out, hipStream_t s);

@@ -1,0 +1,92 @@
+"""ctypes binding of libwct_hip.so (the C ABI declared in include/wct_hip.h).
+
+The product path has no CPU fallback: if the HIP library is missing or a call fails this module raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, byref, c_char_p, c_double, c_float, c_int, c_long, c_size_t, c_void_p
+
+_PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(_PKG, "libwct_hip.so")
+
+WCT_OK, WCT_ERR_INVALID, WCT_ERR_HIP, WCT_ERR_NOMEM, WCT_ERR_STATE = 0, -1, -2, -3, -4
+KIND_ENC, KIND_DEC = 0, 1
+LAYOUT_NHWC, LAYOUT_NCHW = 0, 1
+
+# every symbol include/wct_hip.h declares (tests check that the built library exports all of them)
+SYMBOLS = [
+    "wct_version", "wct_create", "wct_destroy", "wct_last_error", "wct_set_stream", "wct_sync",
+    "wct_load_module", "wct_feature_shape", "wct_encode", "wct_decode", "wct_moments", "wct_solve",
+    "wct_apply", "wct_transform", "wct_decode_affine", "wct_style_transfer_level", "wct_stylize",
+    "wct_workspace_bytes", "wct_reserve", "wct_profile_enable", "wct_profile_reset", "wct_profile_read",
+]
+
+
+class WctLayer(ctypes.Structure):
+    _fields_ = [("cin", c_int), ("cout", c_int), ("pool_after", c_int), ("up_after", c_int),
+                ("weight", POINTER(c_float)), ("bias", POINTER(c_float))]
+
+
+class WctProfEntry(ctypes.Structure):
+    _fields_ = [("name", ctypes.c_char * 48), ("ms", c_double), ("flops", c_double), ("bytes", c_double),
+                ("launches", c_long)]
+
+
+class WctError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libwct_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    """dlopen the in-tree library.  Raises ImportError when it has not been built
+    (`python -c 'import __graft_entry__ as g; g.build()'` or collaborative-distillation_amd/build.sh)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("libwct_hip.so not found at %s -- build it with collaborative-distillation_amd/build.sh; "
+                          "there is no CPU fallback" % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    fp, dp, ip = POINTER(c_float), POINTER(c_double), POINTER(c_int)
+    vp = c_void_p  # device pointers travel as integers
+    lib.wct_version.restype = c_int
+    lib.wct_create.argtypes = [c_int, POINTER(c_void_p)]
+    lib.wct_destroy.argtypes = [c_void_p]
+    lib.wct_destroy.restype = None
+    lib.wct_last_error.argtypes = [c_void_p]
+    lib.wct_last_error.restype = c_char_p
+    lib.wct_set_stream.argtypes = [c_void_p, c_void_p]
+    lib.wct_sync.argtypes = [c_void_p]
+    lib.wct_load_module.argtypes = [c_void_p, c_int, c_int, c_int, POINTER(WctLayer), fp, fp]
+    lib.wct_feature_shape.argtypes = [c_void_p, c_int, c_int, c_int, ip, ip, ip]
+    lib.wct_encode.argtypes = [c_void_p, c_int, vp, c_int, c_int, vp, c_int]
+    lib.wct_decode.argtypes = [c_void_p, c_int, vp, c_int, c_int, c_int, vp]
+    lib.wct_moments.argtypes = [c_void_p, vp, c_int, c_int, c_int, c_int, c_int, vp, vp]
+    lib.wct_solve.argtypes = [c_void_p, c_int, c_double, vp, vp, c_double, vp, vp, c_double, vp, vp, ip]
+    lib.wct_apply.argtypes = [c_void_p, vp, c_int, c_int, c_int, c_int, vp, vp, vp]
+    lib.wct_transform.argtypes = [c_void_p, vp, c_int, c_int, c_int, vp, c_int, c_int, c_float, c_int, vp]
+    lib.wct_decode_affine.argtypes = [c_void_p, c_int, vp, c_int, c_int, vp, vp, vp]
+    lib.wct_style_transfer_level.argtypes = [c_void_p, c_int, vp, c_int, c_int, vp, c_int, c_int, c_float, vp, ip, ip]
+    lib.wct_stylize.argtypes = [c_void_p, vp, c_int, c_int, vp, c_int, c_int, c_float, c_int, vp, ip, ip]
+    lib.wct_workspace_bytes.argtypes = [c_void_p, c_int, c_int, c_int, c_int]
+    lib.wct_workspace_bytes.restype = c_size_t
+    lib.wct_reserve.argtypes = [c_void_p, c_int, c_int, c_int, c_int]
+    lib.wct_profile_enable.argtypes = [c_void_p, c_int]
+    lib.wct_profile_reset.argtypes = [c_void_p]
+    lib.wct_profile_read.argtypes = [c_void_p, POINTER(WctProfEntry), c_int, ip]
+    _lib = lib
+    return lib
+
+
+def check(lib, ctx, rc):
+    if rc != WCT_OK:
+        msg = lib.wct_last_error(ctx).decode("utf-8", "replace") if ctx else "no context"
+        if rc == WCT_ERR_INVALID:
+            raise ValueError("libwct_hip: " + msg)
+        raise WctError(rc, msg)

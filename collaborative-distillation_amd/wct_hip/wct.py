@@ -1,0 +1,328 @@
+"""Host-side mirror of the reference's call surface for the WCT stylisation path.
+
+Same names, argument meaning and error behaviour as `PytorchWCT/util_wct.py` / `WCT.py`:
+
+    wct = WCT(args)                      # util_wct.py:30-59   (args.mode, args.e1..e5, args.d1..d5, args.alpha)
+    sF  = wct.e5(styleImg)               # WCT.py:100          NCHW fp32 CUDA tensors in and out
+    csF = wct.transform(cF, sF, csF, a)  # util_wct.py:210-223
+    img = wct.d5(csF)                    # WCT.py:105
+    img = styleTransfer(wct.e5, wct.d5, contentImg, styleImg, csF)   # WCT.py:98-106
+
+All arithmetic happens in libwct_hip.so (hand-written gfx950 kernels) through the C ABI of
+include/wct_hip.h; PyTorch only provides device memory, the current HIP stream and (sharded.py)
+torch.distributed.  There is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import byref, c_int, c_void_p
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import lib as _lib
+from . import model_zoo
+
+_PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DEFAULT_16X_WEIGHTS = os.path.join(_PKG, "weights", "16x.npz")
+
+
+def _fptr(a: np.ndarray):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+
+
+def _load_state(path: str) -> Dict[str, np.ndarray]:
+    """A module's tensors from the reference's own checkpoint format (`{"epoch","model"}` or a bare
+    state_dict, model_cd.py:712-718) -- torch is used for un-pickling only."""
+    sd = torch.load(path, map_location="cpu", weights_only=False)
+    if isinstance(sd, dict) and "model" in sd:
+        sd = sd["model"]
+    return {k: v.detach().cpu().numpy().astype(np.float32) for k, v in sd.items()}
+
+
+class _Module:
+    """`wct.e5` / `wct.d5`: callable like the reference's nn.Module on NCHW fp32 CUDA tensors."""
+
+    def __init__(self, owner: "WCT", kind: str, level: int):
+        self.owner, self.kind, self.level = owner, kind, level
+
+    def __call__(self, x: torch.Tensor) -> torch.Tensor:
+        if self.kind == "enc":
+            return self.owner.encode(self.level, x)
+        return self.owner.decode(self.level, x)
+
+    forward = __call__
+
+    def __repr__(self):
+        return "<wct_hip %s level %d (%s)>" % (self.kind, self.level, self.owner.mode)
+
+
+class WCT:
+    """Drop-in for util_wct.WCT.  `args` needs `.mode` ("16x" | "original" | None) and may carry
+    `.e1..e5/.d1..d5` checkpoint paths (reference format, WCT.py:36-58), `.alpha`, `.numpy`.
+    `weights` (a dict as produced by model_zoo.load_npz_weights / synth_weights) overrides the paths;
+    with neither, mode 16x loads the packaged blob converted from the reference's checkpoints."""
+
+    def __init__(self, args, weights: Optional[Dict[str, np.ndarray]] = None, device: Optional[int] = None):
+        mode = getattr(args, "mode", None)
+        if mode is None:
+            mode = "original"
+        if mode not in model_zoo.MODES:
+            # the reference prints "Wrong mode. Please check." and exit(1)s (util_wct.py:57-59)
+            raise ValueError("Wrong mode. Please check.")
+        if getattr(args, "numpy", False):
+            # --numpy adds +I to the content covariance (util_wct.py:143): a different operator, not the parity target
+            raise NotImplementedError("--numpy (whiten_and_color_np) is not provided by the HIP path")
+        if not torch.cuda.is_available():
+            raise RuntimeError("wct_hip needs a ROCm GPU (torch.cuda.is_available() is False); there is no CPU path")
+        self.args = args
+        self.mode = mode
+        self.alpha = float(getattr(args, "alpha", 1.0))
+        self.device = torch.cuda.current_device() if device is None else int(device)
+        self._lib = _lib.load()
+        self._ctx = c_void_p()
+        _lib.check(self._lib, None, self._lib.wct_create(self.device, byref(self._ctx)))
+        if weights is None:
+            weights = self._weights_from_args(args, mode)
+        self._load_modules(weights)
+        for k in range(1, 6):
+            setattr(self, "e%d" % k, _Module(self, "enc", k))
+            setattr(self, "d%d" % k, _Module(self, "dec", k))
+
+    # ------------------------------------------------------------------ construction
+    @staticmethod
+    def _weights_from_args(args, mode) -> Dict[str, np.ndarray]:
+        paths = {("e%d" % k): getattr(args, "e%d" % k, None) for k in range(1, 6)}
+        paths.update({("d%d" % k): getattr(args, "d%d" % k, None) for k in range(1, 6)})
+        have = [p for p in paths.values() if p and os.path.exists(p)]
+        if len(have) == 10 and all(p.endswith(".pth") for p in have):
+            w = {}
+            for key, p in paths.items():
+                for n, v in _load_state(p).items():
+                    if "aux" not in n:  # conv{k}1_aux heads are training-only (model_cd.py:700-704)
+                        w["%s.%s" % (key, n)] = v
+            return w
+        if mode == "16x":
+            return model_zoo.load_npz_weights(DEFAULT_16X_WEIGHTS)
+        raise FileNotFoundError("mode 'original' needs the torch7 checkpoints of README.md:26 (not in the reference "
+                                "snapshot; load_lua is gone from torch>=1.0) -- pass weights=... instead")
+
+    def _load_modules(self, w: Dict[str, np.ndarray]):
+        self._keep = []  # host arrays must outlive wct_load_module only, but keep them for clarity
+        for k in range(1, 6):
+            for kind, kid, layers in (("enc", _lib.KIND_ENC, model_zoo.encoder_layers(self.mode, k)),
+                                      ("dec", _lib.KIND_DEC, model_zoo.decoder_layers(self.mode, k))):
+                key = model_zoo.module_key(kind, k)
+                arr = (_lib.WctLayer * len(layers))()
+                hold = []
+                for i, l in enumerate(layers):
+                    wt = np.ascontiguousarray(w["%s.%s.weight" % (key, l.name)], np.float32)
+                    bs = np.ascontiguousarray(w["%s.%s.bias" % (key, l.name)], np.float32)
+                    if wt.shape != (l.cout, l.cin, 3, 3):
+                        raise ValueError("%s.%s: weight shape %s != %s" % (key, l.name, wt.shape, (l.cout, l.cin, 3, 3)))
+                    hold += [wt, bs]
+                    arr[i] = _lib.WctLayer(l.cin, l.cout, int(l.pool_after), int(l.up_after), _fptr(wt), _fptr(bs))
+                c0w = c0b = None
+                if kind == "enc":
+                    c0w = np.ascontiguousarray(w[key + ".conv0.weight"], np.float32).reshape(9)
+                    c0b = np.ascontiguousarray(w[key + ".conv0.bias"], np.float32).reshape(3)
+                    hold += [c0w, c0b]
+                rc = self._lib.wct_load_module(self._ctx, kid, k, len(layers), arr,
+                                               _fptr(c0w) if c0w is not None else None,
+                                               _fptr(c0b) if c0b is not None else None)
+                _lib.check(self._lib, self._ctx, rc)
+
+    def __del__(self):
+        try:
+            if getattr(self, "_ctx", None) and self._ctx.value:
+                self._lib.wct_destroy(self._ctx)
+                self._ctx = c_void_p()
+        except Exception:
+            pass
+
+    def cuda(self, device=None):  # `WCT(args).cuda()` (WCT.py:97): weights already live on the GPU
+        return self
+
+    def eval(self):
+        return self
+
+    # ------------------------------------------------------------------ helpers
+    def _stream(self):
+        self._lib.wct_set_stream(self._ctx, c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
+
+    def _img(self, x: torch.Tensor) -> torch.Tensor:
+        if x.dim() == 4:
+            if x.shape[0] != 1:
+                raise ValueError("batch size must be 1 (the reference's DataLoader uses batch_size=1, WCT.py:92)")
+            x = x[0]
+        if x.dim() != 3 or x.shape[0] != 3:
+            raise ValueError("expected a [1,3,H,W] or [3,H,W] image, got %s" % (tuple(x.shape),))
+        return x.to(device="cuda:%d" % self.device, dtype=torch.float32).contiguous()
+
+    def _chk(self, rc):
+        _lib.check(self._lib, self._ctx, rc)
+
+    def feature_shape(self, level: int, H: int, W: int):
+        C, h, w = c_int(), c_int(), c_int()
+        self._chk(self._lib.wct_feature_shape(self._ctx, level, H, W, byref(C), byref(h), byref(w)))
+        return C.value, h.value, w.value
+
+    # ------------------------------------------------------------------ reference surface
+    @torch.no_grad()
+    def encode(self, level: int, img: torch.Tensor, layout: str = "nchw") -> torch.Tensor:
+        x = self._img(img)
+        H, W = int(x.shape[1]), int(x.shape[2])
+        C, h, w = self.feature_shape(level, H, W)
+        nchw = layout == "nchw"
+        out = torch.empty((1, C, h, w) if nchw else (1, h, w, C), device=x.device, dtype=torch.float32)
+        self._stream()
+        self._chk(self._lib.wct_encode(self._ctx, level, x.data_ptr(), H, W, out.data_ptr(),
+                                       _lib.LAYOUT_NCHW if nchw else _lib.LAYOUT_NHWC))
+        return out
+
+    @torch.no_grad()
+    def decode(self, level: int, feat: torch.Tensor, layout: str = "nchw") -> torch.Tensor:
+        f = feat[0] if feat.dim() == 4 else feat
+        f = f.to(device="cuda:%d" % self.device, dtype=torch.float32).contiguous()
+        nchw = layout == "nchw"
+        C = model_zoo.feature_channels(self.mode, level)
+        if nchw:
+            c, h, w = (int(s) for s in f.shape)
+        else:
+            h, w, c = (int(s) for s in f.shape)
+        if c != C:
+            raise ValueError("decoder %d expects %d channels, got %d" % (level, C, c))
+        out = torch.empty((1, 3, h << (level - 1), w << (level - 1)), device=f.device, dtype=torch.float32)
+        self._stream()
+        self._chk(self._lib.wct_decode(self._ctx, level, f.data_ptr(), h, w,
+                                       _lib.LAYOUT_NCHW if nchw else _lib.LAYOUT_NHWC, out.data_ptr()))
+        return out
+
+    @torch.no_grad()
+    def transform(self, cF: torch.Tensor, sF: torch.Tensor, csF: Optional[torch.Tensor] = None,
+                  alpha: Optional[float] = None) -> torch.Tensor:
+        """util_wct.py:210-223.  cF [C,h,w], sF [C,h',w'] fp32 (CPU like the reference, or CUDA) ->
+        csF [1,C,h,w] fp32 on the GPU.  If `csF` is given it is resized in place, filled and returned
+        (the reference's `csF.data.resize_().copy_()`, which silently stopped working in torch>=1.1)."""
+        alpha = self.alpha if alpha is None else float(alpha)
+        dev = "cuda:%d" % self.device
+        c = (cF[0] if cF.dim() == 4 else cF).to(device=dev, dtype=torch.float32).contiguous()
+        s = (sF[0] if sF.dim() == 4 else sF).to(device=dev, dtype=torch.float32).contiguous()
+        if c.dim() != 3 or s.dim() != 3 or c.shape[0] != s.shape[0]:
+            raise ValueError("transform expects cF [C,h,w] and sF [C,h',w'] with equal C")
+        C, h, w = (int(v) for v in c.shape)
+        hs, ws = int(s.shape[1]), int(s.shape[2])
+        out = torch.empty((1, C, h, w), device=dev, dtype=torch.float32)
+        self._stream()
+        self._chk(self._lib.wct_transform(self._ctx, c.data_ptr(), C, h, w, s.data_ptr(), hs, ws, alpha,
+                                          _lib.LAYOUT_NCHW, out.data_ptr()))
+        if csF is not None and csF.is_cuda:
+            csF.resize_(out.shape).copy_(out)
+            return csF
+        return out
+
+    # ------------------------------------------------------------------ split form (used by the sharded path)
+    @torch.no_grad()
+    def moments(self, feat_nhwc: torch.Tensor, x0: int = 0, x1: Optional[int] = None):
+        """Raw fp64 sums over columns [x0,x1) of an NHWC feature [1,h,w,C]: (n, sum[C], sumsq[C,C])."""
+        f = feat_nhwc[0] if feat_nhwc.dim() == 4 else feat_nhwc
+        h, w, C = (int(v) for v in f.shape)
+        x1 = w if x1 is None else x1
+        s = torch.empty(C, device=f.device, dtype=torch.float64)
+        ss = torch.empty(C, C, device=f.device, dtype=torch.float64)
+        self._stream()
+        self._chk(self._lib.wct_moments(self._ctx, f.data_ptr(), C, h, w, x0, x1, s.data_ptr(), ss.data_ptr()))
+        return float(h * (x1 - x0)), s, ss
+
+    @torch.no_grad()
+    def solve(self, n_c, sum_c, sumsq_c, n_s, sum_s, sumsq_s, alpha: Optional[float] = None, want_info=False):
+        alpha = self.alpha if alpha is None else float(alpha)
+        C = int(sum_c.numel())
+        M = torch.empty(C, C, device=sum_c.device, dtype=torch.float64)
+        b = torch.empty(C, device=sum_c.device, dtype=torch.float64)
+        info = (c_int * 2)()
+        self._stream()
+        self._chk(self._lib.wct_solve(self._ctx, C, float(n_c), sum_c.data_ptr(), sumsq_c.data_ptr(), float(n_s),
+                                      sum_s.data_ptr(), sumsq_s.data_ptr(), alpha, M.data_ptr(), b.data_ptr(),
+                                      info if want_info else None))
+        return (M, b, (info[0], info[1])) if want_info else (M, b)
+
+    @torch.no_grad()
+    def decode_affine(self, level: int, feat_nhwc: torch.Tensor, M: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+        f = feat_nhwc[0] if feat_nhwc.dim() == 4 else feat_nhwc
+        h, w, _ = (int(v) for v in f.shape)
+        out = torch.empty((1, 3, h << (level - 1), w << (level - 1)), device=f.device, dtype=torch.float32)
+        self._stream()
+        self._chk(self._lib.wct_decode_affine(self._ctx, level, f.data_ptr(), h, w, M.data_ptr(), b.data_ptr(), out.data_ptr()))
+        return out
+
+    # ------------------------------------------------------------------ fused level / cascade
+    @torch.no_grad()
+    def style_transfer_level(self, level: int, contentImg: torch.Tensor, styleImg: torch.Tensor,
+                             alpha: Optional[float] = None) -> torch.Tensor:
+        alpha = self.alpha if alpha is None else float(alpha)
+        c, s = self._img(contentImg), self._img(styleImg)
+        H, W, Hs, Ws = int(c.shape[1]), int(c.shape[2]), int(s.shape[1]), int(s.shape[2])
+        _, h, w = self.feature_shape(level, H, W)
+        out = torch.empty((1, 3, h << (level - 1), w << (level - 1)), device=c.device, dtype=torch.float32)
+        ho, wo = c_int(), c_int()
+        self._stream()
+        self._chk(self._lib.wct_style_transfer_level(self._ctx, level, c.data_ptr(), H, W, s.data_ptr(), Hs, Ws, alpha,
+                                                     out.data_ptr(), byref(ho), byref(wo)))
+        assert (ho.value, wo.value) == tuple(out.shape[2:])
+        return out
+
+    @torch.no_grad()
+    def stylize(self, contentImg: torch.Tensor, styleImg: torch.Tensor, alpha: Optional[float] = None,
+                num_run: int = 1, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """The 5 -> 1 cascade of WCT.py:120-125 in one call (no host round trips, no allocation after the
+        first call of a size)."""
+        alpha = self.alpha if alpha is None else float(alpha)
+        c, s = self._img(contentImg), self._img(styleImg)
+        H, W, Hs, Ws = int(c.shape[1]), int(c.shape[2]), int(s.shape[1]), int(s.shape[2])
+        if out is None:
+            out = torch.empty((3, H, W), device=c.device, dtype=torch.float32)
+        ho, wo = c_int(), c_int()
+        self._stream()
+        self._chk(self._lib.wct_stylize(self._ctx, c.data_ptr(), H, W, s.data_ptr(), Hs, Ws, alpha, int(num_run),
+                                        out.data_ptr(), byref(ho), byref(wo)))
+        return out.view(-1)[: 3 * ho.value * wo.value].view(1, 3, ho.value, wo.value)
+
+    def reserve(self, H, W, Hs, Ws):
+        self._chk(self._lib.wct_reserve(self._ctx, H, W, Hs, Ws))
+
+    def sync(self):
+        self._chk(self._lib.wct_sync(self._ctx))
+
+    # ------------------------------------------------------------------ profiling (bench.py roofline leg)
+    def profile(self, on: bool):
+        self._chk(self._lib.wct_profile_enable(self._ctx, int(on)))
+
+    def profile_reset(self):
+        self._chk(self._lib.wct_profile_reset(self._ctx))
+
+    def profile_read(self):
+        n = c_int()
+        buf = (_lib.WctProfEntry * 64)()
+        self._chk(self._lib.wct_profile_read(self._ctx, buf, 64, byref(n)))
+        return [{"name": buf[i].name.decode(), "ms": buf[i].ms, "flops": buf[i].flops, "bytes": buf[i].bytes,
+                 "launches": buf[i].launches} for i in range(min(n.value, 64))]
+
+
+@torch.no_grad()
+def styleTransfer(encoder, decoder, contentImg, styleImg, csF=None, alpha=None):
+    """WCT.py:98-106.  With an encoder/decoder pair of one wct_hip.WCT level this runs the fused HIP
+    level (features never leave HBM, M/b folded into the decoder); otherwise it falls back to the
+    reference's literal op sequence on the given callables (still GPU: they are wct_hip modules)."""
+    if isinstance(encoder, _Module) and isinstance(decoder, _Module) and encoder.owner is decoder.owner \
+            and encoder.level == decoder.level and encoder.kind == "enc" and decoder.kind == "dec":
+        return encoder.owner.style_transfer_level(encoder.level, contentImg, styleImg, alpha)
+    owner = getattr(encoder, "owner", None) or getattr(decoder, "owner", None)
+    if owner is None:
+        raise TypeError("styleTransfer needs wct_hip modules")
+    sF = encoder(styleImg)
+    cF = encoder(contentImg)
+    csF = owner.transform(cF.squeeze(0), sF.squeeze(0), csF, alpha)
+    return decoder(csF)

@@ -1,0 +1,129 @@
+/* libwct_hip -- C ABI of the MI355X-native WCT stylisation path.
+ *
+ * Drop-in boundary for ONE path of MingSun-Tse/Collaborative-Distillation: the 5-level encode ->
+ * whitening/colouring transform -> decode cascade of `PytorchWCT/WCT.py --mode 16x|original`.
+ * The reference has no FFI of its own; its boundary is the Python call surface of WCT.py / util_wct.py.
+ * Each entry point below names the reference interface it replaces (paths relative to the reference
+ * repository).  INTEGRATION.md shows the ctypes binding a maintainer adds on the reference side.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative WCT_ERR_* code; wct_last_error() has the text.
+ *     Nothing ever calls exit() (the reference does on a bad mode, util_wct.py:57-59).
+ *   - all tensor arguments are DEVICE pointers to fp32 unless the name says host / f64; images are planar
+ *     3 x H x W (the reference's NCHW with N = 1); feature maps are NHWC (layout 0, native) or NCHW
+ *     (layout 1, the reference's layout) as selected by `layout`.
+ *   - a context is bound to one device and one HIP stream; calls are asynchronous on that stream.
+ *     One context per GPU / rank; a context is not thread-safe.
+ *   - the caller owns every buffer it passes; the context owns weights and an internal workspace that
+ *     grows on first use of a size (no allocation on later calls of the same or smaller size).
+ */
+#ifndef WCT_HIP_H
+#define WCT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WCT_OK 0
+#define WCT_ERR_INVALID (-1) /* bad argument (shape, level, layout, NULL) */
+#define WCT_ERR_HIP (-2)     /* a HIP runtime call failed */
+#define WCT_ERR_NOMEM (-3)   /* device allocation failed */
+#define WCT_ERR_STATE (-4)   /* module for this level not loaded */
+
+#define WCT_KIND_ENC 0
+#define WCT_KIND_DEC 1
+#define WCT_LAYOUT_NHWC 0
+#define WCT_LAYOUT_NCHW 1
+
+typedef struct wct_ctx wct_ctx;
+
+/* One `relu(conv3x3(reflect_pad(x)))` stage, in execution order.
+ * weight: HOST fp32 OIHW [cout][cin][3][3]; bias: HOST fp32 [cout] -- the tensors of the reference's
+ * state_dict (model/model_cd.py:712-718).  pool_after: MaxPool2d(2,2) follows (encoder);
+ * up_after: UpsamplingNearest2d(2) follows (decoder). */
+typedef struct wct_layer {
+  int cin, cout;
+  int pool_after, up_after;
+  const float* weight;
+  const float* bias;
+} wct_layer;
+
+/* per-kernel-family timing collected when profiling is enabled (bench.py's roofline leg) */
+typedef struct wct_prof_entry {
+  char name[48];     /* e.g. "conv3x3<ct=8>" */
+  double ms;         /* summed HIP-event time */
+  double flops;      /* algorithmic FLOPs of those launches */
+  double bytes;      /* algorithmic HBM bytes (input read once + output written once + weights) */
+  long launches;
+} wct_prof_entry;
+
+int wct_version(void);
+
+/* replaces `wct = WCT(args).cuda()` (WCT.py:97, util_wct.py:31-59): create, then load 10 modules */
+int wct_create(int device, wct_ctx** out);
+void wct_destroy(wct_ctx* ctx);
+const char* wct_last_error(const wct_ctx* ctx);
+int wct_set_stream(wct_ctx* ctx, void* hip_stream); /* hipStream_t; NULL = default stream */
+int wct_sync(wct_ctx* ctx);
+
+/* replaces SmallEncoder{L}_16x_aux(path) / SmallDecoder{L}_16x(path) / Encoder{L} / Decoder{L} construction
+ * (util_wct.py:36-55; model_cd.py:712-718).  conv0_w [3*3] / conv0_b [3] (HOST): the encoder's 1x1 colour
+ * affine (model_cd.py:725), folded into the first conv; NULL for decoders. */
+int wct_load_module(wct_ctx* ctx, int kind, int level, int n_layers, const wct_layer* layers,
+                    const float* conv0_w, const float* conv0_b);
+
+/* shape of relu{level}_1 for an H x W image (floor pooling): C, h, w */
+int wct_feature_shape(const wct_ctx* ctx, int level, int H, int W, int* C, int* h, int* w);
+
+/* replaces `encoder(img)`  (WCT.py:100-101 -> model_cd.py:724-743) */
+int wct_encode(wct_ctx* ctx, int level, const float* img, int H, int W, float* feat, int layout);
+/* replaces `decoder(csF)`  (WCT.py:105 -> model_cd.py:276-294); image is 3 x (h<<(L-1)) x (w<<(L-1)) */
+int wct_decode(wct_ctx* ctx, int level, const float* feat, int h, int w, int layout, float* img);
+
+/* raw fp64 moments over the window rows [0,h) x cols [x0,x1) of an NHWC feature map of width w:
+ *   sum[C], sumsq[C*C] (device, f64).  Replaces torch.mean + mm(cF, cF.t()) (util_wct.py:68-70, 94-96);
+ * raw sums (not centred) so that a content-sharded run can all-reduce them across GPUs. */
+int wct_moments(wct_ctx* ctx, const float* feat, int C, int h, int w, int x0, int x1, double* sum, double* sumsq);
+
+/* (n, sum, sumsq) of content and style -> csF = M cF + b.  M [C*C] row-major, b [C], device f64.
+ * Replaces svd / pow / diag / mm of util_wct.py:74-125 and the blend of :219.  info (HOST, may be NULL)
+ * receives the Jacobi sweep counts {content, style} after an internal stream sync. */
+int wct_solve(wct_ctx* ctx, int C, double n_c, const double* sum_c, const double* sumsq_c, double n_s,
+              const double* sum_s, const double* sumsq_s, double alpha, double* M, double* b, int* info);
+
+/* out = M feat + b per pixel (un-fused form).  Replaces mm(step2,cF), mm(S,.), + s_mean (util_wct.py:120-126) */
+int wct_apply(wct_ctx* ctx, const float* feat, int C, int h, int w, int layout, const double* M, const double* b,
+              float* out);
+
+/* replaces `wct.transform(cF, sF, csF, alpha)` (util_wct.py:210-223); out has the shape/layout of cF */
+int wct_transform(wct_ctx* ctx, const float* cF, int C, int h, int w, const float* sF, int hs, int ws,
+                  float alpha, int layout, float* out);
+
+/* decoder with csF = M feat + b folded into its first convolution (feat is NHWC) */
+int wct_decode_affine(wct_ctx* ctx, int level, const float* feat, int h, int w, const double* M, const double* b,
+                      float* img);
+
+/* replaces styleTransfer(encoder, decoder, contentImg, styleImg, csF) (WCT.py:98-106) for one level */
+int wct_style_transfer_level(wct_ctx* ctx, int level, const float* content, int H, int W, const float* style,
+                             int Hs, int Ws, float alpha, float* out, int* Ho, int* Wo);
+
+/* replaces the cascade of WCT.py:120-125 (levels 5..1, num_run times).  out must hold 3*H*W floats. */
+int wct_stylize(wct_ctx* ctx, const float* content, int H, int W, const float* style, int Hs, int Ws, float alpha,
+                int num_run, float* out, int* Ho, int* Wo);
+
+/* bytes of internal workspace a wct_stylize of this size will hold; wct_reserve allocates it up front */
+size_t wct_workspace_bytes(const wct_ctx* ctx, int H, int W, int Hs, int Ws);
+int wct_reserve(wct_ctx* ctx, int H, int W, int Hs, int Ws);
+
+/* profiling: when enabled every kernel launch is bracketed by HIP events on the context's stream */
+int wct_profile_enable(wct_ctx* ctx, int on);
+int wct_profile_reset(wct_ctx* ctx);
+int wct_profile_read(wct_ctx* ctx, wct_prof_entry* entries, int max_entries, int* n_entries);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WCT_HIP_H */
