@@ -1,0 +1,180 @@
+#!/usr/bin/env python3
+"""Benchmark of the MI355X-native WCT stylisation path.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]          (N > 1: launched by torch.distributed.run)
+
+A "step" is one end-to-end 5-level WCT stylisation (levels 5..1; style-side encodes, moments and
+eigensolves INCLUDED) of BASELINE.json configs[1]: `--mode 16x`, 3840x2160 content, 2048x2048 style, synthetic
+uniform-noise images already resident in HBM (fp32, planar 3xHxW).  With N > 1 the content is N times wider
+(3840*N x 2160) and column-sharded: every rank stylises its own 3840-wide strip (+ halo), the only exchanges
+being an RCCL all-reduce of the fp64 content moments per level and a neighbour halo exchange between levels
+(wct_hip/sharded.py) -> weak scaling.  value = content megapixels / second over all ranks.
+
+The JSON line also carries
+  roofline      dominant kernel family: algorithmic FLOP per launch / HIP-event duration vs the gfx950 fp32-MFMA peak
+  passes        relu4_1 encode pass: algorithmic GB/s (364 B/px) and TFLOP/s (30 816 FLOP/px), SURVEY 8(d)
+  cpu_baseline  the CPU oracle (oracle/: numpy + C/OpenMP port of the reference's op sequence) timed on the host
+                cores on a bounded sample (512x512 content + style, 5 levels); rank 0, N = 1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+import types
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(REPO, "collaborative-distillation_amd")
+for p in (REPO, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+H, W, HS, WS = 2160, 3840, 2048, 2048
+PEAK_F32_MFMA_TF = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / 32x32x2_f32, dense
+PEAK_HBM_GBS = 8000.0      # spec; 6290 measured copy
+
+
+def cpu_baseline(weights):
+    """The oracle (a CPU port of the reference's op sequence: fp32 convs, fp64 two-GEMM WCT with SVD) on a bounded
+    sample of the same workload.  This is the ONLY place bench.py touches oracle/."""
+    from oracle import wct_oracle
+    cores = os.cpu_count() or 1
+    wct_oracle.set_num_threads(cores)
+    mods = wct_oracle.Modules("16x", weights)
+    rng = np.random.default_rng(0)
+    n = 512
+    c = rng.random((3, n, n), dtype=np.float32)
+    s = rng.random((3, n, n), dtype=np.float32)
+    t0 = time.perf_counter()
+    out = wct_oracle.stylize(mods, c, s, 1.0)
+    dt = time.perf_counter() - t0
+    assert np.isfinite(out).all()
+    return {"value": round(n * n / 1e6 / dt, 5), "unit": "MP/s", "cores": cores, "kind": "port",
+            "sample": "5-level 16x WCT, %dx%d content + %dx%d style (uniform noise), %.1f s wall, conv threads=%d, "
+                      "numpy/OpenBLAS for the fp64 transform" % (n, n, n, n, dt, wct_oracle.num_threads())}, out, (c, s)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d bench.py --gpus %d"
+                         % (args.gpus, args.gpus))
+    assert torch.cuda.is_available(), "bench.py needs the MI355X (no CPU path)"
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from wct_hip import WCT, model_zoo
+    weights = model_zoo.load_npz_weights(os.path.join(PKG, "weights", "16x.npz"))
+    wct = WCT(types.SimpleNamespace(mode="16x", alpha=1.0), weights=weights)
+
+    g = torch.Generator(device="cuda").manual_seed(1 + rank)
+    content = torch.rand((3, H, W), device="cuda", generator=g)          # this rank's strip (uniform noise, no zeros)
+    g2 = torch.Generator(device="cuda").manual_seed(2)
+    style = torch.rand((3, HS, WS), device="cuda", generator=g2)          # same style on every rank
+
+    if world > 1:
+        from wct_hip.sharded import ShardedStylizer
+        runner = ShardedStylizer(wct, dist, H, W * world, HS, WS)
+        step = lambda: runner.stylize_strip(content, style)   # noqa: E731
+    else:
+        wct.reserve(H, W, HS, WS)
+        out = torch.empty((3, H, W), device="cuda")
+        step = lambda: wct.stylize(content, style, out=out)   # noqa: E731
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    assert bool(torch.isfinite(res).all())
+    mp = H * W * world / 1e6
+    value = mp * args.steps / dt
+
+    # ---- roofline leg (rank 0): HIP events around every kernel launch on the context's stream
+    roof, passes, profile = None, None, None
+    if rank == 0:
+        wct.profile_reset()
+        wct.profile(True)
+        nprof = 2
+        for _ in range(nprof):
+            step()
+        torch.cuda.synchronize()
+        wct.profile(False)
+        ents = sorted(wct.profile_read(), key=lambda e: -e["ms"])
+        tot = sum(e["ms"] for e in ents)
+        profile = [{"kernel": e["name"], "ms_per_step": round(e["ms"] / nprof, 4), "launches_per_step": e["launches"] // nprof,
+                    "tflops": round(e["flops"] / e["ms"] / 1e9, 2) if e["flops"] else None,
+                    "algo_GBs": round(e["bytes"] / e["ms"] / 1e6, 1) if e["bytes"] else None} for e in ents]
+        d = ents[0]
+        ach = d["flops"] / d["ms"] / 1e9
+        roof = {"kernel": d["name"], "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TF, "unit": "TFLOP/s",
+                "frac": round(ach / PEAK_F32_MFMA_TF, 4), "traffic": None,
+                "avg_launch_ms": round(d["ms"] / d["launches"], 4), "share_of_step": round(d["ms"] / tot, 3),
+                "flop_per_launch": d["flops"] / d["launches"]}
+        # relu4_1 encode pass on the 4K content (north_star's named pass)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for _ in range(2):
+            wct.encode(4, content, layout="nhwc")
+        e0.record()
+        for _ in range(5):
+            wct.encode(4, content, layout="nhwc")
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 5
+        passes = {"relu4_1_encode": {"ms": round(ms, 3), "algo_GBs": round(364.0 * H * W / ms / 1e6, 1),
+                                     "frac_hbm_8TBs": round(364.0 * H * W / ms / 1e6 / PEAK_HBM_GBS, 4),
+                                     "tflops": round(30816.0 * H * W / ms / 1e9, 2),
+                                     "frac_f32_mfma": round(30816.0 * H * W / ms / 1e9 / PEAK_F32_MFMA_TF, 4)}}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu, ref, (c_np, s_np) = cpu_baseline(weights)
+        got = wct.stylize(torch.from_numpy(c_np).cuda(), torch.from_numpy(s_np).cuda()).cpu().numpy()[0]
+        cpu["gpu_vs_oracle_rel_err"] = float(np.abs(got - ref).max() / np.abs(ref).max())   # parity gate of the timed path
+
+    if rank == 0:
+        line = {
+            "metric": "content megapixels/sec, end-to-end 5-level WCT (16x VGG, 4K content, 2K style)",
+            "value": round(value, 2), "unit": "MP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "PytorchWCT/WCT.py --mode 16x, 5-level WCT, %dx%d content per GPU / %dx%d style, alpha=1, "
+                                   "style-side work included, images resident in HBM" % (W, H, WS, HS),
+                       "content_total": "%dx%d" % (W * world, H), "parallelism": "content column strips x%d" % world},
+            "roofline": roof, "passes": passes, "cpu_baseline": cpu, "kernels": profile,
+        }
+        print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -194,13 +194,20 @@ __global__ void colnorm_kernel(const double* Gall, double* lamAll, int n, const 
 }
 
 // out[a][b] = sum_{j live} lambda_j^(expo-2) G[a,j] G[b,j]   (G = V diag(lambda), column-major)
-__global__ void sym_power_kernel(const double* G, const double* lam, int n, double expo, double rel_thresh, double* out) {
+// live: lambda_j > max(rel_thresh * lambda_max, ABS_FLOOR * max_a E[x_a^2]).  The absolute floor is the
+// round-off level of the covariance itself (it is formed from raw fp64 sums of magnitude E[x^2]); it makes
+// a constant feature map (cov = 0 up to round-off) whiten to exactly 0 like the reference's exact-zero
+// centred features do (k_c = 0 -> target = s_mean, util_wct.py:82-86,117-126) instead of amplifying noise.
+constexpr double ABS_FLOOR = 1e-13;
+
+__global__ void sym_power_kernel(const double* G, const double* lam, int n, double expo, double rel_thresh,
+                                 const double* sumsq, double npix, double* out) {
   const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= (long)n * n) return;
   const int a = (int)(e / n), b = (int)(e % n);
-  double lmax = 0.;
-  for (int j = 0; j < n; ++j) lmax = fmax(lmax, lam[j]);
-  const double thr = rel_thresh * lmax;
+  double lmax = 0., ex2 = 0.;
+  for (int j = 0; j < n; ++j) { lmax = fmax(lmax, lam[j]); ex2 = fmax(ex2, sumsq[(size_t)j * n + j]); }
+  const double thr = fmax(rel_thresh * lmax, ABS_FLOOR * ex2 / npix);
   double s = 0.;
   for (int j = 0; j < n; ++j) {
     const double l = lam[j];
@@ -286,8 +293,8 @@ hipError_t launch_solve(int C, double n_c, const double* sum_c, const double* su
     hipLaunchKernelGGL(colnorm_kernel, dim3((unsigned)((C + 255) / 256), 2), dim3(256), 0, s, G, lam, C, flags, info);
   }
   const unsigned nb = (unsigned)((cc + 255) / 256);
-  hipLaunchKernelGGL(sym_power_kernel, dim3(nb), dim3(256), 0, s, G, lam, C, -0.5, rel_thresh, Wc);
-  hipLaunchKernelGGL(sym_power_kernel, dim3(nb), dim3(256), 0, s, G + cc, lam + C, C, 0.5, rel_thresh, Ss);
+  hipLaunchKernelGGL(sym_power_kernel, dim3(nb), dim3(256), 0, s, G, lam, C, -0.5, rel_thresh, sumsq_c, n_c, Wc);
+  hipLaunchKernelGGL(sym_power_kernel, dim3(nb), dim3(256), 0, s, G + cc, lam + C, C, 0.5, rel_thresh, sumsq_s, n_s, Ss);
   FinArgs f;
   f.C = C; f.alpha = alpha; f.Ss = Ss; f.Wc = Wc; f.mu = mu; f.M32 = M32; f.b32 = b32; f.M64 = M64; f.b64 = b64; f.T = T;
   hipLaunchKernelGGL(matmul_T_kernel, dim3(nb), dim3(256), 0, s, f);

@@ -116,14 +116,30 @@ def test_g4_cascade(oracle, weights16x, golden, tag):
 
 
 def test_g6_original_arch(oracle, golden):
+    """Un-pruned VGG-19 graph (model_original.py) with generated weights, each level on its own content."""
     g = golden("g6_original.npz")
     w = model_zoo.synth_weights("original", int(g["seed"]))
     m = oracle.Modules("original", w)
-    assert rel_err(m.encode(5, g["content"]), g["e5.y"][0]) < 1e-5
-    img = g["content"]
     for k in (5, 4, 3, 2, 1):
-        img = oracle.style_transfer(m, k, img, g["style"], 1.0)
+        assert rel_err(m.encode(k, g["L%d.content" % k]), g["e%d.y" % k][0]) < 1e-5
+        img = oracle.style_transfer(m, k, g["L%d.content" % k], g["style"], 1.0)
         assert rel_err(img, g["L%d.out" % k]) < 5e-4, k
+
+
+def test_g8_constant_content(oracle, weights16x, golden):
+    """Degenerate input: a constant content image -> every feature map constant -> cov = 0 exactly ->
+    k_c = 0 (util_wct.py:82-86) and the decoder sees the style mean everywhere."""
+    g = golden("g8_constant.npz")
+    m = oracle.Modules("16x", weights16x)
+    for k in (3, 1):
+        out = oracle.style_transfer(m, k, g["content"], g["style"], 1.0)
+        assert rel_err(out, g["L%d.out" % k]) < 1e-5, k
+        # the product's affine form with its absolute eigenvalue floor gives the same answer
+        cF, sF = m.encode(k, g["content"]), m.encode(k, g["style"])
+        _, mc, cc = oracle.moments(cF)
+        _, ms, cs = oracle.moments(sF)
+        M, b = oracle.affine_from_moments(mc, cc, ms, cs, 1.0)
+        assert np.abs(M).max() == 0.0 and rel_err(b, ms) < 1e-14
 
 
 def test_g7_config1(oracle, weights16x, golden):

@@ -248,32 +248,55 @@ def main():
     # ------------------------------------------------------------------ G6 original architecture, generated weights
     from model.model_original import (Encoder1, Encoder2, Encoder3, Encoder4, Encoder5,
                                       Decoder1, Decoder2, Decoder3, Decoder4, Decoder5)
-    ow = model_zoo.synth_weights("original", seed=2024)
     encs = [Encoder1, Encoder2, Encoder3, Encoder4, Encoder5]
     decs = [Decoder1, Decoder2, Decoder3, Decoder4, Decoder5]
-    mods = {}
-    for k in range(1, 6):
-        for kind, cls in (("enc", encs[k - 1]), ("dec", decs[k - 1])):
-            m = cls(None)
-            key = model_zoo.module_key(kind, k)
-            sd = {n[len(key) + 1:]: t(v) for n, v in ow.items() if n.startswith(key + ".")}
-            m.load_state_dict(sd, strict=True)
-            m.eval()
-            mods[key] = m
-    g6 = {"seed": np.int64(2024)}
-    c = rng.random((1, 3, 64, 64), dtype=np.float32)
     s = rng.random((1, 3, 48, 80), dtype=np.float32)
-    g6["content"], g6["style"] = c[0], s[0]
+    contents = {k: rng.random((1, 3, 64, 64), dtype=np.float32) for k in (5, 4, 3, 2, 1)}
     owct = types.SimpleNamespace(transform=wct.transform)
-    img = t(c)
+    # level-isolated (a fresh noise content per level): with random decoders a chained cascade collapses
+    # to a constant image after two levels, which would only test the degenerate cov = 0 branch.  A random
+    # decoder can also die outright (all-negative pre-activations -> image of zeros): take the first seed
+    # for which every level's output is alive.
+    for seed in range(2024, 2100):
+        ow = model_zoo.synth_weights("original", seed=seed)
+        mods = {}
+        for k in range(1, 6):
+            for kind, cls in (("enc", encs[k - 1]), ("dec", decs[k - 1])):
+                m = cls(None)
+                key = model_zoo.module_key(kind, k)
+                sd = {n[len(key) + 1:]: t(v) for n, v in ow.items() if n.startswith(key + ".")}
+                m.load_state_dict(sd, strict=True)
+                m.eval()
+                mods[key] = m
+        g6 = {"seed": np.int64(seed), "style": s[0]}
+        alive = True
+        for k in (5, 4, 3, 2, 1):
+            c = contents[k]
+            g6["L%d.content" % k] = c[0]
+            with torch.no_grad():
+                g6["e%d.y" % k] = mods["e%d" % k](t(c)).numpy()
+            img = ref_style_transfer(owct, mods["e%d" % k], mods["d%d" % k], t(c), t(s), 1.0)
+            g6["L%d.out" % k] = img.squeeze(0).numpy()
+            o = g6["L%d.out" % k]
+            alive = alive and all(o[ch].std() > 0.05 for ch in range(3))
+        if alive:
+            break
     for k in (5, 4, 3, 2, 1):
-        with torch.no_grad():
-            if k == 5:
-                g6["e5.y"] = mods["e5"](t(c)).numpy()
-        img = ref_style_transfer(owct, mods["e%d" % k], mods["d%d" % k], img, t(s), 1.0)
-        g6["L%d.out" % k] = img.squeeze(0).numpy()
-    print("G6: final range [%.3f, %.3f]" % (g6["L1.out"].min(), g6["L1.out"].max()))
+        o = g6["L%d.out" % k]
+        print("G6 seed %d L%d: out range [%.3f, %.3f] std %.3f" % (seed, k, o.min(), o.max(), o.std()))
     np.savez_compressed(os.path.join(GOLD, "g6_original.npz"), **g6)
+
+    # ------------------------------------------------------------------ G8 degenerate: constant content image
+    # every feature map is exactly constant; with hw a power of two the reference's centred features are
+    # exactly 0, cov = 0, k_c = 0 (util_wct.py:82-86) and the target is the style mean everywhere.
+    g8 = {}
+    c = np.full((1, 3, 64, 64), 0.3, np.float32)
+    s8 = load_rgb(os.path.join(REF, "PytorchWCT/style/in3.jpg"), crop=(64, 96))
+    g8["content"], g8["style"] = c[0], s8
+    for k in (3, 1):
+        g8["L%d.out" % k] = ref_style_transfer(wct, getattr(wct, "e%d" % k), getattr(wct, "d%d" % k), t(c), t(s8[None]), 1.0).squeeze(0).numpy()
+        assert np.isfinite(g8["L%d.out" % k]).all()
+    np.savez_compressed(os.path.join(GOLD, "g8_constant.npz"), **g8)
 
     # ------------------------------------------------------------------ G7 config 1 (512x512, relu1_1 only)
     r0 = np.random.default_rng(0)
