@@ -26,7 +26,8 @@ namespace {
 
 constexpr int LPP = 16;        // lanes per column pair
 constexpr int MAX_SWEEPS = 40;
-constexpr double ROT_TOL = 1e-15;
+constexpr double ROT_TOL = 1e-13;  // relative off-diagonal; quadratic convergence overshoots this by far
+constexpr double ABS_FLOOR = 1e-13;
 
 __device__ __forceinline__ void tournament_pair(int n, int round, int k, int& p, int& q) {
   // circle method: player n-1 stays, the others rotate
@@ -36,12 +37,13 @@ __device__ __forceinline__ void tournament_pair(int n, int round, int k, int& p,
   if (p > q) { const int t = p; p = q; q = t; }
 }
 
-__device__ __forceinline__ void rotation(double al, double be, double ga, double& c, double& s) {
-  // Rutishauser: zero the (p,q) entry of G^T G
+__device__ __forceinline__ double rotation(double al, double be, double ga, double& c, double& s) {
+  // Rutishauser: zero the (p,q) entry of G^T G; returns t = s/c
   const double zeta = (be - al) / (2.0 * ga);
   const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
   c = 1.0 / sqrt(1.0 + t * t);
   s = c * t;
+  return t;
 }
 
 struct CovArgs {
@@ -67,26 +69,69 @@ __global__ void cov_kernel(CovArgs a) {
   if (c == 0) a.mu[which * C + r] = mr;
 }
 
-// ---- C <= 128: whole problem in LDS, one workgroup per matrix
-__global__ __launch_bounds__(1024) void jacobi_lds_kernel(double* Gall, double* lamAll, int n, int* info) {
+// ---- 16-lane all-reduce of an fp64 value with DPP moves (no LDS crossbar round trips):
+//      quad_perm[1,0,3,2], quad_perm[2,3,0,1] -> quad sums; row_half_mirror -> 8-lane sums; row_mirror -> 16.
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double reduce16(double v) {
+  v += dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += dpp_mov<0x141>(v);  // row_half_mirror
+  v += dpp_mov<0x140>(v);  // row_mirror
+  return v;
+}
+
+// ---- C <= 128: whole problem in LDS, one workgroup per matrix.
+//  * channels whose variance is at round-off level (exactly-dead ReLU channels: 29..77 of 128 at relu5_1/relu4_1,
+//    SURVEY 7) are compacted away first -- their rows/columns of cov are zero, so they are eigenvectors with
+//    lambda = 0 and the Jacobi problem shrinks to the live block;
+//  * column norms are cached in LDS and updated by the rotation (alpha' = alpha - t*gamma, beta' = beta + t*gamma);
+//    round 0 of every sweep recomputes them exactly, so only ONE dot product per pair is reduced per round.
+__global__ __launch_bounds__(1024) void jacobi_lds_kernel(double* Gall, double* lamAll, int n_full, const double* sumsqAll0,
+                                                          const double* sumsqAll1, double npix0, double npix1, int* info) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int LD = n + 2;
-  double* G = reinterpret_cast<double*>(smem);
-  // the flag lives in the dynamic region too: a static __shared__ would shift the carve base off 8 B
-  // alignment and every ds_read_b64 would be replayed (cdna_hip_programming.md Guideline 17)
-  volatile int& rotated = *reinterpret_cast<volatile int*>(G + (size_t)n * LD);
   const int which = blockIdx.x;
-  double* Gg = Gall + (size_t)which * n * n;
   const int tid = threadIdx.x;
-  for (int e = tid; e < n * n; e += blockDim.x) G[(e / n) * LD + (e % n)] = Gg[e];  // symmetric: row/col-major alike
-  if (tid == 0) rotated = 0;
+  double* Gg = Gall + (size_t)which * n_full * n_full;
+  const double* sumsq = which ? sumsqAll1 : sumsqAll0;
+  const double npix = which ? npix1 : npix0;
+  // carve: G [n_full][n_full+2] | norm2 [n_full] | live [n_full] ints | flag
+  const int LD = n_full + 2;
+  double* G = reinterpret_cast<double*>(smem);
+  double* norm2 = G + (size_t)n_full * LD;
+  int* live = reinterpret_cast<int*>(norm2 + n_full);
+  volatile int* rotated = live + n_full;      // [0] rotation flag, [1] n (live count, even)
+  if (tid == 0) {
+    double ex2 = 0.;
+    for (int j = 0; j < n_full; ++j) ex2 = fmax(ex2, sumsq[(size_t)j * n_full + j]);
+    const double floor_ = ABS_FLOOR * ex2 / npix;
+    int nl = 0;
+    for (int j = 0; j < n_full; ++j)
+      if (Gg[(size_t)j * n_full + j] > floor_) live[nl++] = j;
+    if (nl & 1) {  // the tournament needs an even count: add one dead channel back (a zero row/column)
+      for (int j = 0; j < n_full; ++j)
+        if (!(Gg[(size_t)j * n_full + j] > floor_)) { live[nl++] = j; break; }
+    }
+    rotated[0] = 0;
+    rotated[1] = nl;
+  }
+  __syncthreads();
+  const int n = rotated[1];
+  for (int e = tid; e < n * n; e += blockDim.x) {
+    const int cj = e / n, r = e - cj * n;
+    G[cj * LD + r] = Gg[(size_t)live[cj] * n_full + live[r]];
+  }
   __syncthreads();
   const int npairs = n >> 1;
   const int pair = tid / LPP, sub = tid % LPP;
   const bool active = pair < npairs;
   constexpr int MAXR = 128 / LPP;
   int sweep = 0;
-  for (; sweep < MAX_SWEEPS; ++sweep) {
+  for (; sweep < MAX_SWEEPS && n >= 2; ++sweep) {
     for (int round = 0; round < n - 1; ++round) {
       if (active) {
         int p, q;
@@ -98,15 +143,21 @@ __global__ __launch_bounds__(1024) void jacobi_lds_kernel(double* Gall, double* 
           const int r = sub + LPP * m;
           gp[m] = r < n ? G[p * LD + r] : 0.;
           gq[m] = r < n ? G[q * LD + r] : 0.;
-          al += gp[m] * gp[m]; be += gq[m] * gq[m]; ga += gp[m] * gq[m];
+          ga += gp[m] * gq[m];
         }
+        if (round == 0) {
 #pragma unroll
-        for (int o = LPP / 2; o > 0; o >>= 1) {
-          al += __shfl_xor(al, o); be += __shfl_xor(be, o); ga += __shfl_xor(ga, o);
+          for (int m = 0; m < MAXR; ++m) { al += gp[m] * gp[m]; be += gq[m] * gq[m]; }
+          al = reduce16(al); be = reduce16(be);
+        } else {
+          al = norm2[p]; be = norm2[q];
         }
+        ga = reduce16(ga);
+        bool rot = false;
+        double t = 0.;
         if (fabs(ga) > ROT_TOL * sqrt(al * be) && al * be > 0.) {
           double c, s;
-          rotation(al, be, ga, c, s);
+          t = rotation(al, be, ga, c, s);
 #pragma unroll
           for (int m = 0; m < MAXR; ++m) {
             const int r = sub + LPP * m;
@@ -115,24 +166,34 @@ __global__ __launch_bounds__(1024) void jacobi_lds_kernel(double* Gall, double* 
               G[q * LD + r] = s * gp[m] + c * gq[m];
             }
           }
-          if (sub == 0) rotated = 1;
+          rot = true;
+        }
+        if (sub == 0) {
+          if (rot) rotated[0] = 1;
+          if (rot || round == 0) { norm2[p] = al - t * ga; norm2[q] = be + t * ga; }
         }
       }
       __syncthreads();
     }
-    const int any = rotated;
+    const int any = rotated[0];
     __syncthreads();
-    if (tid == 0) rotated = 0;
+    if (tid == 0) rotated[0] = 0;
     __syncthreads();
     if (!any) break;
   }
-  // eigenvalues = column norms; keep G = V diag(lambda) (assemble divides)
+  // eigenvalues = column norms (recomputed exactly); G = V diag(lambda) written back in the FULL index space
+  for (int e = tid; e < n_full * n_full; e += blockDim.x) Gg[e] = 0.;
+  for (int j = tid; j < n_full; j += blockDim.x) lamAll[which * n_full + j] = 0.;
+  __syncthreads();
   for (int j = tid; j < n; j += blockDim.x) {
     double s = 0.;
     for (int r = 0; r < n; ++r) s += G[j * LD + r] * G[j * LD + r];
-    lamAll[which * n + j] = sqrt(s);
+    lamAll[which * n_full + j] = sqrt(s);
   }
-  for (int e = tid; e < n * n; e += blockDim.x) Gg[e] = G[(e / n) * LD + (e % n)];  // column-major: col = e / n
+  for (int e = tid; e < n * n; e += blockDim.x) {
+    const int cj = e / n, r = e - cj * n;
+    Gg[(size_t)cj * n_full + live[r]] = G[cj * LD + r];  // column-major: column cj, full row index live[r]
+  }
   if (tid == 0) info[which] = sweep;
 }
 
@@ -198,8 +259,6 @@ __global__ void colnorm_kernel(const double* Gall, double* lamAll, int n, const 
 // round-off level of the covariance itself (it is formed from raw fp64 sums of magnitude E[x^2]); it makes
 // a constant feature map (cov = 0 up to round-off) whiten to exactly 0 like the reference's exact-zero
 // centred features do (k_c = 0 -> target = s_mean, util_wct.py:82-86,117-126) instead of amplifying noise.
-constexpr double ABS_FLOOR = 1e-13;
-
 __global__ void sym_power_kernel(const double* G, const double* lam, int n, double expo, double rel_thresh,
                                  const double* sumsq, double npix, double* out) {
   const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -277,11 +336,12 @@ hipError_t launch_solve(int C, double n_c, const double* sum_c, const double* su
   hipLaunchKernelGGL(cov_kernel, dim3((unsigned)((cc + 255) / 256), 2), dim3(256), 0, s, ca);
 
   if (C <= 128) {
-    const size_t lds = (size_t)C * (C + 2) * sizeof(double) + 16;
+    const size_t lds = ((size_t)C * (C + 2) + C) * sizeof(double) + (size_t)(C + 4) * sizeof(int);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(jacobi_lds_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(jacobi_lds_kernel, dim3(2), dim3(1024), lds, s, G, lam, C, info);
+    const unsigned threads = (unsigned)(((C / 2) * LPP + 63) / 64 * 64);
+    hipLaunchKernelGGL(jacobi_lds_kernel, dim3(2), dim3(threads), lds, s, G, lam, C, sumsq_c, sumsq_s, n_c, n_s, info);
   } else {
     hipError_t e = hipMemsetAsync(flags, 0, 2 * (MAX_SWEEPS + 1) * sizeof(int), s);
     if (e != hipSuccess) return e;
