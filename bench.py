@@ -6,9 +6,9 @@
 A "step" is one end-to-end 5-level WCT stylisation (levels 5..1; style-side encodes, moments and
 eigensolves INCLUDED) of BASELINE.json configs[1]: `--mode 16x`, 3840x2160 content, 2048x2048 style, synthetic
 uniform-noise images already resident in HBM (fp32, planar 3xHxW).  With N > 1 the content is N times wider
-(3840*N x 2160) and column-sharded: every rank stylises its own 3840-wide strip (+ halo), the only exchanges
-being an RCCL all-reduce of the fp64 content moments per level and a neighbour halo exchange between levels
-(wct_hip/sharded.py) -> weak scaling.  value = content megapixels / second over all ranks.
+(3840*N x 2160) and column-sharded: every rank stylises its own 3840-wide strip (+ a cumulative halo, so no
+neighbour exchange), the only exchanges being one RCCL all-reduce of the fp64 content moments and one broadcast
+of the colouring map (M, b) per level (wct_hip/sharded.py) -> weak scaling.  value = content megapixels / second over all ranks.
 
 The JSON line also carries
   roofline      dominant kernel family: algorithmic FLOP per launch / HIP-event duration vs the gfx950 fp32-MFMA peak
@@ -83,16 +83,27 @@ def main():
     weights = model_zoo.load_npz_weights(os.path.join(PKG, "weights", "16x.npz"))
     wct = WCT(types.SimpleNamespace(mode="16x", alpha=1.0), weights=weights)
 
-    g = torch.Generator(device="cuda").manual_seed(1 + rank)
-    content = torch.rand((3, H, W), device="cuda", generator=g)          # this rank's strip (uniform noise, no zeros)
+    def strip_image(r):   # strip r of the virtual (W*world) x H content: uniform noise, no zeros, seeded per strip
+        g = torch.Generator(device="cuda").manual_seed(1 + r)
+        return torch.rand((3, H, W), device="cuda", generator=g)
+
     g2 = torch.Generator(device="cuda").manual_seed(2)
     style = torch.rand((3, HS, WS), device="cuda", generator=g2)          # same style on every rank
 
     if world > 1:
         from wct_hip.sharded import ShardedStylizer
         runner = ShardedStylizer(wct, dist, H, W * world, HS, WS)
+        x0, x1 = runner.input_columns()                                    # own strip + cumulative halo
+        parts = []
+        for r in range(world):
+            a, b = max(x0, r * W), min(x1, (r + 1) * W)
+            if a < b:
+                parts.append(strip_image(r)[:, :, a - r * W:b - r * W])
+        content = torch.cat(parts, dim=2).contiguous()
+        del parts
         step = lambda: runner.stylize_strip(content, style)   # noqa: E731
     else:
+        content = strip_image(0)
         wct.reserve(H, W, HS, WS)
         out = torch.empty((3, H, W), device="cuda")
         step = lambda: wct.stylize(content, style, out=out)   # noqa: E731
@@ -120,13 +131,14 @@ def main():
 
     # ---- roofline leg (rank 0): HIP events around every kernel launch on the context's stream
     roof, passes, profile = None, None, None
+    nprof = 2
     if rank == 0:
         wct.profile_reset()
         wct.profile(True)
-        nprof = 2
-        for _ in range(nprof):
-            step()
-        torch.cuda.synchronize()
+    for _ in range(nprof):      # every rank runs these steps (they contain collectives); only rank 0 records events
+        step()
+    barrier()
+    if rank == 0:
         wct.profile(False)
         ents = sorted(wct.profile_read(), key=lambda e: -e["ms"])
         tot = sum(e["ms"] for e in ents)
@@ -140,12 +152,13 @@ def main():
                 "avg_launch_ms": round(d["ms"] / d["launches"], 4), "share_of_step": round(d["ms"] / tot, 3),
                 "flop_per_launch": d["flops"] / d["launches"]}
         # relu4_1 encode pass on the 4K content (north_star's named pass)
+        content4k = content[:, :, :W].contiguous()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         for _ in range(2):
-            wct.encode(4, content, layout="nhwc")
+            wct.encode(4, content4k, layout="nhwc")
         e0.record()
         for _ in range(5):
-            wct.encode(4, content, layout="nhwc")
+            wct.encode(4, content4k, layout="nhwc")
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / 5

@@ -1,0 +1,128 @@
+"""The N > 1 path (wct_hip/sharded.py) under torch.distributed `gloo` on CPU, world_size 2 and 3.
+
+The orchestration under test is the product's; the arithmetic behind it is supplied by the CPU checker
+(oracle/) through the same engine interface the HIP library implements (encode / moments / solve /
+decode_affine), so what is verified here is the sharding logic: strip bounds, cumulative halos, windowed
+moments + all-reduce, broadcast of (M, b), crops, floor-mode shrinking.  Expected result: the gathered strips
+equal the UNTILED cascade."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from tests.conftest import PKG, REPO
+
+
+class OracleEngine:
+    """CPU stand-in with the engine interface of wct_hip.WCT (test infrastructure only)."""
+
+    def __init__(self, weights):
+        from oracle import wct_oracle
+        self.o = wct_oracle
+        self.m = wct_oracle.Modules("16x", weights)
+
+    def encode(self, level, img, layout="nhwc"):
+        x = img[0] if img.dim() == 4 else img
+        f = self.m.encode(level, x.numpy())
+        return torch.from_numpy(np.ascontiguousarray(f.transpose(1, 2, 0)))[None]
+
+    def moments(self, feat, x0=0, x1=None):
+        f = feat[0].numpy().astype(np.float64)
+        x1 = f.shape[1] if x1 is None else x1
+        X = f[:, x0:x1].reshape(-1, f.shape[2])
+        return float(X.shape[0]), torch.from_numpy(X.sum(0)), torch.from_numpy(X.T @ X)
+
+    def solve(self, n_c, sum_c, sumsq_c, n_s, sum_s, sumsq_s, alpha=1.0):
+        def mc(n, s, ss):
+            s, ss = s.numpy(), ss.numpy()
+            mu = s / n
+            return mu, (ss - n * np.outer(mu, mu)) / (n - 1)
+        mu_c, cov_c = mc(n_c, sum_c, sumsq_c)
+        mu_s, cov_s = mc(n_s, sum_s, sumsq_s)
+        M, b = self.o.affine_from_moments(mu_c, cov_c, mu_s, cov_s, alpha)
+        return torch.from_numpy(M), torch.from_numpy(b)
+
+    def decode_affine(self, level, feat, M, b):
+        f = feat[0].numpy().astype(np.float64)
+        y = (f @ M.numpy().T + b.numpy()).astype(np.float32)
+        img = self.m.decode(level, np.ascontiguousarray(y.transpose(2, 0, 1)))
+        return torch.from_numpy(img)[None]
+
+
+def _worker(rank, world, port, H, W, out_path):
+    for p in (REPO, PKG):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from wct_hip import model_zoo
+        from wct_hip.sharded import ShardedStylizer
+        w = model_zoo.load_npz_weights(os.path.join(PKG, "weights", "16x.npz"))
+        eng = OracleEngine(w)
+        eng.o.set_num_threads(2)
+        rng = np.random.default_rng(5)
+        content = rng.random((3, H, W), dtype=np.float32)
+        style = rng.random((3, 80, 96), dtype=np.float32)
+        sh = ShardedStylizer(eng, dist, H, W, 80, 96, alpha=1.0)
+        x0, x1 = sh.input_columns()
+        strip = sh.stylize_strip(torch.from_numpy(np.ascontiguousarray(content[:, :, x0:x1])), torch.from_numpy(style))
+        parts = [None] * world
+        dist.all_gather_object(parts, (sh.own, strip.numpy()))
+        if rank == 0:
+            full = np.concatenate([p[1] for p in sorted(parts, key=lambda t: t[0][0])], axis=3)
+            np.save(out_path, full)
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("world,H,W", [(2, 64, 1280), (3, 48, 1925)])
+def test_sharded_equals_untiled(tmp_path, oracle, weights16x, world, H, W):
+    out = str(tmp_path / "sharded.npy")
+    mp.spawn(_worker, args=(world, _free_port(), H, W, out), nprocs=world, join=True)
+    got = np.load(out)
+    rng = np.random.default_rng(5)
+    content = rng.random((3, H, W), dtype=np.float32)
+    style = rng.random((3, 80, 96), dtype=np.float32)
+    # untiled run of the SAME engine (world = 1): isolates the sharding logic from algorithmic differences
+    from wct_hip.sharded import ShardedStylizer
+    eng = OracleEngine(weights16x)
+    one = ShardedStylizer(eng, None, H, W, 80, 96, rank=0, world=1)
+    ref = one.stylize_strip(torch.from_numpy(content), torch.from_numpy(style)).numpy()
+    assert got.shape == ref.shape              # W = 1925 shrinks to 1920 at level 5
+    assert got.shape[3] == (W // 16) * 16 and got.shape[2] == (H // 16) * 16
+    err = np.abs(got - ref).max() / np.abs(ref).max()
+    assert err < 1e-6, err                     # identical arithmetic; only the moment summation order differs
+    # and the whole thing is the reference cascade (SVD path) up to the cascade's own error amplification
+    full = oracle.stylize(oracle.Modules("16x", weights16x), content, style, 1.0)
+    assert np.abs(got[0] - full).max() / np.abs(full).max() < 1e-3
+
+
+def test_strip_bounds():
+    from wct_hip.sharded import CUM_HALO, LEVEL_HALO, ext_bounds, strip_bounds
+    b = strip_bounds(3840 * 8, 8)
+    assert b[0] == (0, 3840) and b[-1] == (3840 * 7, 3840 * 8)
+    assert all(x0 % 16 == 0 for x0, _ in b)
+    assert strip_bounds(10240, 8)[3] == (3840, 5120)     # BASELINE config 4: 8 strips of 1280
+    for L in (5, 4, 3, 2):
+        assert CUM_HALO[L] % (1 << (L - 1)) == 0
+        assert CUM_HALO[L] - LEVEL_HALO[L] >= CUM_HALO[L - 1]   # what stays exact covers the next level's need
+    assert CUM_HALO[1] >= LEVEL_HALO[1]
+    assert ext_bounds((0, 1280), 10240, 272) == (0, 1552) and ext_bounds((8960, 10240), 10240, 272) == (8688, 10240)
+    with pytest.raises(ValueError):
+        strip_bounds(40, 4)
