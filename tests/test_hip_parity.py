@@ -304,4 +304,41 @@ def test_sharded_two_ranks_match_untiled(torch_cuda, tmp_path):
     mp.spawn(_shard_worker, args=(2, port, 272, 1525, out), nprocs=2, join=True)
     z = np.load(out)
     assert z["got"].shape == z["ref"].shape == (1, 3, 272, 1520)
-    assert rel_err(z["got"], z["ref"]) < 1e-6
+    # not bitwise: the two runs' (M, b) differ by ~1e-13 (moment summation order), which flips fp32 roundings of
+    # the folded decoder weights at level 5, and the cascade amplifies that level by level (shard_diag.py)
+    assert rel_err(z["got"], z["ref"]) < 5e-4
+
+
+def test_strip_halos_exact_per_level(torch_cuda, wct16):
+    """Sharding logic on the real kernels, level-isolated: with the SAME (M, b), a strip computed from
+    [own - A_L, own + A_L) is BITWISE equal to the untiled level on own +- (A_L - halo_L), for edge strips and
+    an interior strip, including a width that floor-pooling shrinks (2005 -> 2000)."""
+    from wct_hip.sharded import CUM_HALO, LEVEL_HALO, ext_bounds, strip_bounds
+    torch = torch_cuda
+    H, W, world = 176, 2005, 3
+    g = torch.Generator(device="cuda").manual_seed(3)
+    content = torch.rand((1, 3, H, W), device="cuda", generator=g)
+    style = torch.rand((3, 200, 180), device="cuda", generator=g)
+    for L in (5, 4, 3, 2, 1):
+        sh = L - 1
+        sF = wct16.encode(L, style, layout="nhwc")
+        cF = wct16.encode(L, content, layout="nhwc")
+        nc, sc, ssc = wct16.moments(cF)
+        M, b = wct16.solve(nc, sc, ssc, *wct16.moments(sF))
+        full = wct16.decode_affine(L, cF, M, b)
+        Wn = (W >> sh) << sh
+        assert full.shape[-1] == Wn
+        tot = 0
+        for own in strip_bounds(W, world):
+            lo, hi = ext_bounds(own, W, CUM_HALO[L])
+            f = wct16.encode(L, content[..., lo:hi].contiguous(), layout="nhwc")
+            f0 = (own[0] - lo) >> sh
+            f1 = f.shape[2] if own[1] >= W else (own[1] - lo) >> sh
+            assert torch.equal(f[0, :, f0:f1], cF[0, :, own[0] >> sh:(own[0] >> sh) + f1 - f0])
+            n, s1, s2 = wct16.moments(f, f0, f1)
+            tot += n
+            o = wct16.decode_affine(L, f, M, b)
+            v = CUM_HALO[L] - LEVEL_HALO[L]
+            a, e = max(0, own[0] - v), min(Wn, own[1] + v)
+            assert torch.equal(o[..., a - lo:e - lo], full[..., a:e]), (L, own)
+        assert tot == nc
