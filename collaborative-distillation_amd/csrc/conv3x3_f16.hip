@@ -1,0 +1,379 @@
+// reflect-pad(1) + conv3x3 + bias + ReLU on the f16 matrix cores with SPLIT operands ("f16x3"):
+//     x = hi + lo,  hi = f16(x), lo = f16(x - hi)          (two-term split: 11 + 11 bits + sign of the residual
+//     w.x  ~=  hi_w.hi_x + hi_w.lo_x + lo_w.hi_x            ~ 23-24 significant bits, i.e. fp32-class)
+// accumulated in fp32 by v_mfma_f32_32x32x16_f16 / v_mfma_f32_16x16x32_f16.  The dropped lo.lo term is 2^-22
+// relative.  Measured on the GPU against fp64 (tools/experiments/split_precision.hip, K = 1152, post-ReLU
+// activations with 30x outliers): f16x3 6.2e-7 vs exact-fp32 MFMA 7.7e-7 of max|ref| -- the same accuracy class,
+// at 3/16 of the fp32-MFMA issue time (bf16x3: 9.4e-6, plain f16: 4.1e-4, both rejected by the parity gate).
+// Range: activations of this path are <= ~250 and weights <= ~2 in magnitude (measured on the shipped images);
+// weights are pre-scaled by a per-layer power of two so that their lo parts stay normal f16 numbers, and the
+// epilogue multiplies by the exact inverse.  Activations beyond +-65504 saturate (never inf).
+//
+// Same fusions and the same NHWC/planar layouts as conv3x3.hip (reflect pad, 2x2 max-pool epilogue, nearest-x2
+// in the tile load, folded conv0 / WCT affine); the 3-channel FIRST conv stays on the fp32 kernel (HBM-bound).
+//
+// Tiling: workgroup = 4 waves = 32 x 8 output pixels x all couts (<= 128); wave w owns rows 2w, 2w+1.
+// K is walked in 16-channel chunks; per chunk LDS holds, as 16-byte groups of 8 halfs,
+//   act[hl][kh][pix]      hl = hi/lo plane, kh = channel half (8kh..8kh+7), pix = 34 x 10 halo pixel
+//   wgt[tap][hl][kh][co]
+// so every MFMA operand is ONE ds_read_b128 and consecutive lanes (consecutive pixels / couts) read consecutive
+// 16-B slots with plane strides that are multiples of 256 B: bank-conflict free.
+//   Cout >= 32: 32x32x16, A = 32 couts x 16 channels of one tap, B = 16 channels x 32 pixels of one tile row.
+//   Cout == 16 (and the 3-channel last conv, padded): 16x16x32, the 32-deep K holds TWO taps x 16 channels.
+#include "wct_common.h"
+
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int FTW = 32, FTH = 8;
+constexpr int FHW = FTW + 2, FHH = FTH + 2;   // 34 x 10 halo
+constexpr int NPH = FHW * FHH;                // 340
+constexpr int NPP = 352;                      // plane stride in 16-B units (multiple of 16)
+
+struct F16Args {
+  const float* in;
+  float* out;
+  const uint4* wpk;        // [chunk][taps][hl][kh][cout_pad] x 16 B
+  const float* bias;
+  const float* inv_scale_ptr;  // device scalar (folded layers) or null
+  float inv_scale;
+  int H, W, inH, inW;
+  int cin, cout, cin_chunks, cout_pad, taps;  // taps = 9 (32x32 path) or 10 (16x16x32 path, tap 9 = zeros)
+  int tiles_x, tiles_y;
+  int up_in, relu;
+};
+
+__device__ __forceinline__ int reflect_clamp(int i, int n) {
+  if (i < 0) i = -i;
+  if (i >= n) i = 2 * n - 2 - i;
+  i = i < 0 ? 0 : i;
+  return i >= n ? n - 1 : i;
+}
+
+__device__ __forceinline__ int xcd_swizzle(int bid, int n) {
+  const int q = n >> 3, r = n & 7, xcd = bid & 7, idx = bid >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+__device__ __forceinline__ void split8(const f32x4& a, const f32x4& b, f16x8& hi, f16x8& lo) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    float x = j < 4 ? a[j] : b[j - 4];
+    x = fminf(fmaxf(x, -65504.f), 65504.f);
+    const _Float16 h = (_Float16)x;
+    hi[j] = h;
+    lo[j] = (_Float16)(x - (float)h);
+  }
+}
+
+// stage one 16-channel chunk of the halo tile, converting fp32 -> (hi, lo) f16 planes
+__device__ __forceinline__ void stage_act(const F16Args& a, uint4* act, int ch, int ty0, int tx0, int tid) {
+  for (int e = tid; e < NPH * 2; e += 256) {
+    const int kh = e & 1, pix = e >> 1;
+    const int py = pix / FHW, px = pix - py * FHW;
+    int gy = reflect_clamp(ty0 - 1 + py, a.H), gx = reflect_clamp(tx0 - 1 + px, a.W);
+    if (a.up_in) { gy >>= 1; gx >>= 1; }
+    const int c = ch * 16 + kh * 8;
+    const float* src = a.in + ((size_t)gy * a.inW + gx) * a.cin + c;
+    f32x4 v0 = f32x4{0.f, 0.f, 0.f, 0.f}, v1 = v0;
+    if (c < a.cin) v0 = *reinterpret_cast<const f32x4*>(src);
+    if (c + 4 < a.cin) v1 = *reinterpret_cast<const f32x4*>(src + 4);
+    f16x8 hi, lo;
+    split8(v0, v1, hi, lo);
+    act[(0 * 2 + kh) * NPP + pix] = __builtin_bit_cast(uint4, hi);
+    act[(1 * 2 + kh) * NPP + pix] = __builtin_bit_cast(uint4, lo);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ Cout >= 32
+template <int CT, bool POOL>
+__global__ __launch_bounds__(256) void conv3x3_f16_kernel(F16Args a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int COW = CT * 32;
+  uint4* act = reinterpret_cast<uint4*>(smem);   // [4][NPP]
+  uint4* wgt = act + 4 * NPP;                    // [9][2][2][COW]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, kh = lane >> 5;
+  const int tile = xcd_swizzle(blockIdx.x, a.tiles_x * a.tiles_y);
+  const int ty0 = (tile / a.tiles_x) * FTH, tx0 = (tile % a.tiles_x) * FTW;
+  const int co0 = blockIdx.y * COW;
+
+  f32x16 acc[CT][2];
+#pragma unroll
+  for (int c = 0; c < CT; ++c)
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[c][p][r] = 0.f;
+
+  for (int ch = 0; ch < a.cin_chunks; ++ch) {
+    if (ch) __syncthreads();
+    stage_act(a, act, ch, ty0, tx0, tid);
+    const uint4* wsrc = a.wpk + (size_t)ch * 36 * a.cout_pad;
+    for (int e = tid; e < 36 * COW; e += 256) {
+      const int seg = e / COW, j = e - seg * COW;
+      wgt[e] = wsrc[(size_t)seg * a.cout_pad + co0 + j];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int dy = tap / 3, dx = tap - dy * 3;
+      f16x8 bh[2], bl[2];
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        const int pix = (wave * 2 + p + dy) * FHW + li + dx;
+        bh[p] = __builtin_bit_cast(f16x8, act[(0 * 2 + kh) * NPP + pix]);
+        bl[p] = __builtin_bit_cast(f16x8, act[(1 * 2 + kh) * NPP + pix]);
+      }
+#pragma unroll
+      for (int c = 0; c < CT; ++c) {
+        const f16x8 ah = __builtin_bit_cast(f16x8, wgt[((tap * 2 + 0) * 2 + kh) * COW + c * 32 + li]);
+        const f16x8 al = __builtin_bit_cast(f16x8, wgt[((tap * 2 + 1) * 2 + kh) * COW + c * 32 + li]);
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+          acc[c][p] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[p], acc[c][p], 0, 0, 0);
+          acc[c][p] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[p], acc[c][p], 0, 0, 0);
+          acc[c][p] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[p], acc[c][p], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  // epilogue.  D: col = lane & 31 (pixel), row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) (cout)
+  const float inv = a.inv_scale_ptr ? *a.inv_scale_ptr : a.inv_scale;
+  const int gx = tx0 + li;
+#pragma unroll
+  for (int c = 0; c < CT; ++c) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int co = co0 + c * 32 + 8 * q + 4 * kh;
+      const f32x4 bias = *reinterpret_cast<const f32x4*>(a.bias + co);
+      if constexpr (POOL) {
+        const int Hp = a.H >> 1, Wp = a.W >> 1;
+        f32x4 m;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = fmaxf(acc[c][0][4 * q + r], acc[c][1][4 * q + r]);
+          v = fmaxf(v, __shfl_xor(v, 1));
+          v = v * inv + bias[r];
+          m[r] = a.relu ? fmaxf(v, 0.f) : v;
+        }
+        const int oy = (ty0 + wave * 2) >> 1, ox = gx >> 1;
+        if (!(li & 1) && oy < Hp && ox < Wp && co < a.cout)
+          *reinterpret_cast<f32x4*>(a.out + ((size_t)oy * Wp + ox) * a.cout + co) = m;
+      } else {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+          const int gy = ty0 + wave * 2 + p;
+          f32x4 v;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            v[r] = acc[c][p][4 * q + r] * inv + bias[r];
+            if (a.relu) v[r] = fmaxf(v[r], 0.f);
+          }
+          if (gy < a.H && gx < a.W && co < a.cout)
+            *reinterpret_cast<f32x4*>(a.out + ((size_t)gy * a.W + gx) * a.cout + co) = v;
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ Cout <= 16
+template <bool POOL, bool OUT3>
+__global__ __launch_bounds__(256) void conv3x3_f16_c16_kernel(F16Args a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint4* act = reinterpret_cast<uint4*>(smem);   // [4][NPP]
+  uint4* wgt = act + 4 * NPP;                    // [10][2][2][16]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, kq = lane >> 4, kh = kq & 1, ts = kq >> 1;
+  const int tile = xcd_swizzle(blockIdx.x, a.tiles_x * a.tiles_y);
+  const int ty0 = (tile / a.tiles_x) * FTH, tx0 = (tile % a.tiles_x) * FTW;
+
+  f32x4 acc[2][2];  // [row][half row]
+#pragma unroll
+  for (int r = 0; r < 2; ++r)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) acc[r][h] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int ch = 0; ch < a.cin_chunks; ++ch) {
+    if (ch) __syncthreads();
+    stage_act(a, act, ch, ty0, tx0, tid);
+    const uint4* wsrc = a.wpk + (size_t)ch * 40 * 16;
+    for (int e = tid; e < 40 * 16; e += 256) wgt[e] = wsrc[e];
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < 5; ++s) {
+      const int tap = 2 * s + ts;               // tap 9 carries zero weights
+      const int tc = tap > 8 ? 8 : tap;
+      const int dy = tc / 3, dx = tc - dy * 3;
+      const f16x8 ah = __builtin_bit_cast(f16x8, wgt[((tap * 2 + 0) * 2 + kh) * 16 + li]);
+      const f16x8 al = __builtin_bit_cast(f16x8, wgt[((tap * 2 + 1) * 2 + kh) * 16 + li]);
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int pix = (wave * 2 + r + dy) * FHW + h * 16 + li + dx;
+          const f16x8 bh = __builtin_bit_cast(f16x8, act[(0 * 2 + kh) * NPP + pix]);
+          const f16x8 bl = __builtin_bit_cast(f16x8, act[(1 * 2 + kh) * NPP + pix]);
+          acc[r][h] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc[r][h], 0, 0, 0);
+          acc[r][h] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc[r][h], 0, 0, 0);
+          acc[r][h] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc[r][h], 0, 0, 0);
+        }
+    }
+  }
+
+  // D: col = lane & 15 (pixel), row = 4 * (lane >> 4) + reg (cout)
+  const float inv = a.inv_scale_ptr ? *a.inv_scale_ptr : a.inv_scale;
+  const int co = 4 * kq;
+  const f32x4 bias = *reinterpret_cast<const f32x4*>(a.bias + co);
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int gx = tx0 + h * 16 + li;
+    if constexpr (POOL) {
+      const int Hp = a.H >> 1, Wp = a.W >> 1;
+      f32x4 m;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = fmaxf(acc[0][h][r], acc[1][h][r]);
+        v = fmaxf(v, __shfl_xor(v, 1));
+        v = v * inv + bias[r];
+        m[r] = a.relu ? fmaxf(v, 0.f) : v;
+      }
+      const int oy = (ty0 + wave * 2) >> 1, ox = gx >> 1;
+      if (!(li & 1) && oy < Hp && ox < Wp && co < a.cout)
+        *reinterpret_cast<f32x4*>(a.out + ((size_t)oy * Wp + ox) * a.cout + co) = m;
+    } else {
+#pragma unroll
+      for (int r2 = 0; r2 < 2; ++r2) {
+        const int gy = ty0 + wave * 2 + r2;
+        f32x4 v;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          v[r] = acc[r2][h][r] * inv + bias[r];
+          if (a.relu) v[r] = fmaxf(v[r], 0.f);
+        }
+        if (gy < a.H && gx < a.W) {
+          if constexpr (OUT3) {
+            if (kq == 0) {
+              const size_t plane = (size_t)a.H * a.W, off = (size_t)gy * a.W + gx;
+              a.out[off] = v[0];
+              a.out[plane + off] = v[1];
+              a.out[2 * plane + off] = v[2];
+            }
+          } else if (co < a.cout) {
+            *reinterpret_cast<f32x4*>(a.out + ((size_t)gy * a.W + gx) * a.cout + co) = v;
+          }
+        }
+      }
+    }
+  }
+}
+
+template <typename K>
+hipError_t launch_k(K k, const F16Args& a, size_t lds, int groups, hipStream_t s) {
+  if (lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(k, dim3(a.tiles_x * a.tiles_y, groups), dim3(256), lds, s, a);
+  return hipGetLastError();
+}
+
+// ---- weight preparation on the device (folded first decoder conv): fp32 packed [chunk][tap][kq][cout_pad][4]
+//      -> scaled (hi, lo) f16 in this file's layout.  `maxbits` holds max|w| as float bits (atomicMax on uint).
+__global__ void absmax_kernel(const float* w, long n, unsigned* maxbits) {
+  float m = 0.f;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) m = fmaxf(m, fabsf(w[e]));
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0) atomicMax(maxbits, __float_as_uint(m));
+}
+
+__global__ void split_pack_kernel(const float* wpk32, int chunks, int cout_pad, int taps, const unsigned* maxbits,
+                                  uint4* out, float* inv_scale_out) {
+  // scale = 2^e with max|w| * scale in [256, 512)
+  const float mx = __uint_as_float(*maxbits);
+  int ex = 0;
+  if (mx > 0.f && mx < 3.0e38f) { (void)frexpf(mx, &ex); ex = 9 - ex; }
+  ex = ex > 100 ? 100 : (ex < -100 ? -100 : ex);
+  const float scale = ldexpf(1.f, ex);
+  const long total = (long)chunks * taps * 2 * 2 * cout_pad;  // 16-B groups
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e == 0) *inv_scale_out = ldexpf(1.f, -ex);
+  if (e >= total) return;
+  long t = e;
+  const int co = (int)(t % cout_pad); t /= cout_pad;
+  const int kh = (int)(t & 1); t >>= 1;
+  const int hl = (int)(t & 1); t >>= 1;
+  const int tap = (int)(t % taps);
+  const int chunk = (int)(t / taps);
+  f16x8 v;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    float x = 0.f;
+    if (tap < 9) {
+      const int ci = kh * 8 + j;  // channel within the chunk -> fp32 layout [chunk][tap][kq = ci/4][cout_pad][ci%4]
+      x = wpk32[((((size_t)chunk * 9 + tap) * 4 + (ci >> 2)) * cout_pad + co) * 4 + (ci & 3)] * scale;
+    }
+    const _Float16 h = (_Float16)x;
+    v[j] = hl ? (_Float16)(x - (float)h) : h;
+  }
+  out[e] = __builtin_bit_cast(uint4, v);
+}
+
+}  // namespace
+
+size_t conv_f16_weight_bytes(int cin, int cout_pad, int taps) {
+  return (size_t)((cin + 15) / 16) * taps * 4 * cout_pad * 16;
+}
+
+hipError_t launch_split_pack(const float* wpk32, int cin, int cout_pad, int taps, unsigned* maxbits_dev, void* out,
+                             float* inv_scale_out, hipStream_t s) {
+  const int chunks = (cin + 15) / 16;
+  hipError_t e = hipMemsetAsync(maxbits_dev, 0, sizeof(unsigned), s);
+  if (e != hipSuccess) return e;
+  const long n = (long)chunks * 36 * cout_pad * 4;
+  hipLaunchKernelGGL(absmax_kernel, dim3(64), dim3(256), 0, s, wpk32, n, maxbits_dev);
+  const long total = (long)chunks * taps * 4 * cout_pad;
+  hipLaunchKernelGGL(split_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, wpk32, chunks, cout_pad, taps,
+                     maxbits_dev, reinterpret_cast<uint4*>(out), inv_scale_out);
+  return hipGetLastError();
+}
+
+hipError_t launch_conv3x3_f16(const ConvDesc& d, const float* in, float* out, int H, int W, hipStream_t s) {
+  if (H < 2 || W < 2 || (d.flags & CONV_IN_NCHW3) || !d.wpk16) return hipErrorInvalidValue;
+  F16Args a;
+  a.in = in; a.out = out; a.wpk = reinterpret_cast<const uint4*>(d.wpk16); a.bias = d.bias;
+  a.inv_scale_ptr = d.inv_scale_ptr; a.inv_scale = d.inv_scale;
+  a.H = H; a.W = W;
+  a.up_in = (d.flags & CONV_UP_IN) ? 1 : 0;
+  a.inH = a.up_in ? H / 2 : H; a.inW = a.up_in ? W / 2 : W;
+  a.cin = d.cin; a.cout = d.cout; a.cin_chunks = d.cin_chunks; a.cout_pad = d.cout_pad;
+  a.tiles_x = (W + FTW - 1) / FTW; a.tiles_y = (H + FTH - 1) / FTH;
+  a.relu = (d.flags & CONV_NO_RELU) ? 0 : 1;
+  const bool pool = d.flags & CONV_POOL_OUT, out3 = d.flags & CONV_OUT_NCHW3;
+  const size_t act_b = (size_t)4 * NPP * 16;
+  if (d.cout_pad == 16) {
+    a.taps = 10;
+    const size_t lds = act_b + (size_t)40 * 16 * 16;
+    if (out3) return pool ? hipErrorInvalidValue : launch_k(conv3x3_f16_c16_kernel<false, true>, a, lds, 1, s);
+    return pool ? launch_k(conv3x3_f16_c16_kernel<true, false>, a, lds, 1, s) : launch_k(conv3x3_f16_c16_kernel<false, false>, a, lds, 1, s);
+  }
+  if (out3) return hipErrorInvalidValue;
+  a.taps = 9;
+  int ct = d.cout_pad / 32, groups = 1;
+  if (ct > 4) {
+    if (d.cout_pad % 128) return hipErrorInvalidValue;
+    groups = d.cout_pad / 128; ct = 4;
+  }
+  const size_t lds = act_b + (size_t)36 * ct * 32 * 16;
+#define WCT_F16_CASE(CTV) \
+  case CTV: return pool ? launch_k(conv3x3_f16_kernel<CTV, true>, a, lds, groups, s) : launch_k(conv3x3_f16_kernel<CTV, false>, a, lds, groups, s);
+  switch (ct) {
+    WCT_F16_CASE(1) WCT_F16_CASE(2) WCT_F16_CASE(4)
+    default: return hipErrorInvalidValue;
+  }
+#undef WCT_F16_CASE
+}

@@ -4,7 +4,9 @@
 #include "../../include/wct_hip.h"
 #include "wct_common.h"
 
+#include <cmath>
 #include <cstdarg>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <map>
@@ -25,6 +27,7 @@ struct LayerDev {
   float* bias_raw = nullptr;
   float* wpk = nullptr;
   float* bias = nullptr;
+  void* wpk16 = nullptr;  // split-f16 weights (all but the 3-channel first conv)
 };
 
 struct Module {
@@ -46,7 +49,8 @@ struct wct_ctx {
   std::string err;
   Module mod[2][6];
   // workspace
-  DevBuf actA, actB, featC, featS, tmpT, wsMom, wsSolve, small, foldW;
+  DevBuf actA, actB, featC, featS, tmpT, wsMom, wsSolve, small, foldW, foldW16;
+  int conv_mode = 1;  // 0: exact-fp32 MFMA everywhere; 1: split-f16 (f16x3) MFMA for all but the first conv
   // profiling
   bool prof = false;
   std::vector<ProfRec> recs;
@@ -136,15 +140,16 @@ void prof_collect(wct_ctx* ctx) {
 // ---- one conv launch, with algorithmic work accounting ---------------------------------------------
 int run_conv(wct_ctx* ctx, const ConvDesc& d, const float* in, float* out, int H, int W) {
   char name[48];
-  const int ct = d.cout_pad > 128 ? 8 : d.cout_pad / 16;
-  snprintf(name, sizeof name, "conv3x3<ct=%d%s%s%s>", ct, (d.flags & CONV_IN_NCHW3) ? ",in3" : "",
-           (d.flags & CONV_POOL_OUT) ? ",pool" : "", (d.flags & CONV_OUT_NCHW3) ? ",out3" : "");
+  const bool f16 = ctx->conv_mode == 1 && d.wpk16 && !(d.flags & CONV_IN_NCHW3);
+  snprintf(name, sizeof name, "conv3x3%s<co=%d%s%s%s>", f16 ? "_f16x3" : "_f32", d.cout_pad > 128 ? 128 : d.cout_pad,
+           (d.flags & CONV_IN_NCHW3) ? ",in3" : "", (d.flags & CONV_POOL_OUT) ? ",pool" : "", (d.flags & CONV_OUT_NCHW3) ? ",out3" : "");
   const double px = (double)H * W;
   const double in_px = (d.flags & CONV_UP_IN) ? px / 4 : px, out_px = (d.flags & CONV_POOL_OUT) ? px / 4 : px;
   const double flops = 2.0 * 9 * d.cin * d.cout * px;
   const double bytes = 4.0 * (in_px * d.cin + out_px * d.cout + 9.0 * d.cin * d.cout);
   ProfScope ps(ctx, name, flops, bytes);
-  HIPCHK(ctx, launch_conv3x3(d, in, out, H, W, ctx->stream));
+  if (f16) HIPCHK(ctx, launch_conv3x3_f16(d, in, out, H, W, ctx->stream));
+  else HIPCHK(ctx, launch_conv3x3(d, in, out, H, W, ctx->stream));
   return WCT_OK;
 }
 
@@ -185,6 +190,31 @@ void pack_weights(const float* w, const float* b, int cout, int cin, int cout_pa
   }
 }
 
+// split-f16 packing of a static layer: [chunk][taps][hl][kh][cout_pad] x 8 halfs, scaled by 2^e with
+// max|w| * 2^e in [256, 512) so that the lo parts are normal f16 numbers; returns 2^-e
+float pack_weights_f16(const float* w, int cout, int cin, int cout_pad, int taps, std::vector<_Float16>& out) {
+  float mx = 0.f;
+  for (size_t i = 0; i < (size_t)cout * cin * 9; ++i) mx = std::max(mx, std::fabs(w[i]));
+  int ex = 0;
+  if (mx > 0.f && std::isfinite(mx)) { (void)std::frexp(mx, &ex); ex = 9 - ex; }
+  const float scale = std::ldexp(1.f, ex);
+  const int chunks = (cin + 15) / 16;
+  out.assign((size_t)chunks * taps * 4 * cout_pad * 8, (_Float16)0.f);
+  for (int o = 0; o < cout; ++o)
+    for (int i = 0; i < cin; ++i) {
+      const int chunk = i / 16, kh = (i % 16) / 8, j = i % 8;
+      for (int t = 0; t < 9; ++t) {
+        const float x = w[((size_t)o * cin + i) * 9 + t] * scale;
+        const _Float16 h = (_Float16)x;
+        const _Float16 l = (_Float16)(x - (float)h);
+        const size_t base = ((size_t)chunk * taps + t) * 4;
+        out[((base + 0 * 2 + kh) * cout_pad + o) * 8 + j] = h;
+        out[((base + 1 * 2 + kh) * cout_pad + o) * 8 + j] = l;
+      }
+    }
+  return std::ldexp(1.f, -ex);
+}
+
 int upload(wct_ctx* ctx, float** dst, const std::vector<float>& v) {
   HIPCHK(ctx, hipMalloc(reinterpret_cast<void**>(dst), v.size() * sizeof(float)));
   HIPCHK(ctx, hipMemcpy(*dst, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -196,6 +226,7 @@ void free_module(Module& m) {
     if (l.w_oihw) (void)hipFree(l.w_oihw);
     if (l.bias_raw) (void)hipFree(l.bias_raw);
     if (l.wpk) (void)hipFree(l.wpk);
+    if (l.wpk16) (void)hipFree(l.wpk16);
     if (l.bias) (void)hipFree(l.bias);
   }
   m.layers.clear();
@@ -321,6 +352,19 @@ int fold_impl(wct_ctx* ctx, int level, const double* M, const double* b, ConvDes
   out = l.d;
   out.wpk = wpk;
   out.bias = bias;
+  out.wpk16 = nullptr;
+  out.inv_scale_ptr = nullptr;
+  if (ctx->conv_mode == 1) {
+    const int taps = l.d.cout_pad == 16 ? 10 : 9;
+    const size_t b16 = conv_f16_weight_bytes(l.d.cin, l.d.cout_pad, taps);
+    if (int rc = ensure(ctx, ctx->foldW16, b16 + 64)) return rc;
+    char* base = reinterpret_cast<char*>(ctx->foldW16.p);
+    float* inv = reinterpret_cast<float*>(base + b16);
+    unsigned* maxbits = reinterpret_cast<unsigned*>(base + b16 + 16);
+    HIPCHK(ctx, launch_split_pack(wpk, l.d.cin, l.d.cout_pad, taps, maxbits, base, inv, ctx->stream));
+    out.wpk16 = base;
+    out.inv_scale_ptr = inv;
+  }
   return WCT_OK;
 }
 
@@ -372,6 +416,7 @@ int wct_create(int device, wct_ctx** out) {
   wct_ctx* c = new (std::nothrow) wct_ctx();
   if (!c) return WCT_ERR_NOMEM;
   c->device = device;
+  if (const char* m = getenv("WCT_CONV_MODE")) c->conv_mode = (m[0] == '0' || !strcmp(m, "fp32")) ? 0 : 1;
   *out = c;
   return WCT_OK;
 }
@@ -383,7 +428,7 @@ void wct_destroy(wct_ctx* ctx) {
   prof_collect(ctx);
   for (int k = 0; k < 2; ++k)
     for (int l = 0; l < 6; ++l) free_module(ctx->mod[k][l]);
-  for (DevBuf* b : {&ctx->actA, &ctx->actB, &ctx->featC, &ctx->featS, &ctx->tmpT, &ctx->wsMom, &ctx->wsSolve, &ctx->small, &ctx->foldW}) release(*b);
+  for (DevBuf* b : {&ctx->actA, &ctx->actB, &ctx->featC, &ctx->featS, &ctx->tmpT, &ctx->wsMom, &ctx->wsSolve, &ctx->small, &ctx->foldW, &ctx->foldW16}) release(*b);
   delete ctx;
 }
 
@@ -439,6 +484,14 @@ int wct_load_module(wct_ctx* ctx, int kind, int level, int n_layers, const wct_l
     if (int rc = upload(ctx, &ld.wpk, wpk)) return rc;
     if (int rc = upload(ctx, &ld.bias, bias)) return rc;
     ld.d.wpk = ld.wpk; ld.d.bias = ld.bias;
+    if (!in3) {
+      std::vector<_Float16> w16;
+      const int taps = ld.d.cout_pad == 16 ? 10 : 9;
+      ld.d.inv_scale = pack_weights_f16(L.weight, L.cout, L.cin, ld.d.cout_pad, taps, w16);
+      HIPCHK(ctx, hipMalloc(&ld.wpk16, w16.size() * sizeof(_Float16)));
+      HIPCHK(ctx, hipMemcpy(ld.wpk16, w16.data(), w16.size() * sizeof(_Float16), hipMemcpyHostToDevice));
+      ld.d.wpk16 = ld.wpk16;
+    }
     if (kind == WCT_KIND_DEC && i == 0) {
       std::vector<float> raw(L.weight, L.weight + (size_t)L.cout * L.cin * 9), rb(L.bias, L.bias + L.cout);
       if (int rc = upload(ctx, &ld.w_oihw, raw)) return rc;
@@ -642,6 +695,13 @@ int wct_reserve(wct_ctx* ctx, int H, int W, int Hs, int Ws) {
   if (int rc = ensure(ctx, ctx->wsSolve, solve_workspace_bytes(cmax))) return rc;
   SmallView sv;
   return small_view(ctx, sv);
+}
+
+int wct_set_conv_mode(wct_ctx* ctx, int mode) {
+  if (!ctx) return WCT_ERR_INVALID;
+  if (mode != 0 && mode != 1) return fail(ctx, WCT_ERR_INVALID, "conv mode must be 0 (fp32) or 1 (f16x3)");
+  ctx->conv_mode = mode;
+  return WCT_OK;
 }
 
 int wct_profile_enable(wct_ctx* ctx, int on) {

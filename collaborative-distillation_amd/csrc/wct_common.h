@@ -23,11 +23,22 @@ struct ConvDesc {
   int flags;
   const float* wpk;    // device, packed [chunk][tap][kq][cout_pad][4]  (IN_NCHW3: [tap][4][cout_pad])
   const float* bias;   // device, [cout_pad]
+  // split-f16 ("f16x3") form of the same weights, conv3x3_f16.hip: [chunk][taps][hi/lo][kh][cout_pad] x 8 halfs,
+  // pre-multiplied by a power of two; the epilogue multiplies by inv_scale (or *inv_scale_ptr when non-null)
+  const void* wpk16 = nullptr;
+  float inv_scale = 1.f;
+  const float* inv_scale_ptr = nullptr;
 };
 
 // Launch one conv layer.  (H, W) = spatial size the convolution runs at (after the fused upsample,
 // before the fused pool).  `in` is NHWC [inH*inW][cin] (or planar 3xHxW), `out` NHWC or planar.
 hipError_t launch_conv3x3(const ConvDesc& d, const float* in, float* out, int H, int W, hipStream_t s);
+
+hipError_t launch_conv3x3_f16(const ConvDesc& d, const float* in, float* out, int H, int W, hipStream_t s);
+size_t conv_f16_weight_bytes(int cin, int cout_pad, int taps);
+// fp32 packed weights (device) -> scaled split-f16 packed weights + inverse scale (device scalar)
+hipError_t launch_split_pack(const float* wpk32, int cin, int cout_pad, int taps, unsigned* maxbits_dev, void* out,
+                             float* inv_scale_out, hipStream_t s);
 
 // ---- layout
 hipError_t launch_nhwc_to_nchw(const float* in, float* out, int C, int npix, hipStream_t s);

@@ -290,6 +290,10 @@ class WCT:
                                         out.data_ptr(), byref(ho), byref(wo)))
         return out.view(-1)[: 3 * ho.value * wo.value].view(1, 3, ho.value, wo.value)
 
+    def set_conv_mode(self, mode: str):
+        """'f16x3' (default: split-f16 MFMA, fp32-class accuracy) or 'fp32' (exact fp32 MFMA)."""
+        self._chk(self._lib.wct_set_conv_mode(self._ctx, {"fp32": 0, "f16x3": 1}[mode]))
+
     def reserve(self, H, W, Hs, Ws):
         self._chk(self._lib.wct_reserve(self._ctx, H, W, Hs, Ws))
 

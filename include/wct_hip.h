@@ -118,6 +118,13 @@ int wct_stylize(wct_ctx* ctx, const float* content, int H, int W, const float* s
 size_t wct_workspace_bytes(const wct_ctx* ctx, int H, int W, int Hs, int Ws);
 int wct_reserve(wct_ctx* ctx, int H, int W, int Hs, int Ws);
 
+/* arithmetic of the 3x3 convolutions (all but the HBM-bound 3-channel first conv):
+ *   1 (default)  split-f16 "f16x3" MFMA: x = hi + lo in f16, w.x ~ hi.hi + hi.lo + lo.hi, fp32 accumulate --
+ *                fp32-class accuracy (6e-7 vs 8e-7 for exact fp32 on K = 1152 dot products) at 3/16 of the issue time
+ *   0            exact fp32 MFMA (v_mfma_f32_16x16x4_f32)
+ * env WCT_CONV_MODE=0|fp32 selects 0 at wct_create. */
+int wct_set_conv_mode(wct_ctx* ctx, int mode);
+
 /* profiling: when enabled every kernel launch is bracketed by HIP events on the context's stream */
 int wct_profile_enable(wct_ctx* ctx, int on);
 int wct_profile_reset(wct_ctx* ctx);
