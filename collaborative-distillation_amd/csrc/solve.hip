@@ -10,6 +10,10 @@
 // The reference multiplies the C x hw feature map by Wc and then by Ss (two skinny fp64 GEMMs, its
 // dominant cost); here T is formed once (C^3) and applied inside the decoder's first convolution.
 //
+// Two steps so that the style side can run ahead on its own stream (it does not depend on the content):
+//   launch_eig       moments of ONE feature map -> EigResult {G = V diag(lambda), lambda, mu, floor}
+//   launch_assemble  two EigResults -> M, b
+//
 // Eigen-decomposition: one-sided (Hestenes) Jacobi in fp64 on G = cov.  Rotating column pairs of G from
 // the right until all columns are mutually orthogonal leaves G = V diag(lambda): the column norms are the
 // eigenvalues and the normalised columns the eigenvectors, so no separate V is accumulated and a C<=128
@@ -18,15 +22,20 @@
 // Rank policy: the reference keeps every singular value >= 1e-100 (util_wct.py:25,82-86), i.e. all of
 // them -- null directions get lambda ~ 1e-15 from LAPACK and are multiplied into exactly-zero centred
 // features.  Jacobi returns the same directions with tiny norms; directions with
-// lambda <= rel_thresh * lambda_max are dropped (rel_thresh 1e-10; live spectra sit >= 13 decades above
-// the noise), which reproduces the reference to <= 2e-6 in every regime of tests/golden/g3.
+// lambda <= max(rel_thresh * lambda_max, ABS_FLOOR * max E[x^2]) are dropped (rel_thresh 1e-10; live spectra
+// sit >= 13 decades above the noise), which reproduces the reference to <= 2e-6 in every regime of
+// tests/golden/g3.  The absolute floor is the round-off level of the covariance itself (formed from raw fp64
+// sums of magnitude E[x^2]); it makes a constant feature map (cov = 0 up to round-off) whiten to exactly 0 like
+// the reference's exact-zero centred features do (k_c = 0 -> target = s_mean, util_wct.py:82-86,117-126).
 #include "wct_common.h"
+#include <cstdlib>
 
 namespace {
 
-constexpr int LPP = 16;        // lanes per column pair
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+
 constexpr int MAX_SWEEPS = 40;
-constexpr double ROT_TOL = 1e-13;  // relative off-diagonal; quadratic convergence overshoots this by far
+constexpr double ROT_TOL = 1e-12;  // relative off-diagonal; quadratic convergence overshoots this by far
 constexpr double ABS_FLOOR = 1e-13;
 
 __device__ __forceinline__ void tournament_pair(int n, int round, int k, int& p, int& q) {
@@ -37,39 +46,48 @@ __device__ __forceinline__ void tournament_pair(int n, int round, int k, int& p,
   if (p > q) { const int t = p; p = q; q = t; }
 }
 
-__device__ __forceinline__ double rotation(double al, double be, double ga, double& c, double& s) {
-  // Rutishauser: zero the (p,q) entry of G^T G; returns t = s/c
-  const double zeta = (be - al) / (2.0 * ga);
-  const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-  c = 1.0 / sqrt(1.0 + t * t);
-  s = c * t;
-  return t;
+// 1/sqrt(x) to fp64 round-off: hardware estimate (v_rsq_f64, ~2^-26) + two Newton steps
+__device__ __forceinline__ double rsqrt_nr(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  y = y * (1.5 - 0.5 * x * y * y);
+  y = y * (1.5 - 0.5 * x * y * y);
+  return y;
 }
 
-struct CovArgs {
-  int C;
-  double n[2];
-  const double* sum[2];
-  const double* sumsq[2];
-  double* mu;   // [2][C]
-  double* G;    // [2][C*C]
-};
+// Jacobi rotation that zeroes the (p,q) entry of G^T G, division-free:
+//   d = be - al, h = hypot(d, 2 ga), c^2 = (1 + |d|/h)/2, s = sign(d) ga / (h c), t = s / c
+// (equivalent to Rutishauser's t = sign(zeta)/(|zeta| + sqrt(1 + zeta^2)), zeta = d/(2 ga): the small-angle root)
+__device__ __forceinline__ double rotation(double al, double be, double ga, double& c, double& s) {
+  const double d = be - al, g2 = 2.0 * ga;
+  const double rh = rsqrt_nr(d * d + g2 * g2);       // 1/h
+  const double c2 = 0.5 + 0.5 * fabs(d) * rh;        // in [0.5, 1]
+  const double rc = rsqrt_nr(c2);                    // 1/c
+  c = c2 * rc;
+  const double sg = d >= 0 ? ga : -ga;
+  s = sg * rh * rc;
+  return s * rc;                                     // t
+}
 
-__global__ void cov_kernel(CovArgs a) {
-  const int which = blockIdx.y;
+// ---- EigResult layout (doubles): G[C*C] | lam[C] | mu[C] | floor | pad(3)
+__host__ __device__ inline size_t eig_doubles(int C) { return (size_t)C * C + 2 * (size_t)C + 4; }
+
+__global__ void cov_kernel(int C, double n, const double* sum, const double* sumsq, double* res) {
   const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  const int C = a.C;
   if (e >= (long)C * C) return;
   const int r = (int)(e / C), c = (int)(e % C);
-  const double n = a.n[which];
-  const double mr = a.sum[which][r] / n, mc = a.sum[which][c] / n;
+  const double mr = sum[r] / n, mc = sum[c] / n;
   // symmetric by construction: use the (min,max) entry for both halves
   const int lo = r < c ? r : c, hi = r < c ? c : r;
-  a.G[(size_t)which * C * C + e] = (a.sumsq[which][(size_t)lo * C + hi] - n * mr * mc) / (n - 1.0);
-  if (c == 0) a.mu[which * C + r] = mr;
+  res[e] = (sumsq[(size_t)lo * C + hi] - n * mr * mc) / (n - 1.0);
+  if (c == 0) res[(size_t)C * C + C + r] = mr;  // mu
+  if (e == 0) {
+    double ex2 = 0.;
+    for (int j = 0; j < C; ++j) ex2 = fmax(ex2, sumsq[(size_t)j * C + j]);
+    res[(size_t)C * C + 2 * C] = ABS_FLOOR * ex2 / n;
+  }
 }
 
-// ---- 16-lane all-reduce of an fp64 value with DPP moves (no LDS crossbar round trips):
+// ---- all-reduce of an fp64 value over the LPP (4, 8 or 16) lanes of a pair with DPP moves (no LDS round trips):
 //      quad_perm[1,0,3,2], quad_perm[2,3,0,1] -> quad sums; row_half_mirror -> 8-lane sums; row_mirror -> 16.
 template <int CTRL>
 __device__ __forceinline__ double dpp_mov(double v) {
@@ -77,11 +95,12 @@ __device__ __forceinline__ double dpp_mov(double v) {
   const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
   return __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ double reduce16(double v) {
+template <int LPP>
+__device__ __forceinline__ double reduce_pair(double v) {
   v += dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]
   v += dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
-  v += dpp_mov<0x141>(v);  // row_half_mirror
-  v += dpp_mov<0x140>(v);  // row_mirror
+  if constexpr (LPP >= 8) v += dpp_mov<0x141>(v);   // row_half_mirror
+  if constexpr (LPP >= 16) v += dpp_mov<0x140>(v);  // row_mirror
   return v;
 }
 
@@ -90,25 +109,25 @@ __device__ __forceinline__ double reduce16(double v) {
 //    SURVEY 7) are compacted away first -- their rows/columns of cov are zero, so they are eigenvectors with
 //    lambda = 0 and the Jacobi problem shrinks to the live block;
 //  * column norms are cached in LDS and updated by the rotation (alpha' = alpha - t*gamma, beta' = beta + t*gamma);
-//    round 0 of every sweep recomputes them exactly, so only ONE dot product per pair is reduced per round.
-__global__ __launch_bounds__(1024) void jacobi_lds_kernel(double* Gall, double* lamAll, int n_full, const double* sumsqAll0,
-                                                          const double* sumsqAll1, double npix0, double npix1, int* info) {
+//    round 0 of every sweep recomputes them exactly, so only ONE dot product per pair is reduced per round;
+//  * the kernel is bound by fp64 VALU issue on ONE CU: LPP lanes share a pair (each lane owns 2-row groups read as
+//    ds_read_b128), so the per-pair rotation arithmetic is amortised over 64/LPP pairs per wave instruction.
+template <int LPP>
+__global__ __launch_bounds__(64 * LPP) void jacobi_lds_kernel(double* res, int n_full, int* info) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int which = blockIdx.x;
+  __builtin_amdgcn_s_setprio(3);  // latency-critical single-CU kernel: win issue arbitration against co-resident conv waves
   const int tid = threadIdx.x;
-  double* Gg = Gall + (size_t)which * n_full * n_full;
-  const double* sumsq = which ? sumsqAll1 : sumsqAll0;
-  const double npix = which ? npix1 : npix0;
-  // carve: G [n_full][n_full+2] | norm2 [n_full] | live [n_full] ints | flag
-  const int LD = n_full + 2;
+  double* Gg = res;
+  double* lamg = res + (size_t)n_full * n_full;
+  const double floor_ = res[(size_t)n_full * n_full + 2 * n_full];
+  // carve: G [n_full][LD] | norm2 [n_full] | live [n_full] ints | flags.  LD: rows padded to a multiple of 32 (whole
+  // 2*LPP-row groups are read; rows >= n hold zeros and stay zero under rotations) + 2 (bank spread)
+  const int LD = (n_full + 31) / 32 * 32 + 2;
   double* G = reinterpret_cast<double*>(smem);
   double* norm2 = G + (size_t)n_full * LD;
   int* live = reinterpret_cast<int*>(norm2 + n_full);
   volatile int* rotated = live + n_full;      // [0] rotation flag, [1] n (live count, even)
   if (tid == 0) {
-    double ex2 = 0.;
-    for (int j = 0; j < n_full; ++j) ex2 = fmax(ex2, sumsq[(size_t)j * n_full + j]);
-    const double floor_ = ABS_FLOOR * ex2 / npix;
     int nl = 0;
     for (int j = 0; j < n_full; ++j)
       if (Gg[(size_t)j * n_full + j] > floor_) live[nl++] = j;
@@ -121,49 +140,68 @@ __global__ __launch_bounds__(1024) void jacobi_lds_kernel(double* Gall, double* 
   }
   __syncthreads();
   const int n = rotated[1];
+  for (int e = tid; e < n_full * LD; e += blockDim.x) G[e] = 0.;   // rows >= n of a column read as 0 below
+  __syncthreads();
   for (int e = tid; e < n * n; e += blockDim.x) {
     const int cj = e / n, r = e - cj * n;
     G[cj * LD + r] = Gg[(size_t)live[cj] * n_full + live[r]];
   }
   __syncthreads();
-  const int npairs = n >> 1;
+  const int npairs = n >> 1, m_ = n - 1;
   const int pair = tid / LPP, sub = tid % LPP;
   const bool active = pair < npairs;
-  constexpr int MAXR = 128 / LPP;
+  constexpr int MAXG = 128 / (2 * LPP);        // 2-row groups per lane
+  const int ngroups = (n + 2 * LPP - 1) / (2 * LPP);
   int sweep = 0;
   for (; sweep < MAX_SWEEPS && n >= 2; ++sweep) {
+    // circle method: player n-1 stays, the others rotate; positions advance by one each round (no modulo)
+    int pa = pair % (m_ > 0 ? m_ : 1), pb = (m_ - pair) % (m_ > 0 ? m_ : 1);
     for (int round = 0; round < n - 1; ++round) {
       if (active) {
-        int p, q;
-        tournament_pair(n, round, pair, p, q);
-        double gp[MAXR], gq[MAXR];
-        double al = 0., be = 0., ga = 0.;
+        int p = pair == 0 ? m_ : pa, q = pair == 0 ? pa : pb;  // pair 0: (n-1, round mod m)
+        if (p > q) { const int t_ = p; p = q; q = t_; }
+        const double* colp = G + p * LD + 2 * sub;
+        const double* colq = G + q * LD + 2 * sub;
+        f64x2 gp[MAXG], gq[MAXG];
+        double ga0 = 0., ga1 = 0.;
 #pragma unroll
-        for (int m = 0; m < MAXR; ++m) {
-          const int r = sub + LPP * m;
-          gp[m] = r < n ? G[p * LD + r] : 0.;
-          gq[m] = r < n ? G[q * LD + r] : 0.;
-          ga += gp[m] * gq[m];
+        for (int g = 0; g < MAXG; ++g) {
+          if (g < ngroups) {
+            gp[g] = *reinterpret_cast<const f64x2*>(colp + 2 * LPP * g);
+            gq[g] = *reinterpret_cast<const f64x2*>(colq + 2 * LPP * g);
+            ga0 += gp[g][0] * gq[g][0]; ga1 += gp[g][1] * gq[g][1];
+          }
         }
+        double al, be;
         if (round == 0) {
+          double a0 = 0., a1 = 0., b0 = 0., b1 = 0.;
 #pragma unroll
-          for (int m = 0; m < MAXR; ++m) { al += gp[m] * gp[m]; be += gq[m] * gq[m]; }
-          al = reduce16(al); be = reduce16(be);
+          for (int g = 0; g < MAXG; ++g) {
+            if (g < ngroups) {
+              a0 += gp[g][0] * gp[g][0]; a1 += gp[g][1] * gp[g][1];
+              b0 += gq[g][0] * gq[g][0]; b1 += gq[g][1] * gq[g][1];
+            }
+          }
+          al = reduce_pair<LPP>(a0 + a1); be = reduce_pair<LPP>(b0 + b1);
         } else {
           al = norm2[p]; be = norm2[q];
         }
-        ga = reduce16(ga);
+        const double ga = reduce_pair<LPP>(ga0 + ga1);
         bool rot = false;
         double t = 0.;
-        if (fabs(ga) > ROT_TOL * sqrt(al * be) && al * be > 0.) {
+        if (ga * ga > (ROT_TOL * ROT_TOL) * al * be && al * be > 0.) {
           double c, s;
           t = rotation(al, be, ga, c, s);
+          double* wp = G + p * LD + 2 * sub;
+          double* wq = G + q * LD + 2 * sub;
 #pragma unroll
-          for (int m = 0; m < MAXR; ++m) {
-            const int r = sub + LPP * m;
-            if (r < n) {
-              G[p * LD + r] = c * gp[m] - s * gq[m];
-              G[q * LD + r] = s * gp[m] + c * gq[m];
+          for (int g = 0; g < MAXG; ++g) {
+            if (g < ngroups) {
+              f64x2 np_, nq_;
+              np_[0] = c * gp[g][0] - s * gq[g][0]; np_[1] = c * gp[g][1] - s * gq[g][1];
+              nq_[0] = s * gp[g][0] + c * gq[g][0]; nq_[1] = s * gp[g][1] + c * gq[g][1];
+              *reinterpret_cast<f64x2*>(wp + 2 * LPP * g) = np_;
+              *reinterpret_cast<f64x2*>(wq + 2 * LPP * g) = nq_;
             }
           }
           rot = true;
@@ -173,6 +211,8 @@ __global__ __launch_bounds__(1024) void jacobi_lds_kernel(double* Gall, double* 
           if (rot || round == 0) { norm2[p] = al - t * ga; norm2[q] = be + t * ga; }
         }
       }
+      pa = pa + 1 == m_ ? 0 : pa + 1;
+      pb = pb + 1 == m_ ? 0 : pb + 1;
       __syncthreads();
     }
     const int any = rotated[0];
@@ -183,31 +223,28 @@ __global__ __launch_bounds__(1024) void jacobi_lds_kernel(double* Gall, double* 
   }
   // eigenvalues = column norms (recomputed exactly); G = V diag(lambda) written back in the FULL index space
   for (int e = tid; e < n_full * n_full; e += blockDim.x) Gg[e] = 0.;
-  for (int j = tid; j < n_full; j += blockDim.x) lamAll[which * n_full + j] = 0.;
+  for (int j = tid; j < n_full; j += blockDim.x) lamg[j] = 0.;
   __syncthreads();
   for (int j = tid; j < n; j += blockDim.x) {
     double s = 0.;
     for (int r = 0; r < n; ++r) s += G[j * LD + r] * G[j * LD + r];
-    lamAll[which * n_full + j] = sqrt(s);
+    lamg[j] = sqrt(s);
   }
   for (int e = tid; e < n * n; e += blockDim.x) {
     const int cj = e / n, r = e - cj * n;
     Gg[(size_t)cj * n_full + live[r]] = G[cj * LD + r];  // column-major: column cj, full row index live[r]
   }
-  if (tid == 0) info[which] = sweep;
+  if (tid == 0 && info) *info = sweep;
 }
 
 // ---- C > 128: columns stay in global memory (L2 resident); one launch per tournament round, one wave per pair.
 //      flags[sweep] is raised when any rotation happened in that sweep; rounds of sweep s+1 return at once when
 //      flags[s] == 0, so a fixed launch schedule needs no host round trip.
-__global__ __launch_bounds__(256) void jacobi_round_global_kernel(double* Gall, int n, int round, int sweep, int* flags) {
-  const int which = blockIdx.y;
-  int* fl = flags + which * (MAX_SWEEPS + 1);
+__global__ __launch_bounds__(256) void jacobi_round_global_kernel(double* G, int n, int round, int sweep, int* fl) {
   if (sweep > 0 && fl[sweep - 1] == 0) return;
   const int lane = threadIdx.x & 63;
   const int pair = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (pair >= (n >> 1)) return;
-  double* G = Gall + (size_t)which * n * n;
   int p, q;
   tournament_pair(n, round, pair, p, q);
   constexpr int MAXR = 512 / 64;
@@ -222,7 +259,7 @@ __global__ __launch_bounds__(256) void jacobi_round_global_kernel(double* Gall, 
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) { al += __shfl_xor(al, o); be += __shfl_xor(be, o); ga += __shfl_xor(ga, o); }
-  if (fabs(ga) > ROT_TOL * sqrt(al * be) && al * be > 0.) {
+  if (ga * ga > (ROT_TOL * ROT_TOL) * al * be && al * be > 0.) {
     double c, s;
     rotation(al, be, ga, c, s);
 #pragma unroll
@@ -237,49 +274,48 @@ __global__ __launch_bounds__(256) void jacobi_round_global_kernel(double* Gall, 
   }
 }
 
-__global__ void colnorm_kernel(const double* Gall, double* lamAll, int n, const int* flags, int* info) {
-  const int which = blockIdx.y;
+__global__ void colnorm_kernel(double* res, int n, const int* fl, int* info) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j < n) {
-    const double* g = Gall + (size_t)which * n * n + (size_t)j * n;
+    const double* g = res + (size_t)j * n;
     double s = 0.;
     for (int r = 0; r < n; ++r) s += g[r] * g[r];
-    lamAll[which * n + j] = sqrt(s);
+    res[(size_t)n * n + j] = sqrt(s);
   }
-  if (j == 0) {
+  if (j == 0 && info) {
     int sw = 0;
-    const int* fl = flags + which * (MAX_SWEEPS + 1);
     while (sw < MAX_SWEEPS && fl[sw]) ++sw;
-    info[which] = sw;
+    *info = sw;
   }
 }
 
 // out[a][b] = sum_{j live} lambda_j^(expo-2) G[a,j] G[b,j]   (G = V diag(lambda), column-major)
-// live: lambda_j > max(rel_thresh * lambda_max, ABS_FLOOR * max_a E[x_a^2]).  The absolute floor is the
-// round-off level of the covariance itself (it is formed from raw fp64 sums of magnitude E[x^2]); it makes
-// a constant feature map (cov = 0 up to round-off) whiten to exactly 0 like the reference's exact-zero
-// centred features do (k_c = 0 -> target = s_mean, util_wct.py:82-86,117-126) instead of amplifying noise.
-__global__ void sym_power_kernel(const double* G, const double* lam, int n, double expo, double rel_thresh,
-                                 const double* sumsq, double npix, double* out) {
+__global__ __launch_bounds__(256) void sym_power_kernel(const double* res, int n, double expo, double rel_thresh, double* out) {
+  __shared__ double wj[512];
+  const double* G = res;
+  const double* lam = res + (size_t)n * n;
+  const double floor_ = res[(size_t)n * n + 2 * n];
+  double lmax = 0.;
+  for (int j = 0; j < n; ++j) lmax = fmax(lmax, lam[j]);
+  const double thr = fmax(rel_thresh * lmax, floor_);
+  for (int j = threadIdx.x; j < n; j += 256) {
+    const double l = lam[j];
+    wj[j] = (l > thr && l > 0.) ? pow(l, expo - 2.0) : 0.;
+  }
+  __syncthreads();
   const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= (long)n * n) return;
   const int a = (int)(e / n), b = (int)(e % n);
-  double lmax = 0., ex2 = 0.;
-  for (int j = 0; j < n; ++j) { lmax = fmax(lmax, lam[j]); ex2 = fmax(ex2, sumsq[(size_t)j * n + j]); }
-  const double thr = fmax(rel_thresh * lmax, ABS_FLOOR * ex2 / npix);
   double s = 0.;
-  for (int j = 0; j < n; ++j) {
-    const double l = lam[j];
-    if (l > thr && l > 0.) s += pow(l, expo - 2.0) * G[(size_t)j * n + a] * G[(size_t)j * n + b];
-  }
+  for (int j = 0; j < n; ++j) s += wj[j] * G[(size_t)j * n + a] * G[(size_t)j * n + b];
   out[e] = s;
 }
 
 struct FinArgs {
   int C;
   double alpha;
-  const double* Ss; const double* Wc; const double* mu;  // mu [2][C]: content, style
-  float* M32; float* b32; double* M64; double* b64; double* T;
+  const double* Ss; const double* Wc; const double* mu_c; const double* mu_s;
+  double* M64; double* b64; double* T;
 };
 
 __global__ void matmul_T_kernel(FinArgs f) {  // T = Ss Wc ; M = alpha T + (1-alpha) I
@@ -290,9 +326,7 @@ __global__ void matmul_T_kernel(FinArgs f) {  // T = Ss Wc ; M = alpha T + (1-al
   double s = 0.;
   for (int k = 0; k < C; ++k) s += f.Ss[(size_t)a * C + k] * f.Wc[(size_t)k * C + b];
   f.T[e] = s;
-  const double m = f.alpha * s + (a == b ? 1.0 - f.alpha : 0.0);
-  if (f.M64) f.M64[e] = m;
-  if (f.M32) f.M32[e] = (float)m;
+  f.M64[e] = f.alpha * s + (a == b ? 1.0 - f.alpha : 0.0);
 }
 
 __global__ void bias_kernel(FinArgs f) {  // b = alpha (mu_s - T mu_c)
@@ -300,63 +334,61 @@ __global__ void bias_kernel(FinArgs f) {  // b = alpha (mu_s - T mu_c)
   const int C = f.C;
   if (a >= C) return;
   double s = 0.;
-  for (int k = 0; k < C; ++k) s += f.T[(size_t)a * C + k] * f.mu[k];
-  const double b = f.alpha * (f.mu[C + a] - s);
-  if (f.b64) f.b64[a] = b;
-  if (f.b32) f.b32[a] = (float)b;
+  for (int k = 0; k < C; ++k) s += f.T[(size_t)a * C + k] * f.mu_c[k];
+  f.b64[a] = f.alpha * (f.mu_s[a] - s);
 }
 
 }  // namespace
 
-// workspace layout (doubles): G[2][C*C] | lam[2][C] | mu[2][C] | Wc[C*C] | Ss[C*C] | T[C*C] | flags (ints)
-size_t solve_workspace_bytes(int C) {
+size_t eig_result_bytes(int C) { return eig_doubles(C) * sizeof(double); }
+size_t eig_workspace_bytes(int C) { return C > 128 ? (MAX_SWEEPS + 1) * sizeof(int) : 16; }
+size_t assemble_workspace_bytes(int C) { return 3 * (size_t)C * C * sizeof(double); }
+
+hipError_t launch_eig(int C, double n, const double* sum, const double* sumsq, double* res, int* info_dev, void* ws,
+                      size_t ws_bytes, hipStream_t s) {
+  if (C < 2 || (C & 1) || C > 512 || n < 2) return hipErrorInvalidValue;  // unbiased covariance needs n >= 2
+  if (ws_bytes < eig_workspace_bytes(C)) return hipErrorOutOfMemory;
   const size_t cc = (size_t)C * C;
-  return (5 * cc + 4 * (size_t)C) * sizeof(double) + 2 * (MAX_SWEEPS + 1) * sizeof(int) + 64;
-}
-
-hipError_t launch_solve(int C, double n_c, const double* sum_c, const double* sumsq_c, double n_s,
-                        const double* sum_s, const double* sumsq_s, double alpha, double rel_thresh,
-                        float* M32, float* b32, double* M64, double* b64, int* info, void* ws, size_t ws_bytes,
-                        hipStream_t s) {
-  if (C < 2 || (C & 1) || C > 512) return hipErrorInvalidValue;
-  if (ws_bytes < solve_workspace_bytes(C)) return hipErrorOutOfMemory;
-  if (n_c < 2 || n_s < 2) return hipErrorInvalidValue;  // unbiased covariance needs n >= 2
-  const size_t cc = (size_t)C * C;
-  double* G = reinterpret_cast<double*>(ws);
-  double* lam = G + 2 * cc;
-  double* mu = lam + 2 * C;
-  double* Wc = mu + 2 * C;
-  double* Ss = Wc + cc;
-  double* T = Ss + cc;
-  int* flags = reinterpret_cast<int*>(T + cc);
-
-  CovArgs ca;
-  ca.C = C; ca.n[0] = n_c; ca.n[1] = n_s; ca.sum[0] = sum_c; ca.sum[1] = sum_s;
-  ca.sumsq[0] = sumsq_c; ca.sumsq[1] = sumsq_s; ca.mu = mu; ca.G = G;
-  hipLaunchKernelGGL(cov_kernel, dim3((unsigned)((cc + 255) / 256), 2), dim3(256), 0, s, ca);
-
+  hipLaunchKernelGGL(cov_kernel, dim3((unsigned)((cc + 255) / 256)), dim3(256), 0, s, C, n, sum, sumsq, res);
   if (C <= 128) {
-    const size_t lds = ((size_t)C * (C + 2) + C) * sizeof(double) + (size_t)(C + 4) * sizeof(int);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(jacobi_lds_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const size_t lds = ((size_t)C * ((C + 31) / 32 * 32 + 2) + C) * sizeof(double) + (size_t)(C + 4) * sizeof(int);
+    static int lpp = [] { const char* e = getenv("WCT_JACOBI_LPP"); return e ? atoi(e) : 16; }();
+    auto go = [&](auto kern, int LPPv) -> hipError_t {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return e;
+      const unsigned threads = (unsigned)(((C / 2) * LPPv + 63) / 64 * 64);
+      hipLaunchKernelGGL(kern, dim3(1), dim3(threads), lds, s, res, C, info_dev);
+      return hipSuccess;
+    };
+    hipError_t e = lpp == 16 ? go(jacobi_lds_kernel<16>, 16) : lpp == 8 ? go(jacobi_lds_kernel<8>, 8) : go(jacobi_lds_kernel<4>, 4);
     if (e != hipSuccess) return e;
-    const unsigned threads = (unsigned)(((C / 2) * LPP + 63) / 64 * 64);
-    hipLaunchKernelGGL(jacobi_lds_kernel, dim3(2), dim3(threads), lds, s, G, lam, C, sumsq_c, sumsq_s, n_c, n_s, info);
   } else {
-    hipError_t e = hipMemsetAsync(flags, 0, 2 * (MAX_SWEEPS + 1) * sizeof(int), s);
+    int* flags = reinterpret_cast<int*>(ws);
+    hipError_t e = hipMemsetAsync(flags, 0, (MAX_SWEEPS + 1) * sizeof(int), s);
     if (e != hipSuccess) return e;
     const int sweeps = 16;  // fp64 cyclic Jacobi converges quadratically; later sweeps exit at once via flags
-    const dim3 grid((unsigned)((C / 2 + 3) / 4), 2);
+    const dim3 grid((unsigned)((C / 2 + 3) / 4));
     for (int sw = 0; sw < sweeps; ++sw)
       for (int r = 0; r < C - 1; ++r)
-        hipLaunchKernelGGL(jacobi_round_global_kernel, grid, dim3(256), 0, s, G, C, r, sw, flags);
-    hipLaunchKernelGGL(colnorm_kernel, dim3((unsigned)((C + 255) / 256), 2), dim3(256), 0, s, G, lam, C, flags, info);
+        hipLaunchKernelGGL(jacobi_round_global_kernel, grid, dim3(256), 0, s, res, C, r, sw, flags);
+    hipLaunchKernelGGL(colnorm_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, s, res, C, flags, info_dev);
   }
+  return hipGetLastError();
+}
+
+hipError_t launch_assemble(int C, const double* eig_c, const double* eig_s, double alpha, double rel_thresh, double* M,
+                           double* b, void* ws, size_t ws_bytes, hipStream_t s) {
+  if (ws_bytes < assemble_workspace_bytes(C)) return hipErrorOutOfMemory;
+  const size_t cc = (size_t)C * C;
+  double* Wc = reinterpret_cast<double*>(ws);
+  double* Ss = Wc + cc;
+  double* T = Ss + cc;
   const unsigned nb = (unsigned)((cc + 255) / 256);
-  hipLaunchKernelGGL(sym_power_kernel, dim3(nb), dim3(256), 0, s, G, lam, C, -0.5, rel_thresh, sumsq_c, n_c, Wc);
-  hipLaunchKernelGGL(sym_power_kernel, dim3(nb), dim3(256), 0, s, G + cc, lam + C, C, 0.5, rel_thresh, sumsq_s, n_s, Ss);
+  hipLaunchKernelGGL(sym_power_kernel, dim3(nb), dim3(256), 0, s, eig_c, C, -0.5, rel_thresh, Wc);
+  hipLaunchKernelGGL(sym_power_kernel, dim3(nb), dim3(256), 0, s, eig_s, C, 0.5, rel_thresh, Ss);
   FinArgs f;
-  f.C = C; f.alpha = alpha; f.Ss = Ss; f.Wc = Wc; f.mu = mu; f.M32 = M32; f.b32 = b32; f.M64 = M64; f.b64 = b64; f.T = T;
+  f.C = C; f.alpha = alpha; f.Ss = Ss; f.Wc = Wc; f.mu_c = eig_c + cc + C; f.mu_s = eig_s + cc + C;
+  f.M64 = M; f.b64 = b; f.T = T;
   hipLaunchKernelGGL(matmul_T_kernel, dim3(nb), dim3(256), 0, s, f);
   hipLaunchKernelGGL(bias_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, s, f);
   return hipGetLastError();

@@ -43,13 +43,23 @@ struct ProfRec {
 
 }  // namespace
 
+// An in-order execution lane: a stream plus the scratch only that stream touches.  `main` runs on the caller's
+// stream (content side, assembly, decode); `side` is a context-owned stream on which the style side (encode,
+// moments, eigen-decomposition -- independent of the content) runs ahead and overlaps the content side.
+struct Lane {
+  hipStream_t stream = nullptr;
+  DevBuf actA, actB, wsMom, wsEig, sums;  // sums: sum[512] | sumsq[512*512] (doubles) | info (ints)
+};
+
 struct wct_ctx {
   int device = 0;
-  hipStream_t stream = nullptr;
+  Lane main, side;
+  hipEvent_t ev_fork = nullptr, ev_style[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   std::string err;
   Module mod[2][6];
   // workspace
-  DevBuf actA, actB, featC, featS, tmpT, wsMom, wsSolve, small, foldW, foldW16;
+  DevBuf featC, featS, tmpT, wsAsm, small, foldW, foldW16, eigC, eigS[6];
+  int overlap = 1;    // 1: style side on the side lane (overlaps the content side); 0: everything on the caller's stream
   int conv_mode = 1;  // 0: exact-fp32 MFMA everywhere; 1: split-f16 (f16x3) MFMA for all but the first conv
   // profiling
   bool prof = false;
@@ -81,7 +91,8 @@ int ensure(wct_ctx* ctx, DevBuf& b, size_t bytes) {
   if (b.cap >= bytes) return WCT_OK;
   HIPCHK(ctx, hipSetDevice(ctx->device));
   if (b.p) {
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->main.stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->side.stream));
     HIPCHK(ctx, hipFree(b.p));
     b.p = nullptr; b.cap = 0;
   }
@@ -108,24 +119,26 @@ bool valid_level(int l) { return l >= 1 && l <= 5; }
 // ---- profiling wrapper -----------------------------------------------------------------------------
 struct ProfScope {
   wct_ctx* ctx;
+  hipStream_t st;
   bool on;
   ProfRec r;
-  ProfScope(wct_ctx* c, const char* name, double flops, double bytes) : ctx(c), on(c->prof) {
+  ProfScope(wct_ctx* c, hipStream_t stream, const char* name, double flops, double bytes) : ctx(c), st(stream), on(c->prof) {
     if (!on) return;
     r.name = name; r.flops = flops; r.bytes = bytes;
     (void)hipEventCreate(&r.e0); (void)hipEventCreate(&r.e1);
-    (void)hipEventRecord(r.e0, ctx->stream);
+    (void)hipEventRecord(r.e0, st);
   }
   ~ProfScope() {
     if (!on) return;
-    (void)hipEventRecord(r.e1, ctx->stream);
+    (void)hipEventRecord(r.e1, st);
     ctx->recs.push_back(r);
   }
 };
 
 void prof_collect(wct_ctx* ctx) {
   if (ctx->recs.empty()) return;
-  (void)hipStreamSynchronize(ctx->stream);
+  (void)hipStreamSynchronize(ctx->main.stream);
+  (void)hipStreamSynchronize(ctx->side.stream);
   for (auto& r : ctx->recs) {
     float ms = 0.f;
     (void)hipEventElapsedTime(&ms, r.e0, r.e1);
@@ -138,7 +151,7 @@ void prof_collect(wct_ctx* ctx) {
 }
 
 // ---- one conv launch, with algorithmic work accounting ---------------------------------------------
-int run_conv(wct_ctx* ctx, const ConvDesc& d, const float* in, float* out, int H, int W) {
+int run_conv(wct_ctx* ctx, Lane& ln, const ConvDesc& d, const float* in, float* out, int H, int W) {
   char name[48];
   const bool f16 = ctx->conv_mode == 1 && d.wpk16 && !(d.flags & CONV_IN_NCHW3);
   snprintf(name, sizeof name, "conv3x3%s<co=%d%s%s%s>", f16 ? "_f16x3" : "_f32", d.cout_pad > 128 ? 128 : d.cout_pad,
@@ -147,9 +160,9 @@ int run_conv(wct_ctx* ctx, const ConvDesc& d, const float* in, float* out, int H
   const double in_px = (d.flags & CONV_UP_IN) ? px / 4 : px, out_px = (d.flags & CONV_POOL_OUT) ? px / 4 : px;
   const double flops = 2.0 * 9 * d.cin * d.cout * px;
   const double bytes = 4.0 * (in_px * d.cin + out_px * d.cout + 9.0 * d.cin * d.cout);
-  ProfScope ps(ctx, name, flops, bytes);
-  if (f16) HIPCHK(ctx, launch_conv3x3_f16(d, in, out, H, W, ctx->stream));
-  else HIPCHK(ctx, launch_conv3x3(d, in, out, H, W, ctx->stream));
+  ProfScope ps(ctx, ln.stream, name, flops, bytes);
+  if (f16) HIPCHK(ctx, launch_conv3x3_f16(d, in, out, H, W, ln.stream));
+  else HIPCHK(ctx, launch_conv3x3(d, in, out, H, W, ln.stream));
   return WCT_OK;
 }
 
@@ -252,21 +265,21 @@ size_t max_act_bytes(const Module& m, int H, int W, bool enc) {
   return best;
 }
 
-int encode_impl(wct_ctx* ctx, int level, const float* img, int H, int W, float* feat_nhwc, int* ho, int* wo) {
+int encode_impl(wct_ctx* ctx, Lane& ln, int level, const float* img, int H, int W, float* feat_nhwc, int* ho, int* wo) {
   Module& m = ctx->mod[WCT_KIND_ENC][level];
   if (!m.loaded) return fail(ctx, WCT_ERR_STATE, "encoder %d not loaded", level);
   if (H < (2 << (level - 1)) || W < (2 << (level - 1)))
     return fail(ctx, WCT_ERR_INVALID, "image %dx%d too small for level %d (reflect padding needs >= 2 samples at every scale)", H, W, level);
   const size_t need = max_act_bytes(m, H, W, true);
-  if (int rc = ensure(ctx, ctx->actA, need)) return rc;
-  if (int rc = ensure(ctx, ctx->actB, need)) return rc;
+  if (int rc = ensure(ctx, ln.actA, need)) return rc;
+  if (int rc = ensure(ctx, ln.actB, need)) return rc;
   const float* cur = img;
   int h = H, w = W;
   for (size_t i = 0; i < m.layers.size(); ++i) {
     const auto& l = m.layers[i];
     const bool last = i + 1 == m.layers.size();
-    float* dst = last ? feat_nhwc : reinterpret_cast<float*>((i & 1) ? ctx->actB.p : ctx->actA.p);
-    if (int rc = run_conv(ctx, l.d, cur, dst, h, w)) return rc;
+    float* dst = last ? feat_nhwc : reinterpret_cast<float*>((i & 1) ? ln.actB.p : ln.actA.p);
+    if (int rc = run_conv(ctx, ln, l.d, cur, dst, h, w)) return rc;
     if (l.pool_after) { h /= 2; w /= 2; }
     cur = dst;
   }
@@ -280,9 +293,10 @@ int decode_impl(wct_ctx* ctx, int level, const float* feat, int h, int w, const 
   Module& m = ctx->mod[WCT_KIND_DEC][level];
   if (!m.loaded) return fail(ctx, WCT_ERR_STATE, "decoder %d not loaded", level);
   if (h < 2 || w < 2) return fail(ctx, WCT_ERR_INVALID, "feature %dx%d too small (reflect padding needs >= 2 samples)", h, w);
+  Lane& ln = ctx->main;
   const size_t need = max_act_bytes(m, h, w, false);
-  if (int rc = ensure(ctx, ctx->actA, need)) return rc;
-  if (int rc = ensure(ctx, ctx->actB, need)) return rc;
+  if (int rc = ensure(ctx, ln.actA, need)) return rc;
+  if (int rc = ensure(ctx, ln.actB, need)) return rc;
   const float* cur = feat;
   int ch = h, cw = w;
   for (size_t i = 0; i < m.layers.size(); ++i) {
@@ -290,52 +304,60 @@ int decode_impl(wct_ctx* ctx, int level, const float* feat, int h, int w, const 
     const bool last = i + 1 == m.layers.size();
     ConvDesc d = (i == 0 && first) ? *first : l.d;
     if (i > 0 && m.layers[i - 1].up_after) { ch *= 2; cw *= 2; }
-    float* dst = last ? img : reinterpret_cast<float*>((i & 1) ? ctx->actB.p : ctx->actA.p);
-    if (int rc = run_conv(ctx, d, cur, dst, ch, cw)) return rc;
+    float* dst = last ? img : reinterpret_cast<float*>((i & 1) ? ln.actB.p : ln.actA.p);
+    if (int rc = run_conv(ctx, ln, d, cur, dst, ch, cw)) return rc;
     cur = dst;
   }
   return WCT_OK;
 }
 
-// layout of ctx->small (doubles): sum_c[512] sumsq_c[512*512] sum_s[512] sumsq_s[512*512] M[512*512] b[512] | info ints
-struct SmallView {
-  double *sum_c, *sumsq_c, *sum_s, *sumsq_s, *M, *b;
-  int* info;
-};
-constexpr size_t SMALL_BYTES = (3 * 512 * 512 + 3 * 512) * sizeof(double) + 64;
+// ctx->small (doubles): M[512*512] | b[512]     lane.sums (doubles): sum[512] | sumsq[512*512] | info (2 ints)
+constexpr size_t SMALL_BYTES = (512 * 512 + 512) * sizeof(double);
+constexpr size_t SUMS_BYTES = (512 * 512 + 512) * sizeof(double) + 64;
 
-int small_view(wct_ctx* ctx, SmallView& v) {
-  if (int rc = ensure(ctx, ctx->small, SMALL_BYTES)) return rc;
-  double* p = reinterpret_cast<double*>(ctx->small.p);
-  v.sum_c = p; p += 512;
-  v.sumsq_c = p; p += 512 * 512;
-  v.sum_s = p; p += 512;
-  v.sumsq_s = p; p += 512 * 512;
-  v.M = p; p += 512 * 512;
-  v.b = p; p += 512;
-  v.info = reinterpret_cast<int*>(p);
+struct SumsView { double *sum, *sumsq; int* info; };
+
+int sums_view(wct_ctx* ctx, Lane& ln, SumsView& v) {
+  if (int rc = ensure(ctx, ln.sums, SUMS_BYTES)) return rc;
+  double* p = reinterpret_cast<double*>(ln.sums.p);
+  v.sum = p; v.sumsq = p + 512; v.info = reinterpret_cast<int*>(p + 512 + 512 * 512);
   return WCT_OK;
 }
 
-int moments_impl(wct_ctx* ctx, const float* feat, int C, int h, int w, int x0, int x1, double* sum, double* sumsq) {
+int mb_view(wct_ctx* ctx, double** M, double** b) {
+  if (int rc = ensure(ctx, ctx->small, SMALL_BYTES)) return rc;
+  *M = reinterpret_cast<double*>(ctx->small.p);
+  *b = *M + 512 * 512;
+  return WCT_OK;
+}
+
+int moments_impl(wct_ctx* ctx, Lane& ln, const float* feat, int C, int h, int w, int x0, int x1, double* sum, double* sumsq) {
   if (C < 4 || (C & 3) || C > 512) return fail(ctx, WCT_ERR_INVALID, "moments: C=%d must be a multiple of 4 in [4,512]", C);
   if (h < 1 || x0 < 0 || x1 > w || x1 <= x0) return fail(ctx, WCT_ERR_INVALID, "moments: bad window h=%d w=%d [%d,%d)", h, w, x0, x1);
   const long npix = (long)h * (x1 - x0);
   const size_t wsb = moments_workspace_bytes(C, npix);
-  if (int rc = ensure(ctx, ctx->wsMom, wsb)) return rc;
-  ProfScope ps(ctx, "moments", 2.0 * C * C * npix, 4.0 * C * npix);
-  HIPCHK(ctx, launch_moments(feat, C, h, w, x0, x1, sum, sumsq, ctx->wsMom.p, ctx->wsMom.cap, ctx->stream));
+  if (int rc = ensure(ctx, ln.wsMom, wsb)) return rc;
+  ProfScope ps(ctx, ln.stream, "moments", 2.0 * C * C * npix, 4.0 * C * npix);
+  HIPCHK(ctx, launch_moments(feat, C, h, w, x0, x1, sum, sumsq, ln.wsMom.p, ln.wsMom.cap, ln.stream));
   return WCT_OK;
 }
 
-int solve_impl(wct_ctx* ctx, int C, double n_c, const double* sum_c, const double* sumsq_c, double n_s,
-               const double* sum_s, const double* sumsq_s, double alpha, double* M, double* b, int* info_dev) {
+// (n, sum, sumsq) of one feature map -> EigResult in `res` (covariance, Jacobi eigen-decomposition)
+int eig_impl(wct_ctx* ctx, Lane& ln, int C, double n, const double* sum, const double* sumsq, DevBuf& res, int* info_dev) {
   if (C < 2 || (C & 1) || C > 512) return fail(ctx, WCT_ERR_INVALID, "solve: C=%d must be even and <= 512", C);
-  if (n_c < 2 || n_s < 2) return fail(ctx, WCT_ERR_INVALID, "solve: unbiased covariance needs >= 2 pixels (n_c=%g n_s=%g)", n_c, n_s);
-  if (int rc = ensure(ctx, ctx->wsSolve, solve_workspace_bytes(C))) return rc;
-  ProfScope ps(ctx, "solve", 0, 0);
-  HIPCHK(ctx, launch_solve(C, n_c, sum_c, sumsq_c, n_s, sum_s, sumsq_s, alpha, 1e-10, nullptr, nullptr, M, b, info_dev,
-                           ctx->wsSolve.p, ctx->wsSolve.cap, ctx->stream));
+  if (n < 2) return fail(ctx, WCT_ERR_INVALID, "solve: unbiased covariance needs >= 2 pixels (n=%g)", n);
+  if (int rc = ensure(ctx, res, eig_result_bytes(C))) return rc;
+  if (int rc = ensure(ctx, ln.wsEig, eig_workspace_bytes(C))) return rc;
+  ProfScope ps(ctx, ln.stream, "eig_jacobi", 0, 0);
+  HIPCHK(ctx, launch_eig(C, n, sum, sumsq, reinterpret_cast<double*>(res.p), info_dev, ln.wsEig.p, ln.wsEig.cap, ln.stream));
+  return WCT_OK;
+}
+
+int assemble_impl(wct_ctx* ctx, int C, const DevBuf& eig_c, const DevBuf& eig_s, double alpha, double* M, double* b) {
+  if (int rc = ensure(ctx, ctx->wsAsm, assemble_workspace_bytes(C))) return rc;
+  ProfScope ps(ctx, ctx->main.stream, "assemble_Mb", 0, 0);
+  HIPCHK(ctx, launch_assemble(C, reinterpret_cast<const double*>(eig_c.p), reinterpret_cast<const double*>(eig_s.p), alpha, 1e-10,
+                              M, b, ctx->wsAsm.p, ctx->wsAsm.cap, ctx->main.stream));
   return WCT_OK;
 }
 
@@ -343,12 +365,13 @@ int fold_impl(wct_ctx* ctx, int level, const double* M, const double* b, ConvDes
   Module& m = ctx->mod[WCT_KIND_DEC][level];
   if (!m.loaded) return fail(ctx, WCT_ERR_STATE, "decoder %d not loaded", level);
   const LayerDev& l = m.layers[0];
+  hipStream_t st = ctx->main.stream;
   const size_t wbytes = (size_t)l.d.cin_chunks * 36 * l.d.cout_pad * 4 * sizeof(float);
   if (int rc = ensure(ctx, ctx->foldW, wbytes + l.d.cout_pad * sizeof(float))) return rc;
   float* wpk = reinterpret_cast<float*>(ctx->foldW.p);
   float* bias = wpk + wbytes / sizeof(float);
-  ProfScope ps(ctx, "fold_affine", 0, 0);
-  HIPCHK(ctx, launch_fold_affine(l.w_oihw, l.bias_raw, l.d.cout, l.d.cin, l.d.cout_pad, M, b, wpk, bias, ctx->stream));
+  ProfScope ps(ctx, st, "fold_affine", 0, 0);
+  HIPCHK(ctx, launch_fold_affine(l.w_oihw, l.bias_raw, l.d.cout, l.d.cin, l.d.cout_pad, M, b, wpk, bias, st));
   out = l.d;
   out.wpk = wpk;
   out.bias = bias;
@@ -361,39 +384,70 @@ int fold_impl(wct_ctx* ctx, int level, const double* M, const double* b, ConvDes
     char* base = reinterpret_cast<char*>(ctx->foldW16.p);
     float* inv = reinterpret_cast<float*>(base + b16);
     unsigned* maxbits = reinterpret_cast<unsigned*>(base + b16 + 16);
-    HIPCHK(ctx, launch_split_pack(wpk, l.d.cin, l.d.cout_pad, taps, maxbits, base, inv, ctx->stream));
+    HIPCHK(ctx, launch_split_pack(wpk, l.d.cin, l.d.cout_pad, taps, maxbits, base, inv, st));
     out.wpk16 = base;
     out.inv_scale_ptr = inv;
   }
   return WCT_OK;
 }
 
-int level_impl(wct_ctx* ctx, int level, const float* content, int H, int W, const float* style, int Hs, int Ws,
-               float alpha, float* out, int* Ho, int* Wo) {
+void level_dims(int level, int H, int W, int& h, int& w) {
+  h = H; w = W;
+  for (int i = 1; i < level; ++i) { h /= 2; w /= 2; }
+}
+
+// style side of one level on the SIDE lane: sF = encoder(styleImg) (WCT.py:100), its moments and eigen-decomposition.
+// Independent of the content, so it is enqueued first and overlaps the content side.  Leaves eigS[level] + ev_style[level].
+int style_side(wct_ctx* ctx, int level, const float* style, int Hs, int Ws) {
   Module& me = ctx->mod[WCT_KIND_ENC][level];
   if (!me.loaded) return fail(ctx, WCT_ERR_STATE, "encoder %d not loaded", level);
   const int C = me.layers.back().d.cout;
-  int h, w, hs, ws;
-  {
-    h = H; w = W; hs = Hs; ws = Ws;
-    for (int i = 1; i < level; ++i) { h /= 2; w /= 2; hs /= 2; ws /= 2; }
-  }
-  if (int rc = ensure(ctx, ctx->featC, (size_t)h * w * C * sizeof(float))) return rc;
+  int hs, ws;
+  level_dims(level, Hs, Ws, hs, ws);
+  Lane& ln = ctx->overlap ? ctx->side : ctx->main;
   if (int rc = ensure(ctx, ctx->featS, (size_t)hs * ws * C * sizeof(float))) return rc;
-  SmallView sv;
-  if (int rc = small_view(ctx, sv)) return rc;
+  SumsView sv;
+  if (int rc = sums_view(ctx, ln, sv)) return rc;
   float* fS = reinterpret_cast<float*>(ctx->featS.p);
+  if (int rc = encode_impl(ctx, ln, level, style, Hs, Ws, fS, nullptr, nullptr)) return rc;
+  if (int rc = moments_impl(ctx, ln, fS, C, hs, ws, 0, ws, sv.sum, sv.sumsq)) return rc;
+  if (int rc = eig_impl(ctx, ln, C, (double)hs * ws, sv.sum, sv.sumsq, ctx->eigS[level], sv.info + 1)) return rc;
+  HIPCHK(ctx, hipEventRecord(ctx->ev_style[level], ln.stream));
+  return WCT_OK;
+}
+
+// the side lane may start once everything already enqueued on the caller's stream (e.g. the producer of the
+// style image) has run
+int fork_side(wct_ctx* ctx) {
+  HIPCHK(ctx, hipEventRecord(ctx->ev_fork, ctx->main.stream));
+  HIPCHK(ctx, hipStreamWaitEvent(ctx->side.stream, ctx->ev_fork, 0));
+  return WCT_OK;
+}
+
+// content side of one level on the MAIN lane; expects style_side(level) to have been enqueued
+int content_side(wct_ctx* ctx, int level, const float* content, int H, int W, float alpha, float* out, int* Ho, int* Wo) {
+  Module& me = ctx->mod[WCT_KIND_ENC][level];
+  if (!me.loaded) return fail(ctx, WCT_ERR_STATE, "encoder %d not loaded", level);
+  const int C = me.layers.back().d.cout;
+  int h, w;
+  level_dims(level, H, W, h, w);
+  Lane& ln = ctx->main;
+  if (int rc = ensure(ctx, ctx->featC, (size_t)h * w * C * sizeof(float))) return rc;
+  SumsView sv;
+  if (int rc = sums_view(ctx, ln, sv)) return rc;
+  double *M, *b;
+  if (int rc = mb_view(ctx, &M, &b)) return rc;
   float* fC = reinterpret_cast<float*>(ctx->featC.p);
-  // sF = encoder(styleImg); cF = encoder(contentImg)        (WCT.py:100-101)
-  if (int rc = encode_impl(ctx, level, style, Hs, Ws, fS, nullptr, nullptr)) return rc;
-  if (int rc = moments_impl(ctx, fS, C, hs, ws, 0, ws, sv.sum_s, sv.sumsq_s)) return rc;
-  if (int rc = encode_impl(ctx, level, content, H, W, fC, nullptr, nullptr)) return rc;
-  if (int rc = moments_impl(ctx, fC, C, h, w, 0, w, sv.sum_c, sv.sumsq_c)) return rc;
+  // cF = encoder(contentImg)                                  (WCT.py:101)
+  if (int rc = encode_impl(ctx, ln, level, content, H, W, fC, nullptr, nullptr)) return rc;
+  if (int rc = moments_impl(ctx, ln, fC, C, h, w, 0, w, sv.sum, sv.sumsq)) return rc;
+  if (int rc = eig_impl(ctx, ln, C, (double)h * w, sv.sum, sv.sumsq, ctx->eigC, sv.info)) return rc;
   // csF = wct.transform(cF, sF, csF, alpha)                  (WCT.py:104) -- as an affine map
-  if (int rc = solve_impl(ctx, C, (double)h * w, sv.sum_c, sv.sumsq_c, (double)hs * ws, sv.sum_s, sv.sumsq_s, alpha, sv.M, sv.b, sv.info)) return rc;
+  HIPCHK(ctx, hipStreamWaitEvent(ln.stream, ctx->ev_style[level], 0));
+  if (int rc = assemble_impl(ctx, C, ctx->eigC, ctx->eigS[level], alpha, M, b)) return rc;
   // Img = decoder(csF)                                       (WCT.py:105) -- M, b folded into the first conv
   ConvDesc first;
-  if (int rc = fold_impl(ctx, level, sv.M, sv.b, first)) return rc;
+  if (int rc = fold_impl(ctx, level, M, b, first)) return rc;
   if (int rc = decode_impl(ctx, level, fC, h, w, &first, out)) return rc;
   if (Ho) *Ho = h << (level - 1);
   if (Wo) *Wo = w << (level - 1);
@@ -417,6 +471,11 @@ int wct_create(int device, wct_ctx** out) {
   if (!c) return WCT_ERR_NOMEM;
   c->device = device;
   if (const char* m = getenv("WCT_CONV_MODE")) c->conv_mode = (m[0] == '0' || !strcmp(m, "fp32")) ? 0 : 1;
+  if (const char* m = getenv("WCT_OVERLAP")) c->overlap = m[0] != '0';
+  bool ok = hipStreamCreateWithFlags(&c->side.stream, hipStreamNonBlocking) == hipSuccess;
+  ok = ok && hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess;
+  for (int l = 1; l <= 5 && ok; ++l) ok = hipEventCreateWithFlags(&c->ev_style[l], hipEventDisableTiming) == hipSuccess;
+  if (!ok) { delete c; return WCT_ERR_HIP; }
   *out = c;
   return WCT_OK;
 }
@@ -424,11 +483,20 @@ int wct_create(int device, wct_ctx** out) {
 void wct_destroy(wct_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
-  (void)hipStreamSynchronize(ctx->stream);
+  (void)hipStreamSynchronize(ctx->main.stream);
+  (void)hipStreamSynchronize(ctx->side.stream);
   prof_collect(ctx);
   for (int k = 0; k < 2; ++k)
     for (int l = 0; l < 6; ++l) free_module(ctx->mod[k][l]);
-  for (DevBuf* b : {&ctx->actA, &ctx->actB, &ctx->featC, &ctx->featS, &ctx->tmpT, &ctx->wsMom, &ctx->wsSolve, &ctx->small, &ctx->foldW, &ctx->foldW16}) release(*b);
+  for (Lane* ln : {&ctx->main, &ctx->side})
+    for (DevBuf* b : {&ln->actA, &ln->actB, &ln->wsMom, &ln->wsEig, &ln->sums}) release(*b);
+  for (DevBuf* b : {&ctx->featC, &ctx->featS, &ctx->tmpT, &ctx->wsAsm, &ctx->small, &ctx->foldW, &ctx->foldW16, &ctx->eigC}) release(*b);
+  for (int l = 0; l < 6; ++l) {
+    release(ctx->eigS[l]);
+    if (ctx->ev_style[l]) (void)hipEventDestroy(ctx->ev_style[l]);
+  }
+  if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+  if (ctx->side.stream) (void)hipStreamDestroy(ctx->side.stream);
   delete ctx;
 }
 
@@ -436,13 +504,14 @@ const char* wct_last_error(const wct_ctx* ctx) { return ctx ? ctx->err.c_str() :
 
 int wct_set_stream(wct_ctx* ctx, void* s) {
   if (!ctx) return WCT_ERR_INVALID;
-  ctx->stream = reinterpret_cast<hipStream_t>(s);
+  ctx->main.stream = reinterpret_cast<hipStream_t>(s);
   return WCT_OK;
 }
 
 int wct_sync(wct_ctx* ctx) {
   if (!ctx) return WCT_ERR_INVALID;
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->side.stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->main.stream));
   return WCT_OK;
 }
 
@@ -516,13 +585,13 @@ int wct_feature_shape(const wct_ctx* ctx, int level, int H, int W, int* C, int* 
 int wct_encode(wct_ctx* ctx, int level, const float* img, int H, int W, float* feat, int layout) {
   if (!ctx) return WCT_ERR_INVALID;
   if (!valid_level(level) || !img || !feat || H < 1 || W < 1) return fail(ctx, WCT_ERR_INVALID, "encode: bad arguments");
-  if (layout == WCT_LAYOUT_NHWC) return encode_impl(ctx, level, img, H, W, feat, nullptr, nullptr);
+  if (layout == WCT_LAYOUT_NHWC) return encode_impl(ctx, ctx->main, level, img, H, W, feat, nullptr, nullptr);
   if (layout != WCT_LAYOUT_NCHW) return fail(ctx, WCT_ERR_INVALID, "encode: bad layout %d", layout);
   int C, h, w;
   if (int rc = wct_feature_shape(ctx, level, H, W, &C, &h, &w)) return fail(ctx, rc, "encoder %d not loaded", level);
   if (int rc = ensure(ctx, ctx->tmpT, (size_t)h * w * C * sizeof(float))) return rc;
-  if (int rc = encode_impl(ctx, level, img, H, W, reinterpret_cast<float*>(ctx->tmpT.p), nullptr, nullptr)) return rc;
-  HIPCHK(ctx, launch_nhwc_to_nchw(reinterpret_cast<float*>(ctx->tmpT.p), feat, C, h * w, ctx->stream));
+  if (int rc = encode_impl(ctx, ctx->main, level, img, H, W, reinterpret_cast<float*>(ctx->tmpT.p), nullptr, nullptr)) return rc;
+  HIPCHK(ctx, launch_nhwc_to_nchw(reinterpret_cast<float*>(ctx->tmpT.p), feat, C, h * w, ctx->main.stream));
   return WCT_OK;
 }
 
@@ -535,7 +604,7 @@ int wct_decode(wct_ctx* ctx, int level, const float* feat, int h, int w, int lay
   if (layout == WCT_LAYOUT_NCHW) {
     const int C = m.layers[0].d.cin;
     if (int rc = ensure(ctx, ctx->tmpT, (size_t)h * w * C * sizeof(float))) return rc;
-    HIPCHK(ctx, launch_nchw_to_nhwc(feat, reinterpret_cast<float*>(ctx->tmpT.p), C, h * w, ctx->stream));
+    HIPCHK(ctx, launch_nchw_to_nhwc(feat, reinterpret_cast<float*>(ctx->tmpT.p), C, h * w, ctx->main.stream));
     f = reinterpret_cast<float*>(ctx->tmpT.p);
   } else if (layout != WCT_LAYOUT_NHWC) {
     return fail(ctx, WCT_ERR_INVALID, "decode: bad layout %d", layout);
@@ -546,19 +615,21 @@ int wct_decode(wct_ctx* ctx, int level, const float* feat, int h, int w, int lay
 int wct_moments(wct_ctx* ctx, const float* feat, int C, int h, int w, int x0, int x1, double* sum, double* sumsq) {
   if (!ctx) return WCT_ERR_INVALID;
   if (!feat || !sum || !sumsq) return fail(ctx, WCT_ERR_INVALID, "moments: NULL pointer");
-  return moments_impl(ctx, feat, C, h, w, x0, x1, sum, sumsq);
+  return moments_impl(ctx, ctx->main, feat, C, h, w, x0, x1, sum, sumsq);
 }
 
 int wct_solve(wct_ctx* ctx, int C, double n_c, const double* sum_c, const double* sumsq_c, double n_s,
               const double* sum_s, const double* sumsq_s, double alpha, double* M, double* b, int* info) {
   if (!ctx) return WCT_ERR_INVALID;
   if (!sum_c || !sumsq_c || !sum_s || !sumsq_s || !M || !b) return fail(ctx, WCT_ERR_INVALID, "solve: NULL pointer");
-  SmallView sv;
-  if (int rc = small_view(ctx, sv)) return rc;
-  if (int rc = solve_impl(ctx, C, n_c, sum_c, sumsq_c, n_s, sum_s, sumsq_s, alpha, M, b, sv.info)) return rc;
+  SumsView sv;
+  if (int rc = sums_view(ctx, ctx->main, sv)) return rc;
+  if (int rc = eig_impl(ctx, ctx->main, C, n_c, sum_c, sumsq_c, ctx->eigC, sv.info)) return rc;
+  if (int rc = eig_impl(ctx, ctx->main, C, n_s, sum_s, sumsq_s, ctx->eigS[0], sv.info + 1)) return rc;
+  if (int rc = assemble_impl(ctx, C, ctx->eigC, ctx->eigS[0], alpha, M, b)) return rc;
   if (info) {
-    HIPCHK(ctx, hipMemcpyAsync(info, sv.info, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(info, sv.info, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->main.stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->main.stream));
   }
   return WCT_OK;
 }
@@ -572,17 +643,17 @@ int wct_apply(wct_ctx* ctx, const float* feat, int C, int h, int w, int layout, 
   if (int rc = ensure(ctx, ctx->foldW, (wfl + cp) * sizeof(float))) return rc;
   float* wpk = reinterpret_cast<float*>(ctx->foldW.p);
   float* bias = wpk + wfl;
-  HIPCHK(ctx, launch_pack_center_tap(M, b, C, cp, wpk, bias, ctx->stream));
+  HIPCHK(ctx, launch_pack_center_tap(M, b, C, cp, wpk, bias, ctx->main.stream));
   ConvDesc d{};
   d.cin = C; d.cout = C; d.cin_chunks = chunks; d.cout_pad = cp; d.flags = CONV_NO_RELU; d.wpk = wpk; d.bias = bias;
-  if (layout == WCT_LAYOUT_NHWC) return run_conv(ctx, d, feat, out, h, w);
+  if (layout == WCT_LAYOUT_NHWC) return run_conv(ctx, ctx->main, d, feat, out, h, w);
   if (layout != WCT_LAYOUT_NCHW) return fail(ctx, WCT_ERR_INVALID, "apply: bad layout %d", layout);
   if (int rc = ensure(ctx, ctx->tmpT, 2 * fbytes)) return rc;
   float* t0 = reinterpret_cast<float*>(ctx->tmpT.p);
   float* t1 = t0 + (size_t)h * w * C;
-  HIPCHK(ctx, launch_nchw_to_nhwc(feat, t0, C, h * w, ctx->stream));
-  if (int rc = run_conv(ctx, d, t0, t1, h, w)) return rc;
-  HIPCHK(ctx, launch_nhwc_to_nchw(t1, out, C, h * w, ctx->stream));
+  HIPCHK(ctx, launch_nchw_to_nhwc(feat, t0, C, h * w, ctx->main.stream));
+  if (int rc = run_conv(ctx, ctx->main, d, t0, t1, h, w)) return rc;
+  HIPCHK(ctx, launch_nhwc_to_nchw(t1, out, C, h * w, ctx->main.stream));
   return WCT_OK;
 }
 
@@ -591,22 +662,27 @@ int wct_transform(wct_ctx* ctx, const float* cF, int C, int h, int w, const floa
   if (!ctx) return WCT_ERR_INVALID;
   if (!cF || !sF || !out || h < 1 || w < 1 || hs < 1 || ws < 1) return fail(ctx, WCT_ERR_INVALID, "transform: bad arguments");
   if (layout != WCT_LAYOUT_NHWC && layout != WCT_LAYOUT_NCHW) return fail(ctx, WCT_ERR_INVALID, "transform: bad layout %d", layout);
-  SmallView sv;
-  if (int rc = small_view(ctx, sv)) return rc;
+  if (h < 2 || w < 2) return fail(ctx, WCT_ERR_INVALID, "transform: feature %dx%d too small", h, w);
+  Lane& ln = ctx->main;
+  SumsView sv;
+  if (int rc = sums_view(ctx, ln, sv)) return rc;
+  double *M, *b;
+  if (int rc = mb_view(ctx, &M, &b)) return rc;
   const float *c = cF, *s = sF;
   if (layout == WCT_LAYOUT_NCHW) {
     if (int rc = ensure(ctx, ctx->featC, (size_t)h * w * C * sizeof(float))) return rc;
     if (int rc = ensure(ctx, ctx->featS, (size_t)hs * ws * C * sizeof(float))) return rc;
-    HIPCHK(ctx, launch_nchw_to_nhwc(cF, reinterpret_cast<float*>(ctx->featC.p), C, h * w, ctx->stream));
-    HIPCHK(ctx, launch_nchw_to_nhwc(sF, reinterpret_cast<float*>(ctx->featS.p), C, hs * ws, ctx->stream));
+    HIPCHK(ctx, launch_nchw_to_nhwc(cF, reinterpret_cast<float*>(ctx->featC.p), C, h * w, ln.stream));
+    HIPCHK(ctx, launch_nchw_to_nhwc(sF, reinterpret_cast<float*>(ctx->featS.p), C, hs * ws, ln.stream));
     c = reinterpret_cast<float*>(ctx->featC.p);
     s = reinterpret_cast<float*>(ctx->featS.p);
   }
-  if (int rc = moments_impl(ctx, c, C, h, w, 0, w, sv.sum_c, sv.sumsq_c)) return rc;
-  if (int rc = moments_impl(ctx, s, C, hs, ws, 0, ws, sv.sum_s, sv.sumsq_s)) return rc;
-  if (int rc = solve_impl(ctx, C, (double)h * w, sv.sum_c, sv.sumsq_c, (double)hs * ws, sv.sum_s, sv.sumsq_s, alpha, sv.M, sv.b, sv.info)) return rc;
-  if (h >= 2 && w >= 2) return wct_apply(ctx, cF, C, h, w, layout, sv.M, sv.b, out);
-  return fail(ctx, WCT_ERR_INVALID, "transform: feature %dx%d too small", h, w);
+  if (int rc = moments_impl(ctx, ln, c, C, h, w, 0, w, sv.sum, sv.sumsq)) return rc;
+  if (int rc = eig_impl(ctx, ln, C, (double)h * w, sv.sum, sv.sumsq, ctx->eigC, sv.info)) return rc;
+  if (int rc = moments_impl(ctx, ln, s, C, hs, ws, 0, ws, sv.sum, sv.sumsq)) return rc;
+  if (int rc = eig_impl(ctx, ln, C, (double)hs * ws, sv.sum, sv.sumsq, ctx->eigS[0], sv.info + 1)) return rc;
+  if (int rc = assemble_impl(ctx, C, ctx->eigC, ctx->eigS[0], alpha, M, b)) return rc;
+  return wct_apply(ctx, cF, C, h, w, layout, M, b, out);
 }
 
 int wct_decode_affine(wct_ctx* ctx, int level, const float* feat, int h, int w, const double* M, const double* b, float* img) {
@@ -621,15 +697,21 @@ int wct_style_transfer_level(wct_ctx* ctx, int level, const float* content, int 
                              int Ws, float alpha, float* out, int* Ho, int* Wo) {
   if (!ctx) return WCT_ERR_INVALID;
   if (!valid_level(level) || !content || !style || !out) return fail(ctx, WCT_ERR_INVALID, "style_transfer_level: bad arguments");
-  return level_impl(ctx, level, content, H, W, style, Hs, Ws, alpha, out, Ho, Wo);
+  if (int rc = fork_side(ctx)) return rc;
+  if (int rc = style_side(ctx, level, style, Hs, Ws)) return rc;
+  return content_side(ctx, level, content, H, W, alpha, out, Ho, Wo);
 }
 
 int wct_stylize(wct_ctx* ctx, const float* content, int H, int W, const float* style, int Hs, int Ws, float alpha,
                 int num_run, float* out, int* Ho, int* Wo) {
   if (!ctx) return WCT_ERR_INVALID;
   if (!content || !style || !out || num_run < 1) return fail(ctx, WCT_ERR_INVALID, "stylize: bad arguments");
-  // `out` doubles as the running image: level L reads it and writes a (possibly smaller) image into a
-  // second buffer; ping-pong between `out` and tmpT.
+  // style side of all five levels first, on the side lane: it only depends on the style image (the SAME image at
+  // every level and every run, WCT.py:121-125), so it is computed once and overlaps the content cascade
+  if (int rc = fork_side(ctx)) return rc;
+  for (int level = 5; level >= 1; --level)
+    if (int rc = style_side(ctx, level, style, Hs, Ws)) return rc;
+  // `out` doubles as the running image: level L reads one buffer and writes the other (ping-pong with tmpT)
   const size_t img_bytes = (size_t)3 * H * W * sizeof(float);
   if (int rc = ensure(ctx, ctx->tmpT, img_bytes)) return rc;
   float* bufs[2] = {reinterpret_cast<float*>(ctx->tmpT.p), out};
@@ -639,10 +721,10 @@ int wct_stylize(wct_ctx* ctx, const float* content, int H, int W, const float* s
     for (int level = 5; level >= 1; --level) {
       int ho, wo;
       float* dst = bufs[which];
-      if (int rc = level_impl(ctx, level, cur, h, w, style, Hs, Ws, alpha, dst, &ho, &wo)) return rc;
+      if (int rc = content_side(ctx, level, cur, h, w, alpha, dst, &ho, &wo)) return rc;
       cur = dst; h = ho; w = wo; which ^= 1;
     }
-  if (cur != out) HIPCHK(ctx, hipMemcpyAsync(out, cur, (size_t)3 * h * w * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+  if (cur != out) HIPCHK(ctx, hipMemcpyAsync(out, cur, (size_t)3 * h * w * sizeof(float), hipMemcpyDeviceToDevice, ctx->main.stream));
   if (Ho) *Ho = h;
   if (Wo) *Wo = w;
   return WCT_OK;
@@ -650,51 +732,74 @@ int wct_stylize(wct_ctx* ctx, const float* content, int H, int W, const float* s
 
 size_t wct_workspace_bytes(const wct_ctx* ctx, int H, int W, int Hs, int Ws) {
   if (!ctx) return 0;
-  size_t act = 0, feat = 0, mom = 0;
+  size_t act = 0, acts = 0, featc = 0, feats = 0, mom = 0;
   for (int level = 1; level <= 5; ++level) {
     const Module& e = ctx->mod[WCT_KIND_ENC][level];
     const Module& d = ctx->mod[WCT_KIND_DEC][level];
     if (!e.loaded || !d.loaded) continue;
-    int h = H, w = W, hs = Hs, ws = Ws;
-    for (int i = 1; i < level; ++i) { h /= 2; w /= 2; hs /= 2; ws /= 2; }
+    int h, w, hs, ws;
+    level_dims(level, H, W, h, w);
+    level_dims(level, Hs, Ws, hs, ws);
     const int C = e.layers.back().d.cout;
-    act = std::max(act, std::max(max_act_bytes(e, H, W, true), max_act_bytes(e, Hs, Ws, true)));
-    act = std::max(act, max_act_bytes(d, h, w, false));
-    feat = std::max(feat, (size_t)std::max((size_t)h * w, (size_t)hs * ws) * C * sizeof(float));
-    mom = std::max(mom, std::max(moments_workspace_bytes(C, (long)h * w), moments_workspace_bytes(C, (long)hs * ws)));
+    act = std::max(act, std::max(max_act_bytes(e, H, W, true), max_act_bytes(d, h, w, false)));
+    acts = std::max(acts, max_act_bytes(e, Hs, Ws, true));
+    featc = std::max(featc, (size_t)h * w * C * sizeof(float));
+    feats = std::max(feats, (size_t)hs * ws * C * sizeof(float));
+    mom = std::max(mom, moments_workspace_bytes(C, (long)h * w) + moments_workspace_bytes(C, (long)hs * ws));
   }
-  return 2 * act + 2 * feat + mom + (size_t)3 * H * W * sizeof(float) + SMALL_BYTES + solve_workspace_bytes(512);
+  return 2 * act + 2 * acts + featc + feats + mom + (size_t)3 * H * W * sizeof(float) + SMALL_BYTES + 2 * SUMS_BYTES +
+         6 * eig_result_bytes(512) + assemble_workspace_bytes(512);
 }
 
 int wct_reserve(wct_ctx* ctx, int H, int W, int Hs, int Ws) {
   if (!ctx) return WCT_ERR_INVALID;
-  size_t act = 0, featc = 0, feats = 0, mom = 0;
+  size_t act = 0, acts = 0, featc = 0, feats = 0, momc = 0, moms = 0;
   int cmax = 2;
   for (int level = 1; level <= 5; ++level) {
     const Module& e = ctx->mod[WCT_KIND_ENC][level];
     const Module& d = ctx->mod[WCT_KIND_DEC][level];
     if (!e.loaded || !d.loaded) continue;
-    int h = H, w = W, hs = Hs, ws = Ws;
-    for (int i = 1; i < level; ++i) { h /= 2; w /= 2; hs /= 2; ws /= 2; }
+    int h, w, hs, ws;
+    level_dims(level, H, W, h, w);
+    level_dims(level, Hs, Ws, hs, ws);
     const int C = e.layers.back().d.cout;
     cmax = std::max(cmax, C);
-    act = std::max(act, std::max(max_act_bytes(e, H, W, true), max_act_bytes(e, Hs, Ws, true)));
-    act = std::max(act, max_act_bytes(d, h, w, false));
+    act = std::max(act, std::max(max_act_bytes(e, H, W, true), max_act_bytes(d, h, w, false)));
+    acts = std::max(acts, max_act_bytes(e, Hs, Ws, true));
     featc = std::max(featc, (size_t)h * w * C * sizeof(float));
     feats = std::max(feats, (size_t)hs * ws * C * sizeof(float));
-    mom = std::max(mom, std::max(moments_workspace_bytes(C, (long)h * w), moments_workspace_bytes(C, (long)hs * ws)));
+    momc = std::max(momc, moments_workspace_bytes(C, (long)h * w));
+    moms = std::max(moms, moments_workspace_bytes(C, (long)hs * ws));
     const LayerDev& l0 = d.layers[0];
     if (int rc = ensure(ctx, ctx->foldW, ((size_t)l0.d.cin_chunks * 36 * l0.d.cout_pad * 4 + l0.d.cout_pad) * sizeof(float))) return rc;
+    if (int rc = ensure(ctx, ctx->foldW16, conv_f16_weight_bytes(l0.d.cin, l0.d.cout_pad, l0.d.cout_pad == 16 ? 10 : 9) + 64)) return rc;
+    if (int rc = ensure(ctx, ctx->eigS[level], eig_result_bytes(C))) return rc;
   }
-  if (int rc = ensure(ctx, ctx->actA, act)) return rc;
-  if (int rc = ensure(ctx, ctx->actB, act)) return rc;
+  if (int rc = ensure(ctx, ctx->main.actA, act)) return rc;
+  if (int rc = ensure(ctx, ctx->main.actB, act)) return rc;
+  if (int rc = ensure(ctx, ctx->side.actA, acts)) return rc;
+  if (int rc = ensure(ctx, ctx->side.actB, acts)) return rc;
   if (int rc = ensure(ctx, ctx->featC, featc)) return rc;
   if (int rc = ensure(ctx, ctx->featS, feats)) return rc;
-  if (int rc = ensure(ctx, ctx->wsMom, mom)) return rc;
+  if (int rc = ensure(ctx, ctx->main.wsMom, momc)) return rc;
+  if (int rc = ensure(ctx, ctx->side.wsMom, moms)) return rc;
   if (int rc = ensure(ctx, ctx->tmpT, (size_t)3 * H * W * sizeof(float))) return rc;
-  if (int rc = ensure(ctx, ctx->wsSolve, solve_workspace_bytes(cmax))) return rc;
-  SmallView sv;
-  return small_view(ctx, sv);
+  if (int rc = ensure(ctx, ctx->eigC, eig_result_bytes(cmax))) return rc;
+  if (int rc = ensure(ctx, ctx->wsAsm, assemble_workspace_bytes(cmax))) return rc;
+  for (Lane* ln : {&ctx->main, &ctx->side}) {
+    if (int rc = ensure(ctx, ln->wsEig, eig_workspace_bytes(cmax))) return rc;
+    SumsView sv;
+    if (int rc = sums_view(ctx, *ln, sv)) return rc;
+  }
+  double *M, *b;
+  return mb_view(ctx, &M, &b);
+}
+
+int wct_set_overlap(wct_ctx* ctx, int on) {
+  if (!ctx) return WCT_ERR_INVALID;
+  HIPCHK(ctx, hipStreamSynchronize(ctx->side.stream));
+  ctx->overlap = on != 0;
+  return WCT_OK;
 }
 
 int wct_set_conv_mode(wct_ctx* ctx, int mode) {

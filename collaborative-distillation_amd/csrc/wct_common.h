@@ -50,12 +50,15 @@ size_t moments_workspace_bytes(int C, long npix);
 hipError_t launch_moments(const float* feat_nhwc, int C, int h, int wfull, int x0, int x1, double* sum,
                           double* sumsq, void* workspace, size_t workspace_bytes, hipStream_t s);
 
-// ---- solve: (n, sum, sumsq) x2 -> M (C x C), b (C)   csF = M cF + b   (util_wct.py:62-131, 219)
-size_t solve_workspace_bytes(int C);
-hipError_t launch_solve(int C, double n_c, const double* sum_c, const double* sumsq_c, double n_s,
-                        const double* sum_s, const double* sumsq_s, double alpha, double rel_thresh,
-                        float* M_f32, float* b_f32, double* M_f64, double* b_f64, int* info,
-                        void* workspace, size_t workspace_bytes, hipStream_t s);
+// ---- solve, in two steps (solve.hip): moments of one map -> EigResult; two EigResults -> M (C x C), b (C)
+//      csF = M cF + b   (util_wct.py:62-131, 219).  EigResult = doubles G[C*C] | lam[C] | mu[C] | floor | pad
+size_t eig_result_bytes(int C);
+size_t eig_workspace_bytes(int C);
+size_t assemble_workspace_bytes(int C);
+hipError_t launch_eig(int C, double n, const double* sum, const double* sumsq, double* res, int* info_dev,
+                      void* workspace, size_t workspace_bytes, hipStream_t s);
+hipError_t launch_assemble(int C, const double* eig_c, const double* eig_s, double alpha, double rel_thresh,
+                           double* M, double* b, void* workspace, size_t workspace_bytes, hipStream_t s);
 
 // ---- fold csF = M x + b into a decoder's first conv:  W' = W o M, b' = bias + W o b
 //      w_oihw: device [cout][cin][3][3] fp32 (original weights), out: packed weights + bias for ConvDesc

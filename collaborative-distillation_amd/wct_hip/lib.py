@@ -20,7 +20,7 @@ SYMBOLS = [
     "wct_version", "wct_create", "wct_destroy", "wct_last_error", "wct_set_stream", "wct_sync",
     "wct_load_module", "wct_feature_shape", "wct_encode", "wct_decode", "wct_moments", "wct_solve",
     "wct_apply", "wct_transform", "wct_decode_affine", "wct_style_transfer_level", "wct_stylize",
-    "wct_workspace_bytes", "wct_reserve", "wct_set_conv_mode", "wct_profile_enable", "wct_profile_reset", "wct_profile_read",
+    "wct_workspace_bytes", "wct_reserve", "wct_set_conv_mode", "wct_set_overlap", "wct_profile_enable", "wct_profile_reset", "wct_profile_read",
 ]
 
 
@@ -78,6 +78,7 @@ def load() -> ctypes.CDLL:
     lib.wct_workspace_bytes.restype = c_size_t
     lib.wct_reserve.argtypes = [c_void_p, c_int, c_int, c_int, c_int]
     lib.wct_set_conv_mode.argtypes = [c_void_p, c_int]
+    lib.wct_set_overlap.argtypes = [c_void_p, c_int]
     lib.wct_profile_enable.argtypes = [c_void_p, c_int]
     lib.wct_profile_reset.argtypes = [c_void_p]
     lib.wct_profile_read.argtypes = [c_void_p, POINTER(WctProfEntry), c_int, ip]

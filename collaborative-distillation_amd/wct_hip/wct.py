@@ -294,6 +294,9 @@ class WCT:
         """'f16x3' (default: split-f16 MFMA, fp32-class accuracy) or 'fp32' (exact fp32 MFMA)."""
         self._chk(self._lib.wct_set_conv_mode(self._ctx, {"fp32": 0, "f16x3": 1}[mode]))
 
+    def set_overlap(self, on: bool):
+        self._chk(self._lib.wct_set_overlap(self._ctx, int(on)))
+
     def reserve(self, H, W, Hs, Ws):
         self._chk(self._lib.wct_reserve(self._ctx, H, W, Hs, Ws))
 

@@ -125,6 +125,11 @@ int wct_reserve(wct_ctx* ctx, int H, int W, int Hs, int Ws);
  * env WCT_CONV_MODE=0|fp32 selects 0 at wct_create. */
 int wct_set_conv_mode(wct_ctx* ctx, int mode);
 
+/* 1 (default): the style side of a level (encode, moments, eigen-decomposition -- independent of the content) runs on
+ * a context-owned side stream and overlaps the content side; 0: everything runs in order on the caller's stream
+ * (used when timing individual kernels). */
+int wct_set_overlap(wct_ctx* ctx, int on);
+
 /* profiling: when enabled every kernel launch is bracketed by HIP events on the context's stream */
 int wct_profile_enable(wct_ctx* ctx, int on);
 int wct_profile_reset(wct_ctx* ctx);
