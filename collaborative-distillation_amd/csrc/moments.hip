@@ -15,35 +15,72 @@
 // operand reads (lane = channel l&15 of pixel l>>4) bank-conflict free.  Partial tiles go to a workspace and a
 // second kernel adds them in a fixed order -> bitwise reproducible, no atomics.
 #include "wct_common.h"
+#include <algorithm>
+#include <cstdlib>
 
 namespace {
 
-constexpr int MP = 64;   // pixels per LDS tile
 constexpr int PPW = 9;   // tile pairs per wave
 constexpr int PPG = 4 * PPW;
 
 struct MomArgs {
   const float* x;
-  int C, T, NP, NPG, NPC, Cs;
+  int C, T, NP, NPG, NPC, Cs, MP, pixsplit;  // MP: pixels per LDS tile
   long npix, chunk;      // pixels per chunk (multiple of MP)
   int wfull, x0, wwin;   // window: pixel p -> (row p / wwin, col x0 + p % wwin) of a map of width wfull
   double* part_sq;       // [NPC][NP][256]
   double* part_sum;      // [NPC][T*16]
 };
 
-__global__ __launch_bounds__(256) void moments_kernel(MomArgs a) {
+constexpr int MAXLD = 8;  // upper bound of float4 loads per thread per tile (MP * C / 4 / 256 <= 8)
+
+// THREE tile pairs x steps [st0, st1) of the LDS tile, 4 steps at a time: all 24 LDS operand reads of a group are
+// issued before the first conversion / MFMA and nothing in here is conditional, so the scheduler overlaps LDS
+// latency with the matrix pipe instead of serialising read -> wait -> MFMA.  A wave's pair list is processed in
+// triples (unused slots alias a valid LDS column; their accumulators are never stored).
+__device__ __forceinline__ void tile_steps3(const float* lds, int Cs, int st0, int st1, int pk, const int* offA, const int* offB,
+                                            f64x4& c0, f64x4& c1, f64x4& c2, double& s0, double& s1, double& s2) {
+  const int oa0 = offA[0], oa1 = offA[1], oa2 = offA[2], ob0 = offB[0], ob1 = offB[1], ob2 = offB[2];
+  for (int st = st0; st < st1; st += 4) {
+    float av[4][3], bv[4][3];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float* row = lds + ((st + u) * 4 + pk) * Cs;
+      av[u][0] = row[oa0]; bv[u][0] = row[ob0];
+      av[u][1] = row[oa1]; bv[u][1] = row[ob1];
+      av[u][2] = row[oa2]; bv[u][2] = row[ob2];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const double a0 = (double)av[u][0], a1 = (double)av[u][1], a2 = (double)av[u][2];
+      s0 += a0; s1 += a1; s2 += a2;
+      c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, (double)bv[u][0], c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, (double)bv[u][1], c1, 0, 0, 0);
+      c2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, (double)bv[u][2], c2, 0, 0, 0);
+    }
+  }
+}
+
+template <int NLD>  // float4 load slots per thread per tile: ceil(MP * C / 4 / 256)
+__global__ __launch_bounds__(256, 2) void moments_kernel(MomArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* lds = reinterpret_cast<float*>(smem);  // [MP][Cs]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform: scalar branches below
   const int c = lane & 15, pk = lane >> 4;
   const int pc = blockIdx.x, pg = blockIdx.y;
-  // pairs owned by this wave: idx = pg*PPG + wave + 4*j
+  const int MP = a.MP;
+  // work split inside the workgroup:
+  //   pixel split (NP <= 6, i.e. C <= 48): every wave owns ALL pairs for a quarter of each tile's pixels (3..6
+  //     independent accumulator chains per wave, all four waves busy); the four partial sets are added in LDS;
+  //   pair split: wave w owns pairs pg*PPG + w + 4j for the whole tile.
+  const bool pixsplit = a.pixsplit != 0;
   int offA[PPW], offB[PPW], pidx[PPW];
   bool diag[PPW];
   int cnt = 0;
 #pragma unroll
   for (int j = 0; j < PPW; ++j) {
-    const int idx = pg * PPG + wave + 4 * j;
+    const int idx = pixsplit ? j : pg * PPG + wave + 4 * j;
     offA[j] = offB[j] = 0; pidx[j] = 0; diag[j] = false;
     if (idx < a.NP) {
       int I = 0, rem = idx;
@@ -52,6 +89,9 @@ __global__ __launch_bounds__(256) void moments_kernel(MomArgs a) {
       cnt = j + 1;
     }
   }
+  cnt = __builtin_amdgcn_readfirstlane(cnt);
+  const int steps = MP / 4;
+  const int st0 = pixsplit ? wave * (steps / 4) : 0, st1 = pixsplit ? st0 + steps / 4 : steps;
   f64x4 acc[PPW];
   double s[PPW];
 #pragma unroll
@@ -61,37 +101,76 @@ __global__ __launch_bounds__(256) void moments_kernel(MomArgs a) {
 
   const long p0 = (long)pc * a.chunk, p1 = min(a.npix, p0 + a.chunk);
   const int c4n = a.C >> 2;
-  for (long pt = p0; pt < p1; pt += MP) {
-    __syncthreads();
-    for (int e = tid; e < MP * c4n; e += 256) {
-      const int pix = e / c4n, c4 = e - pix * c4n;
-      const long pp = pt + pix;
-      f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (pp < p1) {
-        long g = pp;
-        if (a.wwin != a.wfull) { const long r = pp / a.wwin; g = r * a.wfull + a.x0 + (pp - r * a.wwin); }
-        v = *reinterpret_cast<const f32x4*>(a.x + g * a.C + c4 * 4);
-      }
-      *reinterpret_cast<f32x4*>(lds + pix * a.Cs + c4 * 4) = v;
-    }
-    __syncthreads();
-#pragma unroll 4
-    for (int st = 0; st < MP / 4; ++st) {
-      const float* row = lds + (st * 4 + pk) * a.Cs;
+  // this thread's float4 slots of a tile (the same for every tile): pixel-in-tile and channel quad
+  int lpix[NLD], lc4[NLD];
 #pragma unroll
-      for (int j = 0; j < PPW; ++j) {
-        if (j < cnt) {
-          const double av = (double)row[offA[j]], bv = (double)row[offB[j]];
-          s[j] += av;
-          acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[j], 0, 0, 0);
+  for (int k = 0; k < NLD; ++k) {
+    const int e = tid + 256 * k;
+    lpix[k] = e / c4n; lc4[k] = e - lpix[k] * c4n;
+    if (lpix[k] >= MP) lpix[k] = -1;
+  }
+  // Loads are UNCONDITIONAL (addresses clamped into the chunk; out-of-range slots are zeroed when they are written
+  // to LDS): a load guarded by a per-lane condition makes hipcc branch around it and wait for it on the spot,
+  // which serialises the tile fetch and defeats the prefetch (cdna_hip_programming.md, "three .s-level traps" (c)).
+  auto fetch = [&](long pt, f32x4 (&v)[NLD]) {
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+      long pp = pt + (lpix[k] < 0 ? 0 : lpix[k]);
+      pp = pp < p1 ? pp : p1 - 1;
+      long g = pp;
+      if (a.wwin != a.wfull) { const long r = pp / a.wwin; g = r * a.wfull + a.x0 + (pp - r * a.wwin); }
+      v[k] = *reinterpret_cast<const f32x4*>(a.x + g * a.C + (lpix[k] < 0 ? 0 : lc4[k]) * 4);
+    }
+  };
+  // software pipeline: the loads of tile t+1 are in flight while tile t is multiplied (one LDS buffer, the next
+  // tile waits in registers) -- keeps ~one tile per workgroup outstanding towards HBM at all times
+  f32x4 nxt[NLD];
+  fetch(p0, nxt);
+  for (long pt = p0; pt < p1; pt += MP) {
+    __syncthreads();   // previous tile fully consumed
+#pragma unroll
+    for (int k = 0; k < NLD; ++k)
+      if (lpix[k] >= 0) {
+        const bool ok = pt + lpix[k] < p1;
+        *reinterpret_cast<f32x4*>(lds + lpix[k] * a.Cs + lc4[k] * 4) = ok ? nxt[k] : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    __syncthreads();
+    if (pt + MP < p1) fetch(pt + MP, nxt);
+    if (cnt > 0) tile_steps3(lds, a.Cs, st0, st1, pk, offA, offB, acc[0], acc[1], acc[2], s[0], s[1], s[2]);
+    if (cnt > 3) tile_steps3(lds, a.Cs, st0, st1, pk, offA + 3, offB + 3, acc[3], acc[4], acc[5], s[3], s[4], s[5]);
+    if (cnt > 6) tile_steps3(lds, a.Cs, st0, st1, pk, offA + 6, offB + 6, acc[6], acc[7], acc[8], s[6], s[7], s[8]);
+  }
+  // D layout (f64): col = lane & 15, row = (lane >> 4) + 4 * reg
+  if (pixsplit) {
+    // add the four waves' partial sets through LDS (reusing the tile buffer; sized for it on the host)
+    __syncthreads();
+    double* red = reinterpret_cast<double*>(smem);  // [4][NP][256] + [4][T*16]
+    double* reds = red + (size_t)4 * a.NP * 256;
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) {
+      if (j < cnt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[((size_t)wave * a.NP + j) * 256 + (pk + 4 * r) * 16 + c] = acc[j][r];
+        if (diag[j]) {
+          double v = s[j];
+          v += __shfl_xor(v, 16);
+          v += __shfl_xor(v, 32);
+          if (pk == 0) reds[wave * a.T * 16 + offA[j]] = v;
         }
       }
     }
+    __syncthreads();
+    const int nsq = a.NP * 256;
+    for (int e = tid; e < nsq; e += 256)
+      a.part_sq[(size_t)pc * nsq + e] = (red[e] + red[nsq + e]) + (red[2 * nsq + e] + red[3 * nsq + e]);
+    const int ns = a.T * 16;
+    for (int e = tid; e < ns; e += 256)
+      a.part_sum[(size_t)pc * ns + e] = (reds[e] + reds[ns + e]) + (reds[2 * ns + e] + reds[3 * ns + e]);
+    return;
   }
-  // D layout (f64): col = lane & 15, row = (lane >> 4) + 4 * reg
 #pragma unroll
   for (int j = 0; j < PPW; ++j) {
-    if (j < cnt && pg * PPG + wave + 4 * j < a.NP) {
+    if (j < cnt) {
       double* dst = a.part_sq + ((size_t)pc * a.NP + pidx[j]) * 256;
 #pragma unroll
       for (int r = 0; r < 4; ++r) dst[(pk + 4 * r) * 16 + c] = acc[j][r];
@@ -143,10 +222,14 @@ __global__ __launch_bounds__(256) void moments_reduce_kernel(MomArgs a, double* 
 MomArgs plan(int C, long npix) {
   MomArgs a{};
   a.C = C; a.T = (C + 15) / 16; a.NP = a.T * (a.T + 1) / 2;
-  a.NPG = (a.NP + PPG - 1) / PPG;
+  a.pixsplit = a.NP <= 6;
+  a.NPG = a.pixsplit ? 1 : (a.NP + PPG - 1) / PPG;
   a.Cs = (a.T & 1) ? a.T * 16 : a.T * 16 + 16;  // == 16 (mod 32) dwords
+  a.MP = std::min(256, (MAXLD * 256 * 4 / C) / 16 * 16);  // MP * C / 4 <= 8 * 256 float4 slots; multiple of 16
+  const int MP = a.MP;
   a.npix = npix;
-  long npc = 2048 / a.NPG;                 // ~8 workgroups per CU in total
+  static long npc_target = [] { const char* e = getenv("WCT_MOM_NPC"); return e ? atol(e) : 512L; }();
+  long npc = npc_target / a.NPG;           // ~8 workgroups per CU in total
   if (a.NP > 16 && npc > 512) npc = 512;   // bound the partial buffer (NPC * NP * 2 KB)
   const long maxc = (npix + MP - 1) / MP;
   if (npc > maxc) npc = maxc;
@@ -177,12 +260,29 @@ hipError_t launch_moments(const float* feat, int C, int h, int wfull, int x0, in
   a.wfull = wfull; a.x0 = x0; a.wwin = x1 - x0;
   a.part_sq = reinterpret_cast<double*>(ws);
   a.part_sum = a.part_sq + (size_t)a.NPC * a.NP * 256;
-  const size_t lds = (size_t)MP * a.Cs * sizeof(float);
-  if (lds > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(moments_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
+  size_t lds = (size_t)a.MP * a.Cs * sizeof(float);
+  if (a.pixsplit) lds = std::max(lds, ((size_t)4 * a.NP * 256 + 4 * a.T * 16) * sizeof(double));
+  const int nld = (a.MP * (C / 4) + 255) / 256;
+  auto go = [&](auto kern) -> hipError_t {
+    if (lds > 48 * 1024) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)a.NPC, (unsigned)a.NPG), dim3(256), lds, s, a);
+    return hipSuccess;
+  };
+  hipError_t le;
+  switch (nld) {
+    case 1: le = go(moments_kernel<1>); break;
+    case 2: le = go(moments_kernel<2>); break;
+    case 3: le = go(moments_kernel<3>); break;
+    case 4: le = go(moments_kernel<4>); break;
+    case 5: le = go(moments_kernel<5>); break;
+    case 6: le = go(moments_kernel<6>); break;
+    case 7: le = go(moments_kernel<7>); break;
+    default: le = go(moments_kernel<8>); break;
   }
-  hipLaunchKernelGGL(moments_kernel, dim3((unsigned)a.NPC, (unsigned)a.NPG), dim3(256), lds, s, a);
+  if (le != hipSuccess) return le;
   const long ne = (long)a.NP * 256 + a.T * 16;
   hipLaunchKernelGGL(moments_reduce_kernel, dim3((unsigned)((ne + 15) / 16)), dim3(256), 0, s, a, sum, sumsq);
   return hipGetLastError();
