@@ -26,16 +26,19 @@ namespace {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+// native 16-byte vector for register staging: HIP's u32x4 is a struct of unions, arrays of which are not promoted to
+// registers (they land in scratch)
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int FTW = 32, FTH = 8;
-constexpr int FHW = FTW + 2, FHH = FTH + 2;   // 34 x 10 halo
-constexpr int NPH = FHW * FHH;                // 340
-constexpr int NPP = 352;                      // plane stride in 16-B units (multiple of 16)
+constexpr int FTW = 32;
+constexpr int FHW = FTW + 2;                  // halo tile is 34 x (TH + 2), TH = 8 (4 waves) or 16 (8 waves)
+constexpr int nph(int TH) { return FHW * (TH + 2); }                 // 340 / 612 halo pixels
+constexpr int npp(int TH) { return (nph(TH) + 15) / 16 * 16; }       // plane stride in 16-B units: 352 / 624
 
 struct F16Args {
   const float* in;
   float* out;
-  const uint4* wpk;        // [chunk][taps][hl][kh][cout_pad] x 16 B
+  const u32x4* wpk;        // [chunk][taps][hl][kh][cout_pad] x 16 B
   const float* bias;
   const float* inv_scale_ptr;  // device scalar (folded layers) or null
   float inv_scale;
@@ -68,32 +71,84 @@ __device__ __forceinline__ void split8(const f32x4& a, const f32x4& b, f16x8& hi
   }
 }
 
-// stage one 16-channel chunk of the halo tile, converting fp32 -> (hi, lo) f16 planes
-__device__ __forceinline__ void stage_act(const F16Args& a, uint4* act, int ch, int ty0, int tx0, int tid) {
-  for (int e = tid; e < NPH * 2; e += 256) {
+// stage one 16-channel chunk of the halo tile, converting fp32 -> (hi, lo) f16 planes.
+// All of a thread's global loads (<= 3 slots x 2 float4) are issued back to back and UNCONDITIONALLY (addresses
+// clamped; out-of-range channels zeroed afterwards) before the first conversion, so their latencies overlap: a load
+// under a per-lane condition makes hipcc branch around it and wait on the spot (cdna_hip_programming.md traps (c)).
+constexpr int ACT_SLOTS = 3;  // ceil(2 * nph(TH) / (32 * TH)) for TH = 8 and 16
+struct ActRegs { f32x4 v0[ACT_SLOTS], v1[ACT_SLOTS]; };
+
+template <int TH>
+__device__ __forceinline__ void fetch_act(const F16Args& a, ActRegs& r, int ch, int ty0, int tx0, int tid) {
+  constexpr int NPH = nph(TH), NT = 32 * TH;
+  static_assert((NPH * 2 + NT - 1) / NT <= ACT_SLOTS, "slots");
+  const int cbase = ch * 16;
+#pragma unroll
+  for (int k = 0; k < ACT_SLOTS; ++k) {
+    int e = tid + NT * k;
+    e = e < NPH * 2 ? e : NPH * 2 - 1;
     const int kh = e & 1, pix = e >> 1;
     const int py = pix / FHW, px = pix - py * FHW;
     int gy = reflect_clamp(ty0 - 1 + py, a.H), gx = reflect_clamp(tx0 - 1 + px, a.W);
     if (a.up_in) { gy >>= 1; gx >>= 1; }
-    const int c = ch * 16 + kh * 8;
+    int c = cbase + kh * 8;
+    c = c + 8 <= a.cin ? c : 0;   // cin is a multiple of 8 on this path (16, 24, 32, 64, 128, ...)
     const float* src = a.in + ((size_t)gy * a.inW + gx) * a.cin + c;
-    f32x4 v0 = f32x4{0.f, 0.f, 0.f, 0.f}, v1 = v0;
-    if (c < a.cin) v0 = *reinterpret_cast<const f32x4*>(src);
-    if (c + 4 < a.cin) v1 = *reinterpret_cast<const f32x4*>(src + 4);
-    f16x8 hi, lo;
-    split8(v0, v1, hi, lo);
-    act[(0 * 2 + kh) * NPP + pix] = __builtin_bit_cast(uint4, hi);
-    act[(1 * 2 + kh) * NPP + pix] = __builtin_bit_cast(uint4, lo);
+    r.v0[k] = *reinterpret_cast<const f32x4*>(src);
+    r.v1[k] = *reinterpret_cast<const f32x4*>(src + 4);
+  }
+}
+
+template <int TH>
+__device__ __forceinline__ void commit_act(const F16Args& a, const ActRegs& r, u32x4* act, int ch, int tid) {
+  constexpr int NPH = nph(TH), NPP = npp(TH), NT = 32 * TH;
+  const int cbase = ch * 16;
+#pragma unroll
+  for (int k = 0; k < ACT_SLOTS; ++k) {
+    const int e = tid + NT * k;
+    if (e < NPH * 2) {
+      const int kh = e & 1, pix = e >> 1;
+      const bool ok = cbase + kh * 8 + 8 <= a.cin;
+      f16x8 hi, lo;
+      split8(ok ? r.v0[k] : f32x4{0.f, 0.f, 0.f, 0.f}, ok ? r.v1[k] : f32x4{0.f, 0.f, 0.f, 0.f}, hi, lo);
+      act[(0 * 2 + kh) * NPP + pix] = __builtin_bit_cast(u32x4, hi);
+      act[(1 * 2 + kh) * NPP + pix] = __builtin_bit_cast(u32x4, lo);
+    }
+  }
+}
+
+// weight slab of one chunk: NW 16-B groups, global -> registers -> LDS
+template <int NW, int NT = 256>
+struct WRegs { u32x4 w[(NW + NT - 1) / NT]; };
+
+template <int NW, int COW, int NT = 256>
+__device__ __forceinline__ void fetch_w(const F16Args& a, WRegs<NW, NT>& r, int ch, int co0, int tid) {
+  const u32x4* wsrc = a.wpk + (size_t)ch * (NW / COW) * a.cout_pad;
+#pragma unroll
+  for (int k = 0; k < (NW + NT - 1) / NT; ++k) {
+    int e = tid + NT * k;
+    e = e < NW ? e : NW - 1;
+    const int seg = e / COW, j = e - seg * COW;
+    r.w[k] = wsrc[(size_t)seg * a.cout_pad + co0 + j];
+  }
+}
+
+template <int NW, int NT = 256>
+__device__ __forceinline__ void commit_w(const WRegs<NW, NT>& r, u32x4* wgt, int tid) {
+#pragma unroll
+  for (int k = 0; k < (NW + NT - 1) / NT; ++k) {
+    const int e = tid + NT * k;
+    if (e < NW) wgt[e] = r.w[k];
   }
 }
 
 // ------------------------------------------------------------------------------------------------ Cout >= 32
-template <int CT, bool POOL>
-__global__ __launch_bounds__(256) void conv3x3_f16_kernel(F16Args a) {
+template <int CT, bool POOL, int TH>
+__global__ __launch_bounds__(32 * TH) void conv3x3_f16_kernel(F16Args a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int COW = CT * 32;
-  uint4* act = reinterpret_cast<uint4*>(smem);   // [4][NPP]
-  uint4* wgt = act + 4 * NPP;                    // [9][2][2][COW]
+  constexpr int COW = CT * 32, NPP = npp(TH), NT = 32 * TH, FTH = TH;
+  u32x4* act = reinterpret_cast<u32x4*>(smem);   // [4][NPP]
+  u32x4* wgt = act + 4 * NPP;                    // [9][2][2][COW]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, kh = lane >> 5;
   const int tile = xcd_swizzle(blockIdx.x, a.tiles_x * a.tiles_y);
@@ -108,15 +163,35 @@ __global__ __launch_bounds__(256) void conv3x3_f16_kernel(F16Args a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[c][p][r] = 0.f;
 
+  // software pipeline over the 16-channel chunks: the fp32 activations (and, for <= 64 couts, the weight slab) of
+  // chunk ch+1 are fetched into registers while chunk ch is on the matrix cores; they are converted / written to
+  // LDS after the barrier that retires chunk ch.  (128 couts: the 74 KB weight slab does not fit the register
+  // budget next to 128 accumulators -- it is loaded after the barrier, L2-resident.)
+  constexpr int NW = 36 * COW;
+  constexpr bool PREW = CT <= 2;   // prefetch the weight slab into registers
+  constexpr bool PREA = TH == 8;   // prefetch the activations into registers (8-wave tiles: 2 waves/SIMD overlap instead)
+  ActRegs ar;
+  WRegs<PREW ? NW : NT, NT> wr;
+  if constexpr (PREA) fetch_act<TH>(a, ar, 0, ty0, tx0, tid);
+  if constexpr (PREW) fetch_w<NW, COW, NT>(a, wr, 0, co0, tid);
   for (int ch = 0; ch < a.cin_chunks; ++ch) {
     if (ch) __syncthreads();
-    stage_act(a, act, ch, ty0, tx0, tid);
-    const uint4* wsrc = a.wpk + (size_t)ch * 36 * a.cout_pad;
-    for (int e = tid; e < 36 * COW; e += 256) {
-      const int seg = e / COW, j = e - seg * COW;
-      wgt[e] = wsrc[(size_t)seg * a.cout_pad + co0 + j];
+    if constexpr (!PREA) fetch_act<TH>(a, ar, ch, ty0, tx0, tid);
+    if constexpr (PREW) {
+      commit_w<NW, NT>(wr, wgt, tid);
+    } else {
+      const u32x4* wsrc = a.wpk + (size_t)ch * 36 * a.cout_pad;
+      for (int e = tid; e < NW; e += NT) {
+        const int seg = e / COW, j = e - seg * COW;
+        wgt[e] = wsrc[(size_t)seg * a.cout_pad + co0 + j];
+      }
     }
+    commit_act<TH>(a, ar, act, ch, tid);
     __syncthreads();
+    if (ch + 1 < a.cin_chunks) {
+      if constexpr (PREA) fetch_act<TH>(a, ar, ch + 1, ty0, tx0, tid);
+      if constexpr (PREW) fetch_w<NW, COW, NT>(a, wr, ch + 1, co0, tid);
+    }
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       const int dy = tap / 3, dx = tap - dy * 3;
@@ -185,8 +260,9 @@ __global__ __launch_bounds__(256) void conv3x3_f16_kernel(F16Args a) {
 template <bool POOL, bool OUT3>
 __global__ __launch_bounds__(256) void conv3x3_f16_c16_kernel(F16Args a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  uint4* act = reinterpret_cast<uint4*>(smem);   // [4][NPP]
-  uint4* wgt = act + 4 * NPP;                    // [10][2][2][16]
+  constexpr int FTH = 8, NPP = npp(8);
+  u32x4* act = reinterpret_cast<u32x4*>(smem);   // [4][NPP]
+  u32x4* wgt = act + 4 * NPP;                    // [10][2][2][16]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, kq = lane >> 4, kh = kq & 1, ts = kq >> 1;
   const int tile = xcd_swizzle(blockIdx.x, a.tiles_x * a.tiles_y);
@@ -198,12 +274,20 @@ __global__ __launch_bounds__(256) void conv3x3_f16_c16_kernel(F16Args a) {
 #pragma unroll
     for (int h = 0; h < 2; ++h) acc[r][h] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  constexpr int NW = 40 * 16;
+  ActRegs ar;
+  WRegs<NW> wr;
+  fetch_act<8>(a, ar, 0, ty0, tx0, tid);
+  fetch_w<NW, 16>(a, wr, 0, 0, tid);
   for (int ch = 0; ch < a.cin_chunks; ++ch) {
     if (ch) __syncthreads();
-    stage_act(a, act, ch, ty0, tx0, tid);
-    const uint4* wsrc = a.wpk + (size_t)ch * 40 * 16;
-    for (int e = tid; e < 40 * 16; e += 256) wgt[e] = wsrc[e];
+    commit_act<8>(a, ar, act, ch, tid);
+    commit_w<NW>(wr, wgt, tid);
     __syncthreads();
+    if (ch + 1 < a.cin_chunks) {
+      fetch_act<8>(a, ar, ch + 1, ty0, tx0, tid);
+      fetch_w<NW, 16>(a, wr, ch + 1, 0, tid);
+    }
 #pragma unroll
     for (int s = 0; s < 5; ++s) {
       const int tap = 2 * s + ts;               // tap 9 carries zero weights
@@ -273,12 +357,12 @@ __global__ __launch_bounds__(256) void conv3x3_f16_c16_kernel(F16Args a) {
 }
 
 template <typename K>
-hipError_t launch_k(K k, const F16Args& a, size_t lds, int groups, hipStream_t s) {
+hipError_t launch_k(K k, const F16Args& a, size_t lds, int groups, hipStream_t s, int threads = 256) {
   if (lds > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL(k, dim3(a.tiles_x * a.tiles_y, groups), dim3(256), lds, s, a);
+  hipLaunchKernelGGL(k, dim3(a.tiles_x * a.tiles_y, groups), dim3(threads), lds, s, a);
   return hipGetLastError();
 }
 
@@ -292,7 +376,7 @@ __global__ void absmax_kernel(const float* w, long n, unsigned* maxbits) {
 }
 
 __global__ void split_pack_kernel(const float* wpk32, int chunks, int cout_pad, int taps, const unsigned* maxbits,
-                                  uint4* out, float* inv_scale_out) {
+                                  u32x4* out, float* inv_scale_out) {
   // scale = 2^e with max|w| * scale in [256, 512)
   const float mx = __uint_as_float(*maxbits);
   int ex = 0;
@@ -320,7 +404,7 @@ __global__ void split_pack_kernel(const float* wpk32, int chunks, int cout_pad, 
     const _Float16 h = (_Float16)x;
     v[j] = hl ? (_Float16)(x - (float)h) : h;
   }
-  out[e] = __builtin_bit_cast(uint4, v);
+  out[e] = __builtin_bit_cast(u32x4, v);
 }
 
 }  // namespace
@@ -338,23 +422,23 @@ hipError_t launch_split_pack(const float* wpk32, int cin, int cout_pad, int taps
   hipLaunchKernelGGL(absmax_kernel, dim3(64), dim3(256), 0, s, wpk32, n, maxbits_dev);
   const long total = (long)chunks * taps * 4 * cout_pad;
   hipLaunchKernelGGL(split_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, wpk32, chunks, cout_pad, taps,
-                     maxbits_dev, reinterpret_cast<uint4*>(out), inv_scale_out);
+                     maxbits_dev, reinterpret_cast<u32x4*>(out), inv_scale_out);
   return hipGetLastError();
 }
 
 hipError_t launch_conv3x3_f16(const ConvDesc& d, const float* in, float* out, int H, int W, hipStream_t s) {
-  if (H < 2 || W < 2 || (d.flags & CONV_IN_NCHW3) || !d.wpk16) return hipErrorInvalidValue;
+  if (H < 2 || W < 2 || (d.flags & CONV_IN_NCHW3) || !d.wpk16 || (d.cin & 7)) return hipErrorInvalidValue;
   F16Args a;
-  a.in = in; a.out = out; a.wpk = reinterpret_cast<const uint4*>(d.wpk16); a.bias = d.bias;
+  a.in = in; a.out = out; a.wpk = reinterpret_cast<const u32x4*>(d.wpk16); a.bias = d.bias;
   a.inv_scale_ptr = d.inv_scale_ptr; a.inv_scale = d.inv_scale;
   a.H = H; a.W = W;
   a.up_in = (d.flags & CONV_UP_IN) ? 1 : 0;
   a.inH = a.up_in ? H / 2 : H; a.inW = a.up_in ? W / 2 : W;
   a.cin = d.cin; a.cout = d.cout; a.cin_chunks = d.cin_chunks; a.cout_pad = d.cout_pad;
-  a.tiles_x = (W + FTW - 1) / FTW; a.tiles_y = (H + FTH - 1) / FTH;
+  a.tiles_x = (W + FTW - 1) / FTW; a.tiles_y = (H + 7) / 8;
   a.relu = (d.flags & CONV_NO_RELU) ? 0 : 1;
   const bool pool = d.flags & CONV_POOL_OUT, out3 = d.flags & CONV_OUT_NCHW3;
-  const size_t act_b = (size_t)4 * NPP * 16;
+  const size_t act_b = (size_t)4 * npp(8) * 16;
   if (d.cout_pad == 16) {
     a.taps = 10;
     const size_t lds = act_b + (size_t)40 * 16 * 16;
@@ -368,11 +452,17 @@ hipError_t launch_conv3x3_f16(const ConvDesc& d, const float* in, float* out, in
     if (d.cout_pad % 128) return hipErrorInvalidValue;
     groups = d.cout_pad / 128; ct = 4;
   }
+  if (ct == 4) {  // 128 couts: 32 x 16 pixel tile, 8 waves (2 per SIMD), the 74 KB weight slab serves 512 pixels
+    a.tiles_y = (H + 15) / 16;
+    const size_t lds16 = (size_t)4 * npp(16) * 16 + (size_t)36 * 128 * 16;
+    return pool ? launch_k(conv3x3_f16_kernel<4, true, 16>, a, lds16, groups, s, 512)
+                : launch_k(conv3x3_f16_kernel<4, false, 16>, a, lds16, groups, s, 512);
+  }
   const size_t lds = act_b + (size_t)36 * ct * 32 * 16;
 #define WCT_F16_CASE(CTV) \
-  case CTV: return pool ? launch_k(conv3x3_f16_kernel<CTV, true>, a, lds, groups, s) : launch_k(conv3x3_f16_kernel<CTV, false>, a, lds, groups, s);
+  case CTV: return pool ? launch_k(conv3x3_f16_kernel<CTV, true, 8>, a, lds, groups, s) : launch_k(conv3x3_f16_kernel<CTV, false, 8>, a, lds, groups, s);
   switch (ct) {
-    WCT_F16_CASE(1) WCT_F16_CASE(2) WCT_F16_CASE(4)
+    WCT_F16_CASE(1) WCT_F16_CASE(2)
     default: return hipErrorInvalidValue;
   }
 #undef WCT_F16_CASE

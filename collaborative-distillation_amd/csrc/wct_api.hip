@@ -153,7 +153,7 @@ void prof_collect(wct_ctx* ctx) {
 // ---- one conv launch, with algorithmic work accounting ---------------------------------------------
 int run_conv(wct_ctx* ctx, Lane& ln, const ConvDesc& d, const float* in, float* out, int H, int W) {
   char name[48];
-  const bool f16 = ctx->conv_mode == 1 && d.wpk16 && !(d.flags & CONV_IN_NCHW3);
+  const bool f16 = ctx->conv_mode == 1 && d.wpk16 && !(d.flags & CONV_IN_NCHW3) && !(d.cin & 7);
   snprintf(name, sizeof name, "conv3x3%s<co=%d%s%s%s>", f16 ? "_f16x3" : "_f32", d.cout_pad > 128 ? 128 : d.cout_pad,
            (d.flags & CONV_IN_NCHW3) ? ",in3" : "", (d.flags & CONV_POOL_OUT) ? ",pool" : "", (d.flags & CONV_OUT_NCHW3) ? ",out3" : "");
   const double px = (double)H * W;
