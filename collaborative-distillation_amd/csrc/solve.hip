@@ -68,8 +68,10 @@ __device__ __forceinline__ double rotation(double al, double be, double ga, doub
   return s * rc;                                     // t
 }
 
-// ---- EigResult layout (doubles): G[C*C] | lam[C] | mu[C] | floor | pad(3)
-__host__ __device__ inline size_t eig_doubles(int C) { return (size_t)C * C + 2 * (size_t)C + 4; }
+// ---- EigResult layout (doubles): G[C*C] | lam[C] | mu[C] | floor | pad(3) | F[C*C]
+//      F = cov^(-1/2) (content) or cov^(+1/2) (style) on the live subspace -- what launch_assemble consumes
+__host__ __device__ inline size_t eig_doubles(int C) { return 2 * (size_t)C * C + 2 * (size_t)C + 4; }
+__host__ __device__ inline size_t eig_F_offset(int C) { return (size_t)C * C + 2 * (size_t)C + 4; }
 
 __global__ void cov_kernel(int C, double n, const double* sum, const double* sumsq, double* res) {
   const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -85,6 +87,137 @@ __global__ void cov_kernel(int C, double n, const double* sum, const double* sum
     for (int j = 0; j < C; ++j) ex2 = fmax(ex2, sumsq[(size_t)j * C + j]);
     res[(size_t)C * C + 2 * C] = ABS_FLOOR * ex2 / n;
   }
+}
+
+// =====================================================================================================
+// Primary path: coupled Newton-Schulz iteration for cov^(1/2) and cov^(-1/2) -- all GEMMs, so it runs on the
+// whole chip's fp64 matrix cores instead of one CU (a Jacobi sweep is a chain of n-1 dependent rounds):
+//     Y0 = A/s, Z0 = I;   T = (3I - Z Y)/2;  Y <- Y T;  Z <- T Z;     Y -> (A/s)^(1/2),  Z -> (A/s)^(-1/2)
+// with s = ||A||_F (eigenvalues of A/s in (0,1]).  Convergence is quadratic once ||I - Z Y|| < 1; covariances
+// of this path (cond 1e1..1e5 on the live block) take 10..18 iterations to 1e-14 (numpy prototype matched eigh to
+// 1e-13).  Dead channels (variance at round-off level) are replaced by an identity block and zeroed in the
+// result, which is the pseudo-inverse square root the Jacobi path forms by dropping them.
+// Every iterate is a polynomial in A, hence symmetric: operands are read transposed ("k-major") so that both
+// MFMA operands are coalesced 128-B runs.
+// The launch schedule is fixed (no host round trip): stage kernels of iteration k return at once when the
+// residual of iteration k-1 is already below NS_TOL.  If the budget runs out (singular or very ill-conditioned
+// matrix, e.g. fewer pixels than channels) ok stays 0 and the Jacobi path below takes over (C <= 128: one gated
+// launch; C > 128: decided on the host after reading the flag back, see launch_eig).
+constexpr int NS_MAXIT = 26, NS_MAXIT_REG = 26;
+constexpr double NS_TOL = 1e-7;   // on max|ZY - I| BEFORE an update; the update squares it (quadratic convergence)
+
+struct NsWs {           // carved from the eig workspace
+  double* Y[2]; double* Z[2]; double* T;
+  int* dead;            // [C]
+  double* scal;         // [0] = s (Frobenius norm)
+  unsigned long long* resid;  // [maxit + 1] max |ZY - I| per iteration, as double bits (non-negative -> integer order)
+  int* iters;           // iterations actually executed
+  int* ok;              // 1: F holds the Newton-Schulz result
+};
+
+__global__ __launch_bounds__(1024) void ns_init_kernel(const double* res, int C, double eps_rel, NsWs w, int maxit) {
+  __shared__ double red[1024];
+  const int tid = threadIdx.x;
+  const double floor_ = res[(size_t)C * C + 2 * C];
+  for (int j = tid; j < C; j += 1024) w.dead[j] = !(res[(size_t)j * C + j] > floor_);
+  for (int k = tid; k <= maxit; k += 1024) w.resid[k] = 0ull;  // atomicMax target; a skipped iteration leaves 0 = "converged"
+  if (tid == 0) { *w.iters = 0; *w.ok = 0; }
+  __syncthreads();
+  double s = 0.;
+  for (long e = tid; e < (long)C * C; e += 1024) {
+    const int r = (int)(e / C), c = (int)(e % C);
+    if (!w.dead[r] && !w.dead[c]) s += res[e] * res[e];
+  }
+  red[tid] = s;
+  __syncthreads();
+  for (int o = 512; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
+  if (tid == 0) {
+    double f = sqrt(red[0]);
+    if (!(f > 0.)) f = 1.;            // all channels dead: Y0 = I, result zeroed anyway
+    w.scal[0] = f * (1.0 + eps_rel);   // keeps the spectrum of (A + eps f I)/s inside (0, 1]
+    w.scal[1] = eps_rel * f;
+  }
+}
+
+__global__ void ns_fill_kernel(const double* res, int C, int Cp, NsWs w) {
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (long)Cp * Cp) return;
+  const int r = (int)(e / Cp), c = (int)(e % Cp);
+  double y = r == c ? 1.0 : 0.0;     // padding rows/cols and dead channels: identity block
+  if (r < C && c < C && !w.dead[r] && !w.dead[c]) y = (res[(size_t)r * C + c] + (r == c ? w.scal[1] : 0.0)) / w.scal[0];
+  w.Y[0][e] = y;
+  w.Z[0][e] = r == c ? 1.0 : 0.0;
+}
+
+// one 16x16 output tile per wave, 2x2 tiles per workgroup; operands symmetric -> P[i][k] is read as P[k][i]
+__device__ __forceinline__ f64x4 tile_gemm(const double* P, const double* Q, int Cp, int i0, int j0, int lane) {
+  const int li = lane & 15, kk = lane >> 4;
+  f64x4 acc = f64x4{0., 0., 0., 0.};
+  const double* pp = P + (size_t)kk * Cp + i0 + li;
+  const double* qq = Q + (size_t)kk * Cp + j0 + li;
+  for (int k0 = 0; k0 < Cp; k0 += 16) {
+    double a[4], b[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { a[u] = pp[(size_t)(k0 + 4 * u) * Cp]; b[u] = qq[(size_t)(k0 + 4 * u) * Cp]; }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], acc, 0, 0, 0);
+  }
+  return acc;  // row = kk + 4 * reg, col = li
+}
+
+__device__ __forceinline__ bool ns_converged(const NsWs& w, int it) {
+  return it > 0 && __longlong_as_double((long long)w.resid[it - 1]) < NS_TOL;
+}
+
+// stage 1 of iteration `it`: T = 1.5 I - 0.5 Z Y ; resid[it] = max |Z Y - I|
+__global__ __launch_bounds__(256) void ns_stage1_kernel(NsWs w, int Cp, int it) {
+  if (ns_converged(w, it)) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i0 = blockIdx.y * 32 + (wave >> 1) * 16, j0 = blockIdx.x * 32 + (wave & 1) * 16;
+  const int cur = it & 1;
+  const f64x4 acc = tile_gemm(w.Z[cur], w.Y[cur], Cp, i0, j0, lane);
+  const int li = lane & 15, kk = lane >> 4;
+  double m = 0.;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = i0 + kk + 4 * r, col = j0 + li;
+    const double zy = acc[r], d = zy - (row == col ? 1.0 : 0.0);
+    m = (d == d) ? fmax(m, fabs(d)) : __longlong_as_double(0x7ff0000000000000ll);  // fmax would swallow a NaN
+    w.T[(size_t)row * Cp + col] = (row == col ? 1.5 : 0.0) - 0.5 * zy;
+  }
+  for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o));
+  if (lane == 0) atomicMax(&w.resid[it], (unsigned long long)__double_as_longlong(m));
+}
+
+// stage 2: Y' = Y T (blockIdx.z = 0), Z' = T Z (blockIdx.z = 1), into the other ping-pong buffer
+__global__ __launch_bounds__(256) void ns_stage2_kernel(NsWs w, int Cp, int it) {
+  if (ns_converged(w, it)) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i0 = blockIdx.y * 32 + (wave >> 1) * 16, j0 = blockIdx.x * 32 + (wave & 1) * 16;
+  const int cur = it & 1, nxt = cur ^ 1;
+  const bool zside = blockIdx.z == 1;
+  const f64x4 acc = zside ? tile_gemm(w.T, w.Z[cur], Cp, i0, j0, lane) : tile_gemm(w.Y[cur], w.T, Cp, i0, j0, lane);
+  double* out = zside ? w.Z[nxt] : w.Y[nxt];
+  const int li = lane & 15, kk = lane >> 4;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) out[(size_t)(i0 + kk + 4 * r) * Cp + j0 + li] = acc[r];
+  if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) *w.iters = it + 1;
+}
+
+// F = Z / sqrt(s) (inverse) or Y * sqrt(s), dead rows/cols zeroed; ok = converged
+__global__ void ns_final_kernel(double* res, int C, int Cp, int inverse, NsWs w, int maxit, int* info) {
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  // n = executed iterations; the iterate lives in buffer n & 1.  resid[n-1] was measured on the iterate BEFORE the
+  // last executed update, which squares it.
+  const int n = *w.iters;
+  const bool ok = n >= 1 && n <= maxit && __longlong_as_double((long long)w.resid[n - 1]) < NS_TOL;
+  if (e == 0) { *w.ok = ok ? 1 : 0; if (info && ok) *info = n; }
+  if (e >= (long)C * C || !ok) return;
+  const int r = (int)(e / C), c = (int)(e % C);
+  const double s = w.scal[0];
+  double v = 0.;
+  if (!w.dead[r] && !w.dead[c]) v = inverse ? w.Z[n & 1][(size_t)r * Cp + c] * rsqrt(s) : w.Y[n & 1][(size_t)r * Cp + c] * sqrt(s);
+  res[eig_F_offset(C) + e] = v;
 }
 
 // ---- all-reduce of an fp64 value over the LPP (4, 8 or 16) lanes of a pair with DPP moves (no LDS round trips):
@@ -113,8 +246,9 @@ __device__ __forceinline__ double reduce_pair(double v) {
 //  * the kernel is bound by fp64 VALU issue on ONE CU: LPP lanes share a pair (each lane owns 2-row groups read as
 //    ds_read_b128), so the per-pair rotation arithmetic is amortised over 64/LPP pairs per wave instruction.
 template <int LPP>
-__global__ __launch_bounds__(64 * LPP) void jacobi_lds_kernel(double* res, int n_full, int* info) {
+__global__ __launch_bounds__(64 * LPP) void jacobi_lds_kernel(double* res, int n_full, int* info, const int* ns_ok) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  if (*ns_ok) return;   // the Newton-Schulz path converged: nothing to do (uniform branch, before any barrier)
   __builtin_amdgcn_s_setprio(3);  // latency-critical single-CU kernel: win issue arbitration against co-resident conv waves
   const int tid = threadIdx.x;
   double* Gg = res;
@@ -234,7 +368,7 @@ __global__ __launch_bounds__(64 * LPP) void jacobi_lds_kernel(double* res, int n
     const int cj = e / n, r = e - cj * n;
     Gg[(size_t)cj * n_full + live[r]] = G[cj * LD + r];  // column-major: column cj, full row index live[r]
   }
-  if (tid == 0 && info) *info = sweep;
+  if (tid == 0 && info) *info = 100 + sweep;   // 100 + sweeps: the Jacobi fallback ran
 }
 
 // ---- C > 128: columns stay in global memory (L2 resident); one launch per tournament round, one wave per pair.
@@ -290,7 +424,9 @@ __global__ void colnorm_kernel(double* res, int n, const int* fl, int* info) {
 }
 
 // out[a][b] = sum_{j live} lambda_j^(expo-2) G[a,j] G[b,j]   (G = V diag(lambda), column-major)
-__global__ __launch_bounds__(256) void sym_power_kernel(const double* res, int n, double expo, double rel_thresh, double* out) {
+__global__ __launch_bounds__(256) void sym_power_kernel(double* res, int n, double expo, double rel_thresh, const int* ns_ok) {
+  if (ns_ok && *ns_ok) return;
+  double* out = res + eig_F_offset(n);
   __shared__ double wj[512];
   const double* G = res;
   const double* lam = res + (size_t)n * n;
@@ -318,17 +454,6 @@ struct FinArgs {
   double* M64; double* b64; double* T;
 };
 
-__global__ void matmul_T_kernel(FinArgs f) {  // T = Ss Wc ; M = alpha T + (1-alpha) I
-  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  const int C = f.C;
-  if (e >= (long)C * C) return;
-  const int a = (int)(e / C), b = (int)(e % C);
-  double s = 0.;
-  for (int k = 0; k < C; ++k) s += f.Ss[(size_t)a * C + k] * f.Wc[(size_t)k * C + b];
-  f.T[e] = s;
-  f.M64[e] = f.alpha * s + (a == b ? 1.0 - f.alpha : 0.0);
-}
-
 __global__ void bias_kernel(FinArgs f) {  // b = alpha (mu_s - T mu_c)
   const int a = blockIdx.x * blockDim.x + threadIdx.x;
   const int C = f.C;
@@ -341,55 +466,103 @@ __global__ void bias_kernel(FinArgs f) {  // b = alpha (mu_s - T mu_c)
 }  // namespace
 
 size_t eig_result_bytes(int C) { return eig_doubles(C) * sizeof(double); }
-size_t eig_workspace_bytes(int C) { return C > 128 ? (MAX_SWEEPS + 1) * sizeof(int) : 16; }
-size_t assemble_workspace_bytes(int C) { return 3 * (size_t)C * C * sizeof(double); }
+static inline int ns_pad(int C) { return (C + 31) / 32 * 32; }
+size_t eig_workspace_bytes(int C) {
+  const size_t cp2 = (size_t)ns_pad(C) * ns_pad(C);
+  return 5 * cp2 * sizeof(double) + (size_t)C * sizeof(int) + 4 * sizeof(double) + (NS_MAXIT_REG + 2) * sizeof(unsigned long long) + 64;
+}
+size_t assemble_workspace_bytes(int C) { return (size_t)C * C * sizeof(double); }
 
-hipError_t launch_eig(int C, double n, const double* sum, const double* sumsq, double* res, int* info_dev, void* ws,
-                      size_t ws_bytes, hipStream_t s) {
+hipError_t launch_eig(int C, double n, const double* sum, const double* sumsq, int inverse, double* res, int* info_dev,
+                      void* ws, size_t ws_bytes, hipStream_t s) {
   if (C < 2 || (C & 1) || C > 512 || n < 2) return hipErrorInvalidValue;  // unbiased covariance needs n >= 2
   if (ws_bytes < eig_workspace_bytes(C)) return hipErrorOutOfMemory;
   const size_t cc = (size_t)C * C;
+  const int Cp = ns_pad(C);
+  const size_t cp2 = (size_t)Cp * Cp;
   hipLaunchKernelGGL(cov_kernel, dim3((unsigned)((cc + 255) / 256)), dim3(256), 0, s, C, n, sum, sumsq, res);
-  if (C <= 128) {
+  NsWs w;
+  double* p = reinterpret_cast<double*>(ws);
+  w.Y[0] = p; w.Y[1] = p + cp2; w.Z[0] = p + 2 * cp2; w.Z[1] = p + 3 * cp2; w.T = p + 4 * cp2;
+  w.scal = p + 5 * cp2;
+  w.resid = reinterpret_cast<unsigned long long*>(w.scal + 4);
+  w.iters = reinterpret_cast<int*>(w.resid + NS_MAXIT_REG + 2);
+  w.ok = w.iters + 1;
+  w.dead = w.iters + 2;
+  const bool big = C > 128;
+  const int maxit = NS_MAXIT;
+  hipLaunchKernelGGL(ns_init_kernel, dim3(1), dim3(1024), 0, s, res, C, 1e-15, w, maxit);
+  hipLaunchKernelGGL(ns_fill_kernel, dim3((unsigned)((cp2 + 255) / 256)), dim3(256), 0, s, res, C, Cp, w);
+  const dim3 g1(Cp / 32, Cp / 32, 1), g2(Cp / 32, Cp / 32, 2);
+  for (int it = 0; it < maxit; ++it) {
+    hipLaunchKernelGGL(ns_stage1_kernel, g1, dim3(256), 0, s, w, Cp, it);
+    hipLaunchKernelGGL(ns_stage2_kernel, g2, dim3(256), 0, s, w, Cp, it);
+  }
+  hipLaunchKernelGGL(ns_final_kernel, dim3((unsigned)((cc + 255) / 256)), dim3(256), 0, s, res, C, Cp, inverse, w, maxit, info_dev);
+  if (big) {
+    // C > 128 has no single-CU Jacobi.  A singular covariance (fewer pixels than channels) needs the true
+    // pseudo-inverse -- a regularised inverse would put gains of 1e6 into the folded decoder weights and lose
+    // everything to cancellation -- so the outcome of the iteration is read back (one 4-byte copy + stream sync per
+    // solve, original mode only) and the slow global-memory Jacobi (one launch per tournament round) runs only then.
+    int ok_host = 0;
+    hipError_t e = hipMemcpyAsync(&ok_host, w.ok, sizeof(int), hipMemcpyDeviceToHost, s);
+    if (e != hipSuccess) return e;
+    e = hipStreamSynchronize(s);
+    if (e != hipSuccess) return e;
+    if (!ok_host) {
+      int* flags = reinterpret_cast<int*>(w.Y[0]);  // the iteration's buffers are free now
+      e = hipMemsetAsync(flags, 0, (MAX_SWEEPS + 1) * sizeof(int), s);
+      if (e != hipSuccess) return e;
+      const int sweeps = 16;  // fp64 cyclic Jacobi converges quadratically; later sweeps exit at once via flags
+      const dim3 grid((unsigned)((C / 2 + 3) / 4));
+      for (int sw = 0; sw < sweeps; ++sw)
+        for (int r = 0; r < C - 1; ++r)
+          hipLaunchKernelGGL(jacobi_round_global_kernel, grid, dim3(256), 0, s, res, C, r, sw, flags);
+      hipLaunchKernelGGL(colnorm_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, s, res, C, flags, info_dev);
+      hipLaunchKernelGGL(sym_power_kernel, dim3((unsigned)((cc + 255) / 256)), dim3(256), 0, s, res, C, inverse ? -0.5 : 0.5, 1e-10,
+                         (const int*)nullptr);
+    }
+  } else {
     const size_t lds = ((size_t)C * ((C + 31) / 32 * 32 + 2) + C) * sizeof(double) + (size_t)(C + 4) * sizeof(int);
     static int lpp = [] { const char* e = getenv("WCT_JACOBI_LPP"); return e ? atoi(e) : 16; }();
     auto go = [&](auto kern, int LPPv) -> hipError_t {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return e;
       const unsigned threads = (unsigned)(((C / 2) * LPPv + 63) / 64 * 64);
-      hipLaunchKernelGGL(kern, dim3(1), dim3(threads), lds, s, res, C, info_dev);
+      hipLaunchKernelGGL(kern, dim3(1), dim3(threads), lds, s, res, C, info_dev, (const int*)w.ok);
       return hipSuccess;
     };
     hipError_t e = lpp == 16 ? go(jacobi_lds_kernel<16>, 16) : lpp == 8 ? go(jacobi_lds_kernel<8>, 8) : go(jacobi_lds_kernel<4>, 4);
     if (e != hipSuccess) return e;
-  } else {
-    int* flags = reinterpret_cast<int*>(ws);
-    hipError_t e = hipMemsetAsync(flags, 0, (MAX_SWEEPS + 1) * sizeof(int), s);
-    if (e != hipSuccess) return e;
-    const int sweeps = 16;  // fp64 cyclic Jacobi converges quadratically; later sweeps exit at once via flags
-    const dim3 grid((unsigned)((C / 2 + 3) / 4));
-    for (int sw = 0; sw < sweeps; ++sw)
-      for (int r = 0; r < C - 1; ++r)
-        hipLaunchKernelGGL(jacobi_round_global_kernel, grid, dim3(256), 0, s, res, C, r, sw, flags);
-    hipLaunchKernelGGL(colnorm_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, s, res, C, flags, info_dev);
+    hipLaunchKernelGGL(sym_power_kernel, dim3((unsigned)((cc + 255) / 256)), dim3(256), 0, s, res, C, inverse ? -0.5 : 0.5, 1e-10,
+                       (const int*)w.ok);
   }
   return hipGetLastError();
 }
 
+namespace {
+__global__ void matmul_T_kernel2(int C, double alpha, const double* Ss, const double* Wc, double* T, double* M) {
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (long)C * C) return;
+  const int a = (int)(e / C), b = (int)(e % C);
+  double s = 0.;
+  for (int k = 0; k < C; ++k) s += Ss[(size_t)a * C + k] * Wc[(size_t)k * C + b];
+  T[e] = s;
+  M[e] = alpha * s + (a == b ? 1.0 - alpha : 0.0);
+}
+}  // namespace
+
 hipError_t launch_assemble(int C, const double* eig_c, const double* eig_s, double alpha, double rel_thresh, double* M,
                            double* b, void* ws, size_t ws_bytes, hipStream_t s) {
+  (void)rel_thresh;
   if (ws_bytes < assemble_workspace_bytes(C)) return hipErrorOutOfMemory;
   const size_t cc = (size_t)C * C;
-  double* Wc = reinterpret_cast<double*>(ws);
-  double* Ss = Wc + cc;
-  double* T = Ss + cc;
+  double* T = reinterpret_cast<double*>(ws);
   const unsigned nb = (unsigned)((cc + 255) / 256);
-  hipLaunchKernelGGL(sym_power_kernel, dim3(nb), dim3(256), 0, s, eig_c, C, -0.5, rel_thresh, Wc);
-  hipLaunchKernelGGL(sym_power_kernel, dim3(nb), dim3(256), 0, s, eig_s, C, 0.5, rel_thresh, Ss);
+  hipLaunchKernelGGL(matmul_T_kernel2, dim3(nb), dim3(256), 0, s, C, alpha, eig_s + eig_F_offset(C), eig_c + eig_F_offset(C), T, M);
   FinArgs f;
-  f.C = C; f.alpha = alpha; f.Ss = Ss; f.Wc = Wc; f.mu_c = eig_c + cc + C; f.mu_s = eig_s + cc + C;
+  f.C = C; f.alpha = alpha; f.Ss = nullptr; f.Wc = nullptr; f.mu_c = eig_c + cc + C; f.mu_s = eig_s + cc + C;
   f.M64 = M; f.b64 = b; f.T = T;
-  hipLaunchKernelGGL(matmul_T_kernel, dim3(nb), dim3(256), 0, s, f);
   hipLaunchKernelGGL(bias_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, s, f);
   return hipGetLastError();
 }

@@ -343,13 +343,13 @@ int moments_impl(wct_ctx* ctx, Lane& ln, const float* feat, int C, int h, int w,
 }
 
 // (n, sum, sumsq) of one feature map -> EigResult in `res` (covariance, Jacobi eigen-decomposition)
-int eig_impl(wct_ctx* ctx, Lane& ln, int C, double n, const double* sum, const double* sumsq, DevBuf& res, int* info_dev) {
+int eig_impl(wct_ctx* ctx, Lane& ln, int C, double n, const double* sum, const double* sumsq, int inverse, DevBuf& res, int* info_dev) {
   if (C < 2 || (C & 1) || C > 512) return fail(ctx, WCT_ERR_INVALID, "solve: C=%d must be even and <= 512", C);
   if (n < 2) return fail(ctx, WCT_ERR_INVALID, "solve: unbiased covariance needs >= 2 pixels (n=%g)", n);
   if (int rc = ensure(ctx, res, eig_result_bytes(C))) return rc;
   if (int rc = ensure(ctx, ln.wsEig, eig_workspace_bytes(C))) return rc;
-  ProfScope ps(ctx, ln.stream, "eig_jacobi", 0, 0);
-  HIPCHK(ctx, launch_eig(C, n, sum, sumsq, reinterpret_cast<double*>(res.p), info_dev, ln.wsEig.p, ln.wsEig.cap, ln.stream));
+  ProfScope ps(ctx, ln.stream, inverse ? "matfun_invsqrt" : "matfun_sqrt", 0, 0);
+  HIPCHK(ctx, launch_eig(C, n, sum, sumsq, inverse, reinterpret_cast<double*>(res.p), info_dev, ln.wsEig.p, ln.wsEig.cap, ln.stream));
   return WCT_OK;
 }
 
@@ -411,7 +411,7 @@ int style_side(wct_ctx* ctx, int level, const float* style, int Hs, int Ws) {
   float* fS = reinterpret_cast<float*>(ctx->featS.p);
   if (int rc = encode_impl(ctx, ln, level, style, Hs, Ws, fS, nullptr, nullptr)) return rc;
   if (int rc = moments_impl(ctx, ln, fS, C, hs, ws, 0, ws, sv.sum, sv.sumsq)) return rc;
-  if (int rc = eig_impl(ctx, ln, C, (double)hs * ws, sv.sum, sv.sumsq, ctx->eigS[level], sv.info + 1)) return rc;
+  if (int rc = eig_impl(ctx, ln, C, (double)hs * ws, sv.sum, sv.sumsq, 0, ctx->eigS[level], sv.info + 1)) return rc;
   HIPCHK(ctx, hipEventRecord(ctx->ev_style[level], ln.stream));
   return WCT_OK;
 }
@@ -441,7 +441,7 @@ int content_side(wct_ctx* ctx, int level, const float* content, int H, int W, fl
   // cF = encoder(contentImg)                                  (WCT.py:101)
   if (int rc = encode_impl(ctx, ln, level, content, H, W, fC, nullptr, nullptr)) return rc;
   if (int rc = moments_impl(ctx, ln, fC, C, h, w, 0, w, sv.sum, sv.sumsq)) return rc;
-  if (int rc = eig_impl(ctx, ln, C, (double)h * w, sv.sum, sv.sumsq, ctx->eigC, sv.info)) return rc;
+  if (int rc = eig_impl(ctx, ln, C, (double)h * w, sv.sum, sv.sumsq, 1, ctx->eigC, sv.info)) return rc;
   // csF = wct.transform(cF, sF, csF, alpha)                  (WCT.py:104) -- as an affine map
   HIPCHK(ctx, hipStreamWaitEvent(ln.stream, ctx->ev_style[level], 0));
   if (int rc = assemble_impl(ctx, C, ctx->eigC, ctx->eigS[level], alpha, M, b)) return rc;
@@ -624,8 +624,8 @@ int wct_solve(wct_ctx* ctx, int C, double n_c, const double* sum_c, const double
   if (!sum_c || !sumsq_c || !sum_s || !sumsq_s || !M || !b) return fail(ctx, WCT_ERR_INVALID, "solve: NULL pointer");
   SumsView sv;
   if (int rc = sums_view(ctx, ctx->main, sv)) return rc;
-  if (int rc = eig_impl(ctx, ctx->main, C, n_c, sum_c, sumsq_c, ctx->eigC, sv.info)) return rc;
-  if (int rc = eig_impl(ctx, ctx->main, C, n_s, sum_s, sumsq_s, ctx->eigS[0], sv.info + 1)) return rc;
+  if (int rc = eig_impl(ctx, ctx->main, C, n_c, sum_c, sumsq_c, 1, ctx->eigC, sv.info)) return rc;
+  if (int rc = eig_impl(ctx, ctx->main, C, n_s, sum_s, sumsq_s, 0, ctx->eigS[0], sv.info + 1)) return rc;
   if (int rc = assemble_impl(ctx, C, ctx->eigC, ctx->eigS[0], alpha, M, b)) return rc;
   if (info) {
     HIPCHK(ctx, hipMemcpyAsync(info, sv.info, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->main.stream));
@@ -678,9 +678,9 @@ int wct_transform(wct_ctx* ctx, const float* cF, int C, int h, int w, const floa
     s = reinterpret_cast<float*>(ctx->featS.p);
   }
   if (int rc = moments_impl(ctx, ln, c, C, h, w, 0, w, sv.sum, sv.sumsq)) return rc;
-  if (int rc = eig_impl(ctx, ln, C, (double)h * w, sv.sum, sv.sumsq, ctx->eigC, sv.info)) return rc;
+  if (int rc = eig_impl(ctx, ln, C, (double)h * w, sv.sum, sv.sumsq, 1, ctx->eigC, sv.info)) return rc;
   if (int rc = moments_impl(ctx, ln, s, C, hs, ws, 0, ws, sv.sum, sv.sumsq)) return rc;
-  if (int rc = eig_impl(ctx, ln, C, (double)hs * ws, sv.sum, sv.sumsq, ctx->eigS[0], sv.info + 1)) return rc;
+  if (int rc = eig_impl(ctx, ln, C, (double)hs * ws, sv.sum, sv.sumsq, 0, ctx->eigS[0], sv.info + 1)) return rc;
   if (int rc = assemble_impl(ctx, C, ctx->eigC, ctx->eigS[0], alpha, M, b)) return rc;
   return wct_apply(ctx, cF, C, h, w, layout, M, b, out);
 }

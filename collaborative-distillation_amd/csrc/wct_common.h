@@ -55,7 +55,7 @@ hipError_t launch_moments(const float* feat_nhwc, int C, int h, int wfull, int x
 size_t eig_result_bytes(int C);
 size_t eig_workspace_bytes(int C);
 size_t assemble_workspace_bytes(int C);
-hipError_t launch_eig(int C, double n, const double* sum, const double* sumsq, double* res, int* info_dev,
+hipError_t launch_eig(int C, double n, const double* sum, const double* sumsq, int inverse, double* res, int* info_dev,
                       void* workspace, size_t workspace_bytes, hipStream_t s);
 hipError_t launch_assemble(int C, const double* eig_c, const double* eig_s, double alpha, double rel_thresh,
                            double* M, double* b, void* workspace, size_t workspace_bytes, hipStream_t s);

@@ -103,7 +103,12 @@ def test_moments_and_solve_split_form(torch_cuda, wct16, oracle, C, n):
     _, mc, cc = oracle.moments(np.ascontiguousarray(f[:, x0:x1].transpose(2, 0, 1)))
     _, ms, cs = oracle.moments(np.ascontiguousarray(s.transpose(2, 0, 1)))
     Mr, br = oracle.affine_from_moments(mc, cc, ms, cs, 0.8)
-    assert 0 < info[0] < 40 and 0 < info[1] < 40      # Jacobi converged (sweep counts)
+    # info: Newton-Schulz iterations (< 40), or 100 + Jacobi sweeps when the fallback ran (singular covariance:
+    # fewer pixels than channels) -- either way it converged
+    for i in info:
+        assert 0 < i < 40 or 100 < i < 140
+    if n > 4 * C:
+        assert info[0] < 40    # well-conditioned content covariance: the GEMM path must have handled it
     assert rel_err(M.cpu().numpy(), Mr) < 1e-8 and rel_err(b.cpu().numpy(), br) < 1e-8
 
 
