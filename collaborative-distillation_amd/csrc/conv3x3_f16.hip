@@ -356,6 +356,237 @@ __global__ __launch_bounds__(256) void conv3x3_f16_c16_kernel(F16Args a) {
   }
 }
 
+
+// =====================================================================================================
+// Fused full-resolution ends of the 16x networks.  The first two encoder layers (conv11 3->16, conv12 16->16
+// + pool: model_cd.py:726-728) and the last two decoder layers (conv12 16->16 after the upsample, conv11 16->3:
+// model_cd.py:291-293) run at full image resolution with only 16 channels: unfused they move 156 B per pixel
+// (the 64 B/px intermediate written and read back), fused 28 B per pixel.  The intermediate lives only in LDS,
+// already split into f16 hi/lo planes.  Arithmetic and summation order are those of the unfused kernels, so
+// results are bitwise identical to running the two layers separately.
+// The intermediate's own reflect padding: a halo pixel OUTSIDE the image must hold the intermediate value of its
+// mirror pixel (not the first conv evaluated outside the image), so every halo pixel is evaluated at its reflected
+// image coordinate -- whose 3x3 input window is inside the staged tile -- and stored at the halo position.
+constexpr int I2W = FTW + 4, I2H = 8 + 4;       // 36 x 12: input tile of the first conv (two halo rings)
+constexpr int NPI2 = I2W * I2H;                 // 432 (a multiple of 16)
+constexpr int NGRP = (nph(8) + 15) / 16;        // 22 groups of 16 halo pixels
+
+struct HeadArgs {   // conv11 (3->16, fp32 MFMA, conv0 folded) + ReLU -> conv12 (16->16, f16x3) + ReLU -> 2x2 max-pool
+  const float* img; float* out;
+  const float* w11; const float* b11;           // in3 packing [tap][4][16], bias [16]
+  const u32x4* w12; const float* b12; float inv12;
+  int H, W, tiles_x, tiles_y;
+};
+
+__device__ __forceinline__ void store_split4(u32x4* planes, int npp, int pix, int kq, const f32x4& v) {
+  // 4 consecutive channels 4kq..4kq+3 of halo pixel `pix` -> 8 bytes in the hi plane and 8 in the lo plane
+  _Float16 h[4], l[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float x = fminf(fmaxf(v[r], -65504.f), 65504.f);
+    h[r] = (_Float16)x;
+    l[r] = (_Float16)(x - (float)h[r]);
+  }
+  typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+  f16x4* ph = reinterpret_cast<f16x4*>(planes + (0 * 2 + (kq >> 1)) * npp + pix) + (kq & 1);
+  f16x4* pl = reinterpret_cast<f16x4*>(planes + (1 * 2 + (kq >> 1)) * npp + pix) + (kq & 1);
+  *ph = f16x4{h[0], h[1], h[2], h[3]};
+  *pl = f16x4{l[0], l[1], l[2], l[3]};
+}
+
+// 16->16 conv on the [4][NPP] planes of a 34 x 10 halo tile for the wave's 2 rows x 32 px (the c16 kernel's body)
+__device__ __forceinline__ void c16_compute(const u32x4* act, const u32x4* wgt, int wave, int li, int kq, f32x4 (&acc)[2][2]) {
+  constexpr int NPP = npp(8);
+  const int kh = kq & 1, ts = kq >> 1;
+#pragma unroll
+  for (int s = 0; s < 5; ++s) {
+    const int tap = 2 * s + ts;
+    const int tc = tap > 8 ? 8 : tap;
+    const int dy = tc / 3, dx = tc - dy * 3;
+    const f16x8 ah = __builtin_bit_cast(f16x8, wgt[((tap * 2 + 0) * 2 + kh) * 16 + li]);
+    const f16x8 al = __builtin_bit_cast(f16x8, wgt[((tap * 2 + 1) * 2 + kh) * 16 + li]);
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int pix = (wave * 2 + r + dy) * FHW + h * 16 + li + dx;
+        const f16x8 bh = __builtin_bit_cast(f16x8, act[(0 * 2 + kh) * NPP + pix]);
+        const f16x8 bl = __builtin_bit_cast(f16x8, act[(1 * 2 + kh) * NPP + pix]);
+        acc[r][h] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc[r][h], 0, 0, 0);
+        acc[r][h] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc[r][h], 0, 0, 0);
+        acc[r][h] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc[r][h], 0, 0, 0);
+      }
+  }
+}
+
+__global__ __launch_bounds__(256) void enc_head_kernel(HeadArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NPP = npp(8), NPH = nph(8);
+  f32x4* imgT = reinterpret_cast<f32x4*>(smem);               // [432] (c0, c1, c2, 0)
+  float* w11 = reinterpret_cast<float*>(imgT + NPI2);          // [36][16]
+  u32x4* act = reinterpret_cast<u32x4*>(w11 + 36 * 16);        // [4][NPP]
+  u32x4* wgt = act + 4 * NPP;                                  // [10][2][2][16]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, kq = lane >> 4;
+  const int tile = xcd_swizzle(blockIdx.x, a.tiles_x * a.tiles_y);
+  const int ty0 = (tile / a.tiles_x) * 8, tx0 = (tile % a.tiles_x) * FTW;
+  const size_t plane = (size_t)a.H * a.W;
+  for (int e = tid; e < NPI2; e += 256) {
+    const int py = e / I2W, px = e - py * I2W;
+    const int gy = reflect_clamp(ty0 - 2 + py, a.H), gx = reflect_clamp(tx0 - 2 + px, a.W);
+    const size_t off = (size_t)gy * a.W + gx;
+    imgT[e] = f32x4{a.img[off], a.img[plane + off], a.img[2 * plane + off], 0.f};
+  }
+  for (int e = tid; e < 36 * 16; e += 256) w11[e] = a.w11[e];
+  for (int e = tid; e < 40 * 16; e += 256) wgt[e] = a.w12[e];
+  __syncthreads();
+  // ---- conv11 on the 340 halo pixels (fp32 MFMA, the arithmetic of conv3x3_kernel<IN3>), split into the planes
+  const float* imgF = reinterpret_cast<const float*>(imgT);
+  const f32x4 bias11 = *reinterpret_cast<const f32x4*>(a.b11 + 4 * kq);
+  for (int g = wave; g < NGRP; g += 4) {
+    const int pixr = g * 16 + li, pix = pixr < NPH ? pixr : NPH - 1;
+    const int py = pix / FHW, px = pix - py * FHW;
+    const int iy = reflect_clamp(ty0 - 1 + py, a.H) - (ty0 - 2), ix = reflect_clamp(tx0 - 1 + px, a.W) - (tx0 - 2);
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int dy = tap / 3, dx = tap - dy * 3;
+      const float bv = imgF[((iy - 1 + dy) * I2W + ix - 1 + dx) * 4 + kq];
+      const float av = w11[(tap * 4 + kq) * 16 + li];
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+    }
+    f32x4 v = acc + bias11;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+    if (pixr < NPH) store_split4(act, NPP, pix, kq, v);
+  }
+  __syncthreads();
+  // ---- conv12 + ReLU + 2x2 max-pool (the arithmetic of conv3x3_f16_c16_kernel<POOL>)
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int r = 0; r < 2; ++r)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) acc[r][h] = f32x4{0.f, 0.f, 0.f, 0.f};
+  c16_compute(act, wgt, wave, li, kq, acc);
+  const int co = 4 * kq;
+  const f32x4 bias = *reinterpret_cast<const f32x4*>(a.b12 + co);
+  const int Hp = a.H >> 1, Wp = a.W >> 1;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int gx = tx0 + h * 16 + li;
+    f32x4 m;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float v = fmaxf(acc[0][h][r], acc[1][h][r]);
+      v = fmaxf(v, __shfl_xor(v, 1));
+      v = v * a.inv12 + bias[r];
+      m[r] = fmaxf(v, 0.f);
+    }
+    const int oy = (ty0 + wave * 2) >> 1, ox = gx >> 1;
+    if (!(li & 1) && oy < Hp && ox < Wp) *reinterpret_cast<f32x4*>(a.out + ((size_t)oy * Wp + ox) * 16 + co) = m;
+  }
+}
+
+struct TailArgs {   // conv12 (16->16 on the nearest-x2 upsampled input) + ReLU -> conv11 (16->3) + ReLU -> planar image
+  const float* in; float* out;
+  const u32x4* w12; const float* b12; float inv12; const float* inv12_ptr;
+  const u32x4* w11; const float* b11; float inv11;
+  int H, W, inW, up_in, tiles_x, tiles_y;
+};
+
+__global__ __launch_bounds__(256) void dec_tail_kernel(TailArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NPP = npp(8), NPH = nph(8);
+  u32x4* act0 = reinterpret_cast<u32x4*>(smem);   // [4][432]  input of conv12 (two halo rings)
+  u32x4* wg12 = act0 + 4 * NPI2;                  // [640]
+  u32x4* wg11 = wg12 + 640;                       // [640]
+  u32x4* act1 = wg11 + 640;                       // [4][NPP]  conv12 output on the 34 x 10 halo
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, kq = lane >> 4, kh = kq & 1, ts = kq >> 1;
+  const int tile = xcd_swizzle(blockIdx.x, a.tiles_x * a.tiles_y);
+  const int ty0 = (tile / a.tiles_x) * 8, tx0 = (tile % a.tiles_x) * FTW;
+  // ---- stage the 36 x 12 x 16 input (unconditional batched loads, then split)
+  constexpr int SL = (NPI2 * 2 + 255) / 256;  // 4
+  f32x4 v0[SL], v1[SL];
+#pragma unroll
+  for (int k = 0; k < SL; ++k) {
+    int e = tid + 256 * k;
+    e = e < NPI2 * 2 ? e : NPI2 * 2 - 1;
+    const int h2 = e & 1, pix = e >> 1;
+    const int py = pix / I2W, px = pix - py * I2W;
+    int gy = reflect_clamp(ty0 - 2 + py, a.H), gx = reflect_clamp(tx0 - 2 + px, a.W);
+    if (a.up_in) { gy >>= 1; gx >>= 1; }
+    const float* src = a.in + ((size_t)gy * a.inW + gx) * 16 + h2 * 8;
+    v0[k] = *reinterpret_cast<const f32x4*>(src);
+    v1[k] = *reinterpret_cast<const f32x4*>(src + 4);
+  }
+  for (int e = tid; e < 640; e += 256) { wg12[e] = a.w12[e]; wg11[e] = a.w11[e]; }
+#pragma unroll
+  for (int k = 0; k < SL; ++k) {
+    const int e = tid + 256 * k;
+    if (e < NPI2 * 2) {
+      f16x8 hi, lo;
+      split8(v0[k], v1[k], hi, lo);
+      act0[(0 * 2 + (e & 1)) * NPI2 + (e >> 1)] = __builtin_bit_cast(u32x4, hi);
+      act0[(1 * 2 + (e & 1)) * NPI2 + (e >> 1)] = __builtin_bit_cast(u32x4, lo);
+    }
+  }
+  __syncthreads();
+  // ---- conv12 on the 340 halo pixels (evaluated at their reflected image coordinates), into act1
+  const float inv12 = a.inv12_ptr ? *a.inv12_ptr : a.inv12;
+  const f32x4 bias12 = *reinterpret_cast<const f32x4*>(a.b12 + 4 * kq);
+  for (int g = wave; g < NGRP; g += 4) {
+    const int pixr = g * 16 + li, pix = pixr < NPH ? pixr : NPH - 1;
+    const int py = pix / FHW, px = pix - py * FHW;
+    const int iy = reflect_clamp(ty0 - 1 + py, a.H) - (ty0 - 2), ix = reflect_clamp(tx0 - 1 + px, a.W) - (tx0 - 2);
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 5; ++s) {
+      const int tap = 2 * s + ts;
+      const int tc = tap > 8 ? 8 : tap;
+      const int dy = tc / 3, dx = tc - dy * 3;
+      const f16x8 ah = __builtin_bit_cast(f16x8, wg12[((tap * 2 + 0) * 2 + kh) * 16 + li]);
+      const f16x8 al = __builtin_bit_cast(f16x8, wg12[((tap * 2 + 1) * 2 + kh) * 16 + li]);
+      const int sp = (iy - 1 + dy) * I2W + ix - 1 + dx;
+      const f16x8 bh = __builtin_bit_cast(f16x8, act0[(0 * 2 + kh) * NPI2 + sp]);
+      const f16x8 bl = __builtin_bit_cast(f16x8, act0[(1 * 2 + kh) * NPI2 + sp]);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc, 0, 0, 0);
+    }
+    f32x4 v;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = fmaxf(acc[r] * inv12 + bias12[r], 0.f);
+    if (pixr < NPH) store_split4(act1, NPP, pix, kq, v);
+  }
+  __syncthreads();
+  // ---- conv11 (16 -> 3) + ReLU -> planar output (the arithmetic of conv3x3_f16_c16_kernel<OUT3>)
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int r = 0; r < 2; ++r)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) acc[r][h] = f32x4{0.f, 0.f, 0.f, 0.f};
+  c16_compute(act1, wg11, wave, li, kq, acc);
+  const f32x4 bias = *reinterpret_cast<const f32x4*>(a.b11);
+  const size_t plane = (size_t)a.H * a.W;
+  if (kq == 0) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int gx = tx0 + h * 16 + li;
+#pragma unroll
+      for (int r2 = 0; r2 < 2; ++r2) {
+        const int gy = ty0 + wave * 2 + r2;
+        if (gy < a.H && gx < a.W) {
+          const size_t off = (size_t)gy * a.W + gx;
+          a.out[off] = fmaxf(acc[r2][h][0] * a.inv11 + bias[0], 0.f);
+          a.out[plane + off] = fmaxf(acc[r2][h][1] * a.inv11 + bias[1], 0.f);
+          a.out[2 * plane + off] = fmaxf(acc[r2][h][2] * a.inv11 + bias[2], 0.f);
+        }
+      }
+    }
+  }
+}
+
 template <typename K>
 hipError_t launch_k(K k, const F16Args& a, size_t lds, int groups, hipStream_t s, int threads = 256) {
   if (lds > 48 * 1024) {
@@ -408,6 +639,45 @@ __global__ void split_pack_kernel(const float* wpk32, int chunks, int cout_pad, 
 }
 
 }  // namespace
+
+
+bool conv_fusable_head(const ConvDesc& d0, const ConvDesc& d1) {
+  return (d0.flags & CONV_IN_NCHW3) && !(d0.flags & (CONV_POOL_OUT | CONV_NO_RELU)) && d0.cout == 16 && d0.cout_pad == 16 &&
+         d1.cin == 16 && d1.cout == 16 && d1.cout_pad == 16 && (d1.flags & CONV_POOL_OUT) && !(d1.flags & (CONV_UP_IN | CONV_NO_RELU)) &&
+         d1.wpk16 && !d1.inv_scale_ptr;
+}
+
+bool conv_fusable_tail(const ConvDesc& d0, const ConvDesc& d1) {
+  return d0.cin == 16 && d0.cout == 16 && d0.cout_pad == 16 && !(d0.flags & (CONV_POOL_OUT | CONV_NO_RELU | CONV_IN_NCHW3 | CONV_OUT_NCHW3)) &&
+         d0.wpk16 && (d1.flags & CONV_OUT_NCHW3) && d1.cin == 16 && d1.cout == 3 && d1.cout_pad == 16 && d1.wpk16 &&
+         !(d1.flags & (CONV_UP_IN | CONV_NO_RELU)) && !d1.inv_scale_ptr;
+}
+
+hipError_t launch_enc_head(const ConvDesc& d0, const ConvDesc& d1, const float* img, float* out, int H, int W, hipStream_t s) {
+  if (!conv_fusable_head(d0, d1) || H < 2 || W < 2) return hipErrorInvalidValue;
+  HeadArgs a;
+  a.img = img; a.out = out; a.w11 = d0.wpk; a.b11 = d0.bias;
+  a.w12 = reinterpret_cast<const u32x4*>(d1.wpk16); a.b12 = d1.bias; a.inv12 = d1.inv_scale;
+  a.H = H; a.W = W; a.tiles_x = (W + FTW - 1) / FTW; a.tiles_y = (H + 7) / 8;
+  const size_t lds = (size_t)NPI2 * 16 + 36 * 16 * 4 + (size_t)4 * npp(8) * 16 + 640 * 16;
+  hipLaunchKernelGGL(enc_head_kernel, dim3(a.tiles_x * a.tiles_y), dim3(256), lds, s, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_dec_tail(const ConvDesc& d0, const ConvDesc& d1, const float* in, float* out, int H, int W, hipStream_t s) {
+  if (!conv_fusable_tail(d0, d1) || H < 2 || W < 2) return hipErrorInvalidValue;
+  TailArgs a;
+  a.in = in; a.out = out;
+  a.w12 = reinterpret_cast<const u32x4*>(d0.wpk16); a.b12 = d0.bias; a.inv12 = d0.inv_scale; a.inv12_ptr = d0.inv_scale_ptr;
+  a.w11 = reinterpret_cast<const u32x4*>(d1.wpk16); a.b11 = d1.bias; a.inv11 = d1.inv_scale;
+  a.H = H; a.W = W; a.up_in = (d0.flags & CONV_UP_IN) ? 1 : 0; a.inW = a.up_in ? W / 2 : W;
+  a.tiles_x = (W + FTW - 1) / FTW; a.tiles_y = (H + 7) / 8;
+  const size_t lds = ((size_t)4 * NPI2 + 640 + (size_t)4 * npp(8) + 640) * 16;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(dec_tail_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(dec_tail_kernel, dim3(a.tiles_x * a.tiles_y), dim3(256), lds, s, a);
+  return hipGetLastError();
+}
 
 size_t conv_f16_weight_bytes(int cin, int cout_pad, int taps) {
   return (size_t)((cin + 15) / 16) * taps * 4 * cout_pad * 16;

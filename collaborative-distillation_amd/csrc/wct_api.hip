@@ -59,6 +59,7 @@ struct wct_ctx {
   Module mod[2][6];
   // workspace
   DevBuf featC, featS, tmpT, wsAsm, small, foldW, foldW16, eigC, eigS[6];
+  int fuse = 1;       // 1: fused conv11+conv12+pool / conv12+conv11 kernels at the full-resolution ends of the 16x networks
   int overlap = 1;    // 1: style side on the side lane (overlaps the content side); 0: everything on the caller's stream
   int conv_mode = 1;  // 0: exact-fp32 MFMA everywhere; 1: split-f16 (f16x3) MFMA for all but the first conv
   // profiling
@@ -275,7 +276,19 @@ int encode_impl(wct_ctx* ctx, Lane& ln, int level, const float* img, int H, int 
   if (int rc = ensure(ctx, ln.actB, need)) return rc;
   const float* cur = img;
   int h = H, w = W;
-  for (size_t i = 0; i < m.layers.size(); ++i) {
+  size_t i0 = 0;
+  if (ctx->conv_mode == 1 && ctx->fuse && m.layers.size() >= 2 && conv_fusable_head(m.layers[0].d, m.layers[1].d)) {
+    // conv11 + conv12 + pool in one kernel: the 64 B/px intermediate never leaves LDS
+    const bool last = m.layers.size() == 2;
+    float* dst = last ? feat_nhwc : reinterpret_cast<float*>(ln.actB.p);
+    const double px = (double)h * w;
+    ProfScope ps(ctx, ln.stream, "enc_head_fused<3-16-16,pool>", 2.0 * 9 * (3 * 16 + 16 * 16) * px, 4.0 * (3 * px + 16 * px / 4));
+    HIPCHK(ctx, launch_enc_head(m.layers[0].d, m.layers[1].d, cur, dst, h, w, ln.stream));
+    h /= 2; w /= 2;
+    cur = dst;
+    i0 = 2;
+  }
+  for (size_t i = i0; i < m.layers.size(); ++i) {
     const auto& l = m.layers[i];
     const bool last = i + 1 == m.layers.size();
     float* dst = last ? feat_nhwc : reinterpret_cast<float*>((i & 1) ? ln.actB.p : ln.actA.p);
@@ -299,11 +312,20 @@ int decode_impl(wct_ctx* ctx, int level, const float* feat, int h, int w, const 
   if (int rc = ensure(ctx, ln.actB, need)) return rc;
   const float* cur = feat;
   int ch = h, cw = w;
-  for (size_t i = 0; i < m.layers.size(); ++i) {
+  const size_t n = m.layers.size();
+  for (size_t i = 0; i < n; ++i) {
     const auto& l = m.layers[i];
-    const bool last = i + 1 == m.layers.size();
+    const bool last = i + 1 == n;
     ConvDesc d = (i == 0 && first) ? *first : l.d;
     if (i > 0 && m.layers[i - 1].up_after) { ch *= 2; cw *= 2; }
+    if (ctx->conv_mode == 1 && ctx->fuse && i + 2 == n && conv_fusable_tail(d, m.layers[i + 1].d)) {
+      // conv12 + conv11 in one kernel: the 64 B/px intermediate never leaves LDS
+      const double px = (double)ch * cw;
+      const double in_px = (d.flags & CONV_UP_IN) ? px / 4 : px;
+      ProfScope ps(ctx, ln.stream, "dec_tail_fused<16-16-3>", 2.0 * 9 * (16 * 16 + 16 * 3) * px, 4.0 * (16 * in_px + 3 * px));
+      HIPCHK(ctx, launch_dec_tail(d, m.layers[i + 1].d, cur, img, ch, cw, ln.stream));
+      break;
+    }
     float* dst = last ? img : reinterpret_cast<float*>((i & 1) ? ln.actB.p : ln.actA.p);
     if (int rc = run_conv(ctx, ln, d, cur, dst, ch, cw)) return rc;
     cur = dst;
@@ -472,6 +494,7 @@ int wct_create(int device, wct_ctx** out) {
   c->device = device;
   if (const char* m = getenv("WCT_CONV_MODE")) c->conv_mode = (m[0] == '0' || !strcmp(m, "fp32")) ? 0 : 1;
   if (const char* m = getenv("WCT_OVERLAP")) c->overlap = m[0] != '0';
+  if (const char* m = getenv("WCT_FUSE")) c->fuse = m[0] != '0';
   bool ok = hipStreamCreateWithFlags(&c->side.stream, hipStreamNonBlocking) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess;
   for (int l = 1; l <= 5 && ok; ++l) ok = hipEventCreateWithFlags(&c->ev_style[l], hipEventDisableTiming) == hipSuccess;

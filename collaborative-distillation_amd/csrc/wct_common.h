@@ -36,6 +36,11 @@ hipError_t launch_conv3x3(const ConvDesc& d, const float* in, float* out, int H,
 
 hipError_t launch_conv3x3_f16(const ConvDesc& d, const float* in, float* out, int H, int W, hipStream_t s);
 size_t conv_f16_weight_bytes(int cin, int cout_pad, int taps);
+// fused full-resolution ends of the 16x networks (conv11+conv12+pool / conv12+conv11): see conv3x3_f16.hip
+bool conv_fusable_head(const ConvDesc& d0, const ConvDesc& d1);
+bool conv_fusable_tail(const ConvDesc& d0, const ConvDesc& d1);
+hipError_t launch_enc_head(const ConvDesc& d0, const ConvDesc& d1, const float* img, float* out, int H, int W, hipStream_t s);
+hipError_t launch_dec_tail(const ConvDesc& d0, const ConvDesc& d1, const float* in, float* out, int H, int W, hipStream_t s);
 // fp32 packed weights (device) -> scaled split-f16 packed weights + inverse scale (device scalar)
 hipError_t launch_split_pack(const float* wpk32, int cin, int cout_pad, int taps, unsigned* maxbits_dev, void* out,
                              float* inv_scale_out, hipStream_t s);

@@ -144,6 +144,23 @@ def test_unfused_reference_sequence_matches_fused(torch_cuda, wct16, golden):
         assert rel_err(fused, unfused) < 2e-5, k
 
 
+def test_fused_ends_bitwise_equal_unfused(torch_cuda, weights16x, monkeypatch):
+    """The fused conv11+conv12+pool / conv12+conv11 kernels keep the unfused kernels' arithmetic and summation
+    order, so whole-level outputs are bitwise identical with and without them (odd sizes, image-border tiles)."""
+    from wct_hip import WCT
+    torch = torch_cuda
+    g = torch.Generator(device="cuda").manual_seed(21)
+    c = torch.rand((1, 3, 203, 333), device="cuda", generator=g)
+    s = torch.rand((1, 3, 150, 170), device="cuda", generator=g)
+    outs = {}
+    for fuse in ("1", "0"):
+        monkeypatch.setenv("WCT_FUSE", fuse)
+        w = WCT(types.SimpleNamespace(mode="16x", alpha=1.0), weights=weights16x)
+        outs[fuse] = [w.encode(5, c).clone(), w.encode(2, c).clone()] + [w.style_transfer_level(k, c, s).clone() for k in (5, 3, 2)]
+    for a, b in zip(outs["1"], outs["0"]):
+        assert torch.equal(a, b)
+
+
 # --------------------------------------------------------------------------- G6 original arch, G7 config 1
 def test_g6_original_arch(torch_cuda, golden):
     """--mode original graph (C = 512/512/256/128/64: multi-group conv launches, global-memory Jacobi)."""
