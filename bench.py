@@ -73,12 +73,19 @@ def main():
         raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d bench.py --gpus %d"
                          % (args.gpus, args.gpus))
     assert torch.cuda.is_available(), "bench.py needs the MI355X (no CPU path)"
-    torch.cuda.set_device(local_rank)
+    # one rank per GPU; WCT_DIST_BACKEND=gloo lets several ranks share one GPU (used only to smoke-test the N > 1 code
+    # path on a single-GPU box -- RCCL needs one device per rank)
+    backend = os.environ.get("WCT_DIST_BACKEND", "nccl")
+    dev = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group(backend)
 
     from wct_hip import WCT, model_zoo
     weights = model_zoo.load_npz_weights(os.path.join(PKG, "weights", "16x.npz"))
@@ -193,7 +200,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "PytorchWCT/WCT.py --mode 16x, 5-level WCT, %dx%d content per GPU / %dx%d style, alpha=1, "
                                    "style-side work included, images resident in HBM" % (W, H, WS, HS),
-                       "content_total": "%dx%d" % (W * world, H), "parallelism": "content column strips x%d" % world},
+                       "content_total": "%dx%d" % (W * world, H), "parallelism": "content column strips x%d" % world, "dist_backend": (backend if world > 1 else None)},
             "roofline": roof, "passes": passes, "cpu_baseline": cpu, "kernels": profile,
         }
         print(json.dumps(line))

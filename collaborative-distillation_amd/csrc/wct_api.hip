@@ -59,6 +59,7 @@ struct wct_ctx {
   Module mod[2][6];
   // workspace
   DevBuf featC, featS, tmpT, wsAsm, small, foldW, foldW16, eigC, eigS[6];
+  int cur_level = 0, cur_h = 0, cur_w = 0;  // content feature held in featC by wct_content_encode
   int fuse = 1;       // 1: fused conv11+conv12+pool / conv12+conv11 kernels at the full-resolution ends of the 16x networks
   int overlap = 1;    // 1: style side on the side lane (overlaps the content side); 0: everything on the caller's stream
   int conv_mode = 1;  // 0: exact-fp32 MFMA everywhere; 1: split-f16 (f16x3) MFMA for all but the first conv
@@ -723,6 +724,65 @@ int wct_style_transfer_level(wct_ctx* ctx, int level, const float* content, int 
   if (int rc = fork_side(ctx)) return rc;
   if (int rc = style_side(ctx, level, style, Hs, Ws)) return rc;
   return content_side(ctx, level, content, H, W, alpha, out, Ho, Wo);
+}
+
+// ---- split form of a level, for content-sharded runs (wct_hip/sharded.py): the caller all-reduces the moments
+//      between wct_content_encode and wct_content_solve and may broadcast (M, b) before wct_content_decode.
+int wct_style_prepare(wct_ctx* ctx, const float* style, int Hs, int Ws) {
+  if (!ctx) return WCT_ERR_INVALID;
+  if (!style) return fail(ctx, WCT_ERR_INVALID, "style_prepare: NULL style");
+  if (int rc = fork_side(ctx)) return rc;
+  for (int level = 5; level >= 1; --level)
+    if (ctx->mod[WCT_KIND_ENC][level].loaded)
+      if (int rc = style_side(ctx, level, style, Hs, Ws)) return rc;
+  return WCT_OK;
+}
+
+int wct_content_encode(wct_ctx* ctx, int level, const float* content, int H, int W, int x0, int x1, double* sum,
+                       double* sumsq, int* h_out, int* w_out) {
+  if (!ctx) return WCT_ERR_INVALID;
+  if (!valid_level(level) || !content || !sum || !sumsq) return fail(ctx, WCT_ERR_INVALID, "content_encode: bad arguments");
+  Module& me = ctx->mod[WCT_KIND_ENC][level];
+  if (!me.loaded) return fail(ctx, WCT_ERR_STATE, "encoder %d not loaded", level);
+  const int C = me.layers.back().d.cout;
+  int h, w;
+  level_dims(level, H, W, h, w);
+  if (x1 < 0) x1 = w;
+  if (int rc = ensure(ctx, ctx->featC, (size_t)h * w * C * sizeof(float))) return rc;
+  float* fC = reinterpret_cast<float*>(ctx->featC.p);
+  if (int rc = encode_impl(ctx, ctx->main, level, content, H, W, fC, nullptr, nullptr)) return rc;
+  if (int rc = moments_impl(ctx, ctx->main, fC, C, h, w, x0, x1, sum, sumsq)) return rc;
+  ctx->cur_level = level; ctx->cur_h = h; ctx->cur_w = w;
+  if (h_out) *h_out = h;
+  if (w_out) *w_out = w;
+  return WCT_OK;
+}
+
+int wct_content_solve(wct_ctx* ctx, int level, double n_c, const double* sum_c, const double* sumsq_c, float alpha, double* M,
+                      double* b) {
+  if (!ctx) return WCT_ERR_INVALID;
+  if (!valid_level(level) || !sum_c || !sumsq_c || !M || !b) return fail(ctx, WCT_ERR_INVALID, "content_solve: bad arguments");
+  Module& me = ctx->mod[WCT_KIND_ENC][level];
+  if (!me.loaded) return fail(ctx, WCT_ERR_STATE, "encoder %d not loaded", level);
+  if (!ctx->eigS[level].p) return fail(ctx, WCT_ERR_STATE, "content_solve: wct_style_prepare has not run for level %d", level);
+  const int C = me.layers.back().d.cout;
+  SumsView sv;
+  if (int rc = sums_view(ctx, ctx->main, sv)) return rc;
+  if (int rc = eig_impl(ctx, ctx->main, C, n_c, sum_c, sumsq_c, 1, ctx->eigC, sv.info)) return rc;
+  HIPCHK(ctx, hipStreamWaitEvent(ctx->main.stream, ctx->ev_style[level], 0));
+  return assemble_impl(ctx, C, ctx->eigC, ctx->eigS[level], alpha, M, b);
+}
+
+int wct_content_decode(wct_ctx* ctx, int level, const double* M, const double* b, float* out, int* Ho, int* Wo) {
+  if (!ctx) return WCT_ERR_INVALID;
+  if (!valid_level(level) || !M || !b || !out) return fail(ctx, WCT_ERR_INVALID, "content_decode: bad arguments");
+  if (ctx->cur_level != level) return fail(ctx, WCT_ERR_STATE, "content_decode: wct_content_encode(level %d) has not run", level);
+  ConvDesc first;
+  if (int rc = fold_impl(ctx, level, M, b, first)) return rc;
+  if (int rc = decode_impl(ctx, level, reinterpret_cast<float*>(ctx->featC.p), ctx->cur_h, ctx->cur_w, &first, out)) return rc;
+  if (Ho) *Ho = ctx->cur_h << (level - 1);
+  if (Wo) *Wo = ctx->cur_w << (level - 1);
+  return WCT_OK;
 }
 
 int wct_stylize(wct_ctx* ctx, const float* content, int H, int W, const float* style, int Hs, int Ws, float alpha,

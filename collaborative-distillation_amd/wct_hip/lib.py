@@ -20,6 +20,7 @@ SYMBOLS = [
     "wct_version", "wct_create", "wct_destroy", "wct_last_error", "wct_set_stream", "wct_sync",
     "wct_load_module", "wct_feature_shape", "wct_encode", "wct_decode", "wct_moments", "wct_solve",
     "wct_apply", "wct_transform", "wct_decode_affine", "wct_style_transfer_level", "wct_stylize",
+    "wct_style_prepare", "wct_content_encode", "wct_content_solve", "wct_content_decode",
     "wct_workspace_bytes", "wct_reserve", "wct_set_conv_mode", "wct_set_overlap", "wct_profile_enable", "wct_profile_reset", "wct_profile_read",
 ]
 
@@ -74,6 +75,10 @@ def load() -> ctypes.CDLL:
     lib.wct_decode_affine.argtypes = [c_void_p, c_int, vp, c_int, c_int, vp, vp, vp]
     lib.wct_style_transfer_level.argtypes = [c_void_p, c_int, vp, c_int, c_int, vp, c_int, c_int, c_float, vp, ip, ip]
     lib.wct_stylize.argtypes = [c_void_p, vp, c_int, c_int, vp, c_int, c_int, c_float, c_int, vp, ip, ip]
+    lib.wct_style_prepare.argtypes = [c_void_p, vp, c_int, c_int]
+    lib.wct_content_encode.argtypes = [c_void_p, c_int, vp, c_int, c_int, c_int, c_int, vp, vp, ip, ip]
+    lib.wct_content_solve.argtypes = [c_void_p, c_int, c_double, vp, vp, c_float, vp, vp]
+    lib.wct_content_decode.argtypes = [c_void_p, c_int, vp, vp, vp, ip, ip]
     lib.wct_workspace_bytes.argtypes = [c_void_p, c_int, c_int, c_int, c_int]
     lib.wct_workspace_bytes.restype = c_size_t
     lib.wct_reserve.argtypes = [c_void_p, c_int, c_int, c_int, c_int]

@@ -65,42 +65,44 @@ class ShardedStylizer:
     @torch.no_grad()
     def stylize_strip(self, content_ext: torch.Tensor, style: torch.Tensor) -> torch.Tensor:
         """content_ext: [3, H, x1-x0] columns `input_columns()` of the content; style: [3, Hs, Ws].
-        Returns this rank's owned columns of the stylised image, [1, 3, H', own_w'] (H' = 16*floor(H/16))."""
+        Returns this rank's owned columns of the stylised image, [1, 3, H', own_w'] (H' = 16*floor(H/16)).
+
+        Engine interface (wct_hip.WCT on the GPU; tests supply a CPU checker with the same four methods):
+          style_prepare(style)                       style side of all levels (GPU: side stream, overlaps the content)
+          content_encode(L, img, f0, f1) -> h, w, sum, sumsq    encoder + raw moments over owned feature columns
+          content_solve(L, n, sum, sumsq, alpha) -> M, b
+          content_decode(L, M, b, H, W) -> image     decoder with (M, b) folded into its first conv
+        """
         e, dist = self.e, self.dist
         img = content_ext if content_ext.dim() == 4 else content_ext[None]
         W_cur = self.W                       # width of the (virtual) full image at the current level
         own = self.own
         lo, hi = ext_bounds(own, W_cur, CUM_HALO[5])
         assert img.shape[-1] == hi - lo, "expected columns [%d,%d) of the content" % (lo, hi)
+        e.style_prepare(style)               # replicated: the style image is small
         for L in (5, 4, 3, 2, 1):
             sh = L - 1
             # crop the running image to this level's extended strip
             nlo, nhi = ext_bounds(own, W_cur, CUM_HALO[L])
             img = img[..., nlo - lo:nhi - lo].contiguous()
             lo, hi = nlo, nhi
-            # style side (replicated) and content side
-            sF = e.encode(L, style, layout="nhwc")
-            n_s, sum_s, sumsq_s = e.moments(sF)
-            cF = e.encode(L, img, layout="nhwc")
-            h, w_ext = int(cF.shape[1]), int(cF.shape[2])
-            f0 = (own[0] - lo) >> sh                                  # owned feature columns
-            f1 = w_ext if own[1] >= W_cur else (own[1] - lo) >> sh    # last strip: to the (floored) end
-            _, sum_c, sumsq_c = e.moments(cF, f0, f1)
+            H_in, W_in = int(img.shape[-2]), int(img.shape[-1])
+            f0 = (own[0] - lo) >> sh                                   # owned feature columns
+            f1 = -1 if own[1] >= W_cur else (own[1] - lo) >> sh        # last strip: to the (floored) end
+            h, w_ext, sum_c, sumsq_c = e.content_encode(L, img, f0, f1)
             C = int(sum_c.numel())
             packed = torch.cat([sum_c.reshape(-1), sumsq_c.reshape(-1)])
             if self.world > 1:
-                dist.all_reduce(packed)                               # SUM, fp64
-            n_c = float(h * (W_cur >> sh))                            # feature pixels of the whole image
-            sum_c, sumsq_c = packed[:C], packed[C:].reshape(C, C)
+                dist.all_reduce(packed)                                # SUM, fp64, C*C + C values
+            n_c = float(h * (W_cur >> sh))                             # feature pixels of the whole image
             Mb = torch.empty(C * C + C, dtype=torch.float64, device=packed.device)
             if self.rank == 0:
-                M, b = e.solve(n_c, sum_c, sumsq_c, n_s, sum_s, sumsq_s, self.alpha)
+                M, b = e.content_solve(L, n_c, packed[:C], packed[C:].reshape(C, C), self.alpha)
                 Mb[:C * C] = M.reshape(-1)
                 Mb[C * C:] = b
             if self.world > 1:
-                dist.broadcast(Mb, src=0)
-            M, b = Mb[:C * C].reshape(C, C), Mb[C * C:]
-            img = e.decode_affine(L, cF, M, b)                        # [1,3,h<<sh, w_ext<<sh]
+                dist.broadcast(Mb, src=0)                              # the colouring map, identical on every rank
+            img = e.content_decode(L, Mb[:C * C].reshape(C, C), Mb[C * C:], H_in, W_in)   # [1,3,h<<sh, w_ext<<sh]
             # floor-mode pooling may have dropped trailing columns/rows of the full image
             W_cur = (W_cur >> sh) << sh
             hi = lo + int(img.shape[-1])

@@ -258,6 +258,50 @@ class WCT:
         self._chk(self._lib.wct_decode_affine(self._ctx, level, f.data_ptr(), h, w, M.data_ptr(), b.data_ptr(), out.data_ptr()))
         return out
 
+    # ------------------------------------------------------------------ split level (content-sharded runs)
+    @torch.no_grad()
+    def style_prepare(self, styleImg: torch.Tensor):
+        """Style side of all five levels on the context's side stream (overlaps whatever follows)."""
+        s = self._img(styleImg)
+        self._style_keep = s   # the side stream reads it asynchronously
+        self._stream()
+        self._chk(self._lib.wct_style_prepare(self._ctx, s.data_ptr(), int(s.shape[1]), int(s.shape[2])))
+
+    @torch.no_grad()
+    def content_encode(self, level: int, img: torch.Tensor, x0: int = 0, x1: int = -1):
+        """cF = encoder(img), kept inside the context; returns (h, w, sum[C], sumsq[C,C]) over feature columns [x0,x1)."""
+        x = self._img(img)
+        self._content_keep = x
+        H, W = int(x.shape[1]), int(x.shape[2])
+        C = model_zoo.feature_channels(self.mode, level)
+        s = torch.empty(C, device=x.device, dtype=torch.float64)
+        ss = torch.empty(C, C, device=x.device, dtype=torch.float64)
+        h, w = c_int(), c_int()
+        self._stream()
+        self._chk(self._lib.wct_content_encode(self._ctx, level, x.data_ptr(), H, W, x0, x1, s.data_ptr(), ss.data_ptr(), byref(h), byref(w)))
+        return h.value, w.value, s, ss
+
+    @torch.no_grad()
+    def content_solve(self, level: int, n_c: float, sum_c: torch.Tensor, sumsq_c: torch.Tensor, alpha: Optional[float] = None):
+        alpha = self.alpha if alpha is None else float(alpha)
+        C = int(sum_c.numel())
+        M = torch.empty(C, C, device=sum_c.device, dtype=torch.float64)
+        b = torch.empty(C, device=sum_c.device, dtype=torch.float64)
+        self._stream()
+        self._chk(self._lib.wct_content_solve(self._ctx, level, float(n_c), sum_c.data_ptr(), sumsq_c.data_ptr(), alpha, M.data_ptr(), b.data_ptr()))
+        return M, b
+
+    @torch.no_grad()
+    def content_decode(self, level: int, M: torch.Tensor, b: torch.Tensor, H: int, W: int) -> torch.Tensor:
+        """H, W: size of the image wct.content_encode() was given (the output is floor-shrunk like the reference's)."""
+        _, h, w = self.feature_shape(level, H, W)
+        out = torch.empty((1, 3, h << (level - 1), w << (level - 1)), device=M.device, dtype=torch.float32)
+        ho, wo = c_int(), c_int()
+        self._stream()
+        self._chk(self._lib.wct_content_decode(self._ctx, level, M.data_ptr(), b.data_ptr(), out.data_ptr(), byref(ho), byref(wo)))
+        assert (ho.value, wo.value) == tuple(out.shape[2:])
+        return out
+
     # ------------------------------------------------------------------ fused level / cascade
     @torch.no_grad()
     def style_transfer_level(self, level: int, contentImg: torch.Tensor, styleImg: torch.Tensor,

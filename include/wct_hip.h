@@ -110,6 +110,21 @@ int wct_decode_affine(wct_ctx* ctx, int level, const float* feat, int h, int w, 
 int wct_style_transfer_level(wct_ctx* ctx, int level, const float* content, int H, int W, const float* style,
                              int Hs, int Ws, float alpha, float* out, int* Ho, int* Wo);
 
+/* Split form of one level for content-sharded (multi-GPU) runs -- the same work as wct_style_transfer_level, cut where
+ * a sharded run exchanges data (wct_hip/sharded.py):
+ *   wct_style_prepare   style side of all loaded levels (encode, moments, cov^1/2), on the context's side stream
+ *   wct_content_encode  cF = encoder(content) kept inside the context + raw moments over feature columns [x0,x1)
+ *                       (x1 < 0: to the end) into sum[C], sumsq[C*C] (device f64) -> caller all-reduces them
+ *   wct_content_solve   global (n, sum, sumsq) -> M [C*C], b [C] (device f64)  -> caller may broadcast them
+ *   wct_content_decode  decoder(M cF + b) with M, b folded into the first conv
+ * Together they replace styleTransfer() (WCT.py:98-106). */
+int wct_style_prepare(wct_ctx* ctx, const float* style, int Hs, int Ws);
+int wct_content_encode(wct_ctx* ctx, int level, const float* content, int H, int W, int x0, int x1, double* sum,
+                       double* sumsq, int* h, int* w);
+int wct_content_solve(wct_ctx* ctx, int level, double n_c, const double* sum_c, const double* sumsq_c, float alpha,
+                      double* M, double* b);
+int wct_content_decode(wct_ctx* ctx, int level, const double* M, const double* b, float* out, int* Ho, int* Wo);
+
 /* replaces the cascade of WCT.py:120-125 (levels 5..1, num_run times).  out must hold 3*H*W floats. */
 int wct_stylize(wct_ctx* ctx, const float* content, int H, int W, const float* style, int Hs, int Ws, float alpha,
                 int num_run, float* out, int* Ho, int* Wo);

@@ -19,39 +19,47 @@ from tests.conftest import PKG, REPO
 
 
 class OracleEngine:
-    """CPU stand-in with the engine interface of wct_hip.WCT (test infrastructure only)."""
+    """CPU stand-in with the engine interface wct_hip.sharded expects of wct_hip.WCT (test infrastructure only)."""
 
     def __init__(self, weights):
         from oracle import wct_oracle
         self.o = wct_oracle
         self.m = wct_oracle.Modules("16x", weights)
+        self.style_moments = {}
+        self.cF = None
 
-    def encode(self, level, img, layout="nhwc"):
-        x = img[0] if img.dim() == 4 else img
-        f = self.m.encode(level, x.numpy())
-        return torch.from_numpy(np.ascontiguousarray(f.transpose(1, 2, 0)))[None]
+    @staticmethod
+    def _raw(f, x0=0, x1=None):
+        f = f.astype(np.float64)
+        x1 = f.shape[2] if x1 is None or x1 < 0 else x1
+        X = f[:, :, x0:x1].reshape(f.shape[0], -1)
+        return float(X.shape[1]), X.sum(1), X @ X.T
 
-    def moments(self, feat, x0=0, x1=None):
-        f = feat[0].numpy().astype(np.float64)
-        x1 = f.shape[1] if x1 is None else x1
-        X = f[:, x0:x1].reshape(-1, f.shape[2])
-        return float(X.shape[0]), torch.from_numpy(X.sum(0)), torch.from_numpy(X.T @ X)
+    def style_prepare(self, style):
+        s = (style[0] if style.dim() == 4 else style).numpy()
+        for L in range(1, 6):
+            self.style_moments[L] = self._raw(self.m.encode(L, s))
 
-    def solve(self, n_c, sum_c, sumsq_c, n_s, sum_s, sumsq_s, alpha=1.0):
+    def content_encode(self, level, img, x0=0, x1=-1):
+        x = (img[0] if img.dim() == 4 else img).numpy()
+        self.cF = self.m.encode(level, x)
+        n, s, ss = self._raw(self.cF, x0, x1)
+        return self.cF.shape[1], self.cF.shape[2], torch.from_numpy(s), torch.from_numpy(ss)
+
+    def content_solve(self, level, n_c, sum_c, sumsq_c, alpha=1.0):
         def mc(n, s, ss):
-            s, ss = s.numpy(), ss.numpy()
             mu = s / n
             return mu, (ss - n * np.outer(mu, mu)) / (n - 1)
-        mu_c, cov_c = mc(n_c, sum_c, sumsq_c)
-        mu_s, cov_s = mc(n_s, sum_s, sumsq_s)
+        mu_c, cov_c = mc(n_c, sum_c.numpy(), sumsq_c.numpy())
+        n_s, s_s, ss_s = self.style_moments[level]
+        mu_s, cov_s = mc(n_s, s_s, ss_s)
         M, b = self.o.affine_from_moments(mu_c, cov_c, mu_s, cov_s, alpha)
         return torch.from_numpy(M), torch.from_numpy(b)
 
-    def decode_affine(self, level, feat, M, b):
-        f = feat[0].numpy().astype(np.float64)
-        y = (f @ M.numpy().T + b.numpy()).astype(np.float32)
-        img = self.m.decode(level, np.ascontiguousarray(y.transpose(2, 0, 1)))
-        return torch.from_numpy(img)[None]
+    def content_decode(self, level, M, b, H, W):
+        f = self.cF.astype(np.float64)
+        y = (np.einsum("ab,bhw->ahw", M.numpy(), f) + b.numpy()[:, None, None]).astype(np.float32)
+        return torch.from_numpy(self.m.decode(level, y))[None]
 
 
 def _worker(rank, world, port, H, W, out_path):
