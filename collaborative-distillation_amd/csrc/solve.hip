@@ -97,8 +97,6 @@ __global__ void cov_kernel(int C, double n, const double* sum, const double* sum
 // of this path (cond 1e1..1e5 on the live block) take 10..18 iterations to 1e-14 (numpy prototype matched eigh to
 // 1e-13).  Dead channels (variance at round-off level) are replaced by an identity block and zeroed in the
 // result, which is the pseudo-inverse square root the Jacobi path forms by dropping them.
-// Every iterate is a polynomial in A, hence symmetric: operands are read transposed ("k-major") so that both
-// MFMA operands are coalesced 128-B runs.
 // The launch schedule is fixed (no host round trip): stage kernels of iteration k return at once when the
 // residual of iteration k-1 is already below NS_TOL.  If the budget runs out (singular or very ill-conditioned
 // matrix, e.g. fewer pixels than channels) ok stays 0 and the Jacobi path below takes over (C <= 128: one gated
@@ -149,16 +147,18 @@ __global__ void ns_fill_kernel(const double* res, int C, int Cp, NsWs w) {
   w.Z[0][e] = r == c ? 1.0 : 0.0;
 }
 
-// one 16x16 output tile per wave, 2x2 tiles per workgroup; operands symmetric -> P[i][k] is read as P[k][i]
+// one 16x16 output tile per wave, 2x2 tiles per workgroup: D = P Q with the TRUE row-major operands.  (Reading P
+// transposed because "every iterate is symmetric" is tempting -- both operands would be coalesced -- but it makes the
+// iteration unstable: the antisymmetric part of the round-off is amplified and it diverges for cond >~ 3e3.)
 __device__ __forceinline__ f64x4 tile_gemm(const double* P, const double* Q, int Cp, int i0, int j0, int lane) {
   const int li = lane & 15, kk = lane >> 4;
   f64x4 acc = f64x4{0., 0., 0., 0.};
-  const double* pp = P + (size_t)kk * Cp + i0 + li;
+  const double* pp = P + (size_t)(i0 + li) * Cp + kk;
   const double* qq = Q + (size_t)kk * Cp + j0 + li;
   for (int k0 = 0; k0 < Cp; k0 += 16) {
     double a[4], b[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) { a[u] = pp[(size_t)(k0 + 4 * u) * Cp]; b[u] = qq[(size_t)(k0 + 4 * u) * Cp]; }
+    for (int u = 0; u < 4; ++u) { a[u] = pp[k0 + 4 * u]; b[u] = qq[(size_t)(k0 + 4 * u) * Cp]; }
 #pragma unroll
     for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], acc, 0, 0, 0);
   }
