@@ -38,6 +38,29 @@ PEAK_HBM_GBS = 8000.0      # spec; 6290 measured copy
 PEAK_F16_MFMA_TF = 2500.0  # dense f16/bf16 MFMA (the f16x3 kernels issue 3 MFMAs per algorithmic product)
 
 
+def pmc_traffic(family):
+    """HBM bytes per launch of the kernel behind a profile family, from the committed rocprofv3 PMC passes
+    (profiles/hbm_traffic_latest.json, made by tools/pmc_summary.py; counters cannot be read from inside this process)."""
+    import re
+    path = os.path.join(REPO, "profiles", "hbm_traffic_latest.json")
+    if not os.path.exists(path):
+        return None
+    ks = json.load(open(path))["kernels"]
+    m = re.match(r"conv3x3_f16x3<co=(\d+)(,pool)?(,out3)?>", family)
+    if not m:
+        return None
+    co, pool, out3 = int(m.group(1)), bool(m.group(2)), bool(m.group(3))
+    if co == 16:
+        name = "void conv3x3_f16_c16_kernel<%s, %s>(F16Args)" % ("true" if pool else "false", "true" if out3 else "false")
+    else:
+        name = "void conv3x3_f16_kernel<%d, %s, %d>(F16Args)" % (co // 32, "true" if pool else "false", 16 if co == 128 else 8)
+    e = ks.get(name)
+    if not e:
+        return None
+    return {"hbm_bytes_per_launch": round((e["read_MB_per_launch"] + e["write_MB_per_launch"]) * 1e6), "source": "profiles/hbm_traffic_latest.json",
+            "pmc_avg_launch_us": e["avg_us"]}
+
+
 def cpu_baseline(weights):
     """The oracle (a CPU port of the reference's op sequence: fp32 convs, fp64 two-GEMM WCT with SVD) on a bounded
     sample of the same workload.  This is the ONLY place bench.py touches oracle/."""
@@ -168,6 +191,7 @@ def main():
             roof = {"kernel": d["name"], "bound": "mfma", "achieved": round(tf, 2), "peak": round(peak_tf, 1), "unit": "TFLOP/s",
                     "frac": round(tf / peak_tf, 4), "traffic": None,
                     "peak_note": "2.5 PF dense f16 MFMA / 3 split terms" if f16 else "fp32 MFMA"}
+        roof["traffic"] = pmc_traffic(d["name"])
         roof.update({"avg_launch_ms": round(d["ms"] / d["launches"], 4), "share_of_kernel_time": round(d["ms"] / tot, 3),
                      "algo_flop_per_launch": d["flops"] / d["launches"], "algo_bytes_per_launch": d["bytes"] / d["launches"]})
         # relu4_1 encode pass on the 4K content (north_star's named pass)
