@@ -371,12 +371,49 @@ constexpr int I2W = FTW + 4, I2H = 8 + 4;       // 36 x 12: input tile of the fi
 constexpr int NPI2 = I2W * I2H;                 // 432 (a multiple of 16)
 constexpr int NGRP = (nph(8) + 15) / 16;        // 22 groups of 16 halo pixels
 
-struct HeadArgs {   // conv11 (3->16, fp32 MFMA, conv0 folded) + ReLU -> conv12 (16->16, f16x3) + ReLU -> 2x2 max-pool
+struct HeadArgs {   // conv11 (3->16, conv0 folded) + ReLU -> conv12 (16->16) + ReLU -> 2x2 max-pool, both f16x3
   const float* img; float* out;
-  const float* w11; const float* b11;           // in3 packing [tap][4][16], bias [16]
+  const u32x4* w11; const float* b11; float inv11;   // [kb][hi/lo][kq][16 couts] x 8 halfs (K layout below)
   const u32x4* w12; const float* b12; float inv12;
   int H, W, tiles_x, tiles_y;
 };
+
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+constexpr int IMG_E = NPI2 + 4;   // 8-byte pixels per plane; the zeroed tail absorbs the "4th pixel" over-read of the last row
+
+// next tile's 36 x 12 x 3 image window -> 6 registers per thread (unconditional, clamped)
+__device__ __forceinline__ void head_fetch(const HeadArgs& a, float (&r)[2][3], int tile, int tid) {
+  const int ty0 = (tile / a.tiles_x) * 8, tx0 = (tile % a.tiles_x) * FTW;
+  const size_t plane = (size_t)a.H * a.W;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    int e = tid + 256 * k;
+    e = e < NPI2 ? e : NPI2 - 1;
+    const int py = e / I2W, px = e - py * I2W;
+    const size_t off = (size_t)reflect_clamp(ty0 - 2 + py, a.H) * a.W + reflect_clamp(tx0 - 2 + px, a.W);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) r[k][c] = a.img[c * plane + off];
+  }
+}
+
+__device__ __forceinline__ void head_commit(const float (&r)[2][3], u32x2* imgH, u32x2* imgL, int tid) {
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int e = tid + 256 * k;
+    if (e < NPI2) {
+      f16x4 h = {0, 0, 0, 0}, l = {0, 0, 0, 0};
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float x = fminf(fmaxf(r[k][c], -65504.f), 65504.f);
+        h[c] = (_Float16)x;
+        l[c] = (_Float16)(x - (float)h[c]);
+      }
+      imgH[e] = __builtin_bit_cast(u32x2, h);
+      imgL[e] = __builtin_bit_cast(u32x2, l);
+    }
+  }
+}
 
 __device__ __forceinline__ void store_split4(u32x4* planes, int npp, int pix, int kq, const f32x4& v) {
   // 4 consecutive channels 4kq..4kq+3 of halo pixel `pix` -> 8 bytes in the hi plane and 8 in the lo plane
@@ -419,71 +456,112 @@ __device__ __forceinline__ void c16_compute(const u32x4* act, const u32x4* wgt, 
   }
 }
 
-__global__ __launch_bounds__(256) void enc_head_kernel(HeadArgs a) {
+// Persistent: a workgroup walks tiles v, v + grid, ...; the image window of the NEXT tile is fetched into registers
+// while the current tile is on the matrix cores and written to LDS behind conv12, conv12's weights are staged once.
+// conv11 as a 16x16x32 MFMA pair: the K = 27 (tap, channel) products are laid out as 8-half slots
+//   slot s = 4 kb + kq  ->  image row dy = s >> 1, pixels 2 (s & 1) + {0, 1}, 4 channels each (RGB0)
+// so that a lane's B operand is 16 contiguous bytes of the RGB0 f16 tile (ds_read2_b64); the 4th pixel / 4th channel /
+// 4th row slots carry zero weights.  (fp32 MFMA for this layer cost 9 x 32 issue cycles per 16 pixels, this 6 x 16.)
+__global__ __launch_bounds__(256, 4) void enc_head_kernel(HeadArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NPP = npp(8), NPH = nph(8);
-  f32x4* imgT = reinterpret_cast<f32x4*>(smem);               // [432] (c0, c1, c2, 0)
-  float* w11 = reinterpret_cast<float*>(imgT + NPI2);          // [36][16]
-  u32x4* act = reinterpret_cast<u32x4*>(w11 + 36 * 16);        // [4][NPP]
+  u32x2* imgH = reinterpret_cast<u32x2*>(smem);                // [IMG_E] RGB0 hi
+  u32x2* imgL = imgH + IMG_E;                                  // [IMG_E] RGB0 lo
+  u32x4* act = reinterpret_cast<u32x4*>(imgL + IMG_E);         // [4][NPP]
   u32x4* wgt = act + 4 * NPP;                                  // [10][2][2][16]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, kq = lane >> 4;
-  const int tile = xcd_swizzle(blockIdx.x, a.tiles_x * a.tiles_y);
-  const int ty0 = (tile / a.tiles_x) * 8, tx0 = (tile % a.tiles_x) * FTW;
-  const size_t plane = (size_t)a.H * a.W;
-  for (int e = tid; e < NPI2; e += 256) {
-    const int py = e / I2W, px = e - py * I2W;
-    const int gy = reflect_clamp(ty0 - 2 + py, a.H), gx = reflect_clamp(tx0 - 2 + px, a.W);
-    const size_t off = (size_t)gy * a.W + gx;
-    imgT[e] = f32x4{a.img[off], a.img[plane + off], a.img[2 * plane + off], 0.f};
-  }
-  for (int e = tid; e < 36 * 16; e += 256) w11[e] = a.w11[e];
+  const int ntiles = a.tiles_x * a.tiles_y;
   for (int e = tid; e < 40 * 16; e += 256) wgt[e] = a.w12[e];
-  __syncthreads();
-  // ---- conv11 on the 340 halo pixels (fp32 MFMA, the arithmetic of conv3x3_kernel<IN3>), split into the planes
-  const float* imgF = reinterpret_cast<const float*>(imgT);
+  if (tid < 4) { imgH[NPI2 + tid] = u32x2{0u, 0u}; imgL[NPI2 + tid] = u32x2{0u, 0u}; }
+  f16x8 a11[2][2];
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+    for (int hl = 0; hl < 2; ++hl) a11[kb][hl] = __builtin_bit_cast(f16x8, a.w11[((kb * 2 + hl) * 4 + kq) * 16 + li]);
   const f32x4 bias11 = *reinterpret_cast<const f32x4*>(a.b11 + 4 * kq);
-  for (int g = wave; g < NGRP; g += 4) {
-    const int pixr = g * 16 + li, pix = pixr < NPH ? pixr : NPH - 1;
-    const int py = pix / FHW, px = pix - py * FHW;
-    const int iy = reflect_clamp(ty0 - 1 + py, a.H) - (ty0 - 2), ix = reflect_clamp(tx0 - 1 + px, a.W) - (tx0 - 2);
-    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      const int dy = tap / 3, dx = tap - dy * 3;
-      const float bv = imgF[((iy - 1 + dy) * I2W + ix - 1 + dx) * 4 + kq];
-      const float av = w11[(tap * 4 + kq) * 16 + li];
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
-    }
-    f32x4 v = acc + bias11;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-    if (pixr < NPH) store_split4(act, NPP, pix, kq, v);
-  }
-  __syncthreads();
-  // ---- conv12 + ReLU + 2x2 max-pool (the arithmetic of conv3x3_f16_c16_kernel<POOL>)
-  f32x4 acc[2][2];
-#pragma unroll
-  for (int r = 0; r < 2; ++r)
-#pragma unroll
-    for (int h = 0; h < 2; ++h) acc[r][h] = f32x4{0.f, 0.f, 0.f, 0.f};
-  c16_compute(act, wgt, wave, li, kq, acc);
-  const int co = 4 * kq;
-  const f32x4 bias = *reinterpret_cast<const f32x4*>(a.b12 + co);
+  const f32x4 bias12 = *reinterpret_cast<const f32x4*>(a.b12 + 4 * kq);
   const int Hp = a.H >> 1, Wp = a.W >> 1;
+  // B-operand slot of this lane in the two K blocks
+  int srow[2], scol[2];
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    const int gx = tx0 + h * 16 + li;
-    f32x4 m;
+  for (int kb = 0; kb < 2; ++kb) {
+    const int s = kb * 4 + kq;
+    srow[kb] = (s >> 1) > 2 ? 2 : (s >> 1);
+    scol[kb] = 2 * (s & 1);
+  }
+
+  float pxr[2][3];
+  int v = blockIdx.x;
+  if (v < ntiles) {
+    head_fetch(a, pxr, xcd_swizzle(v, ntiles), tid);
+    head_commit(pxr, imgH, imgL, tid);
+  }
+  for (; v < ntiles; v += gridDim.x) {
+    const int tile = xcd_swizzle(v, ntiles);
+    const int ty0 = (tile / a.tiles_x) * 8, tx0 = (tile % a.tiles_x) * FTW;
+    __syncthreads();   // image window of this tile is in LDS; every wave is done with the previous tile's planes
+    const int vn = v + gridDim.x;
+    if (vn < ntiles) head_fetch(a, pxr, xcd_swizzle(vn, ntiles), tid);
+    // ---- conv11 on the 340 halo pixels, two 16-pixel groups in flight per wave
+#pragma unroll 1
+    for (int i = 0; i < 6; i += 2) {
+      f32x4 acc[2];
+      int pixs[2];
+      bool ok[2];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      float v = fmaxf(acc[0][h][r], acc[1][h][r]);
-      v = fmaxf(v, __shfl_xor(v, 1));
-      v = v * a.inv12 + bias[r];
-      m[r] = fmaxf(v, 0.f);
+      for (int u = 0; u < 2; ++u) {
+        const int g = wave + 4 * (i + u);
+        const int pixr = g * 16 + li, pix = pixr < NPH ? pixr : NPH - 1;
+        ok[u] = pixr < NPH;
+        pixs[u] = pix;
+        const int py = pix / FHW, px = pix - py * FHW;
+        const int iy = reflect_clamp(ty0 - 1 + py, a.H) - (ty0 - 2), ix = reflect_clamp(tx0 - 1 + px, a.W) - (tx0 - 2);
+        const int base = (iy - 1) * I2W + ix - 1;
+        acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+          const int e0 = base + srow[kb] * I2W + scol[kb];
+          const u32x2 h0 = imgH[e0], h1 = imgH[e0 + 1], l0 = imgL[e0], l1 = imgL[e0 + 1];
+          const f16x8 bh = __builtin_bit_cast(f16x8, u32x4{h0[0], h0[1], h1[0], h1[1]});
+          const f16x8 bl = __builtin_bit_cast(f16x8, u32x4{l0[0], l0[1], l1[0], l1[1]});
+          acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a11[kb][0], bh, acc[u], 0, 0, 0);
+          acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a11[kb][0], bl, acc[u], 0, 0, 0);
+          acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a11[kb][1], bh, acc[u], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        f32x4 x;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) x[r] = fmaxf(acc[u][r] * a.inv11 + bias11[r], 0.f);
+        if (ok[u]) store_split4(act, NPP, pixs[u], kq, x);
+      }
     }
-    const int oy = (ty0 + wave * 2) >> 1, ox = gx >> 1;
-    if (!(li & 1) && oy < Hp && ox < Wp) *reinterpret_cast<f32x4*>(a.out + ((size_t)oy * Wp + ox) * 16 + co) = m;
+    __syncthreads();
+    // ---- conv12 + ReLU + 2x2 max-pool (the arithmetic of conv3x3_f16_c16_kernel<POOL>)
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) acc[r][h] = f32x4{0.f, 0.f, 0.f, 0.f};
+    c16_compute(act, wgt, wave, li, kq, acc);
+    const int co = 4 * kq;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int gx = tx0 + h * 16 + li;
+      f32x4 m;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float x = fmaxf(acc[0][h][r], acc[1][h][r]);
+        x = fmaxf(x, __shfl_xor(x, 1));
+        x = x * a.inv12 + bias12[r];
+        m[r] = fmaxf(x, 0.f);
+      }
+      const int oy = (ty0 + wave * 2) >> 1, ox = gx >> 1;
+      if (!(li & 1) && oy < Hp && ox < Wp) *reinterpret_cast<f32x4*>(a.out + ((size_t)oy * Wp + ox) * 16 + co) = m;
+    }
+    if (vn < ntiles) head_commit(pxr, imgH, imgL, tid);   // conv11 of this tile is behind the barrier above
   }
 }
 
@@ -642,7 +720,7 @@ __global__ void split_pack_kernel(const float* wpk32, int chunks, int cout_pad, 
 
 
 bool conv_fusable_head(const ConvDesc& d0, const ConvDesc& d1) {
-  return (d0.flags & CONV_IN_NCHW3) && !(d0.flags & (CONV_POOL_OUT | CONV_NO_RELU)) && d0.cout == 16 && d0.cout_pad == 16 &&
+  return (d0.flags & CONV_IN_NCHW3) && !(d0.flags & (CONV_POOL_OUT | CONV_NO_RELU)) && d0.cout == 16 && d0.cout_pad == 16 && d0.wpk16 &&
          d1.cin == 16 && d1.cout == 16 && d1.cout_pad == 16 && (d1.flags & CONV_POOL_OUT) && !(d1.flags & (CONV_UP_IN | CONV_NO_RELU)) &&
          d1.wpk16 && !d1.inv_scale_ptr;
 }
@@ -653,14 +731,25 @@ bool conv_fusable_tail(const ConvDesc& d0, const ConvDesc& d1) {
          !(d1.flags & (CONV_UP_IN | CONV_NO_RELU)) && !d1.inv_scale_ptr;
 }
 
+int num_cus() {
+  static int n = [] {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v < 1) v = 256;
+    return v;
+  }();
+  return n;
+}
+
 hipError_t launch_enc_head(const ConvDesc& d0, const ConvDesc& d1, const float* img, float* out, int H, int W, hipStream_t s) {
   if (!conv_fusable_head(d0, d1) || H < 2 || W < 2) return hipErrorInvalidValue;
   HeadArgs a;
-  a.img = img; a.out = out; a.w11 = d0.wpk; a.b11 = d0.bias;
+  a.img = img; a.out = out;
+  a.w11 = reinterpret_cast<const u32x4*>(d0.wpk16); a.b11 = d0.bias; a.inv11 = d0.inv_scale;
   a.w12 = reinterpret_cast<const u32x4*>(d1.wpk16); a.b12 = d1.bias; a.inv12 = d1.inv_scale;
   a.H = H; a.W = W; a.tiles_x = (W + FTW - 1) / FTW; a.tiles_y = (H + 7) / 8;
-  const size_t lds = (size_t)NPI2 * 16 + 36 * 16 * 4 + (size_t)4 * npp(8) * 16 + 640 * 16;
-  hipLaunchKernelGGL(enc_head_kernel, dim3(a.tiles_x * a.tiles_y), dim3(256), lds, s, a);
+  const size_t lds = (size_t)2 * IMG_E * 8 + (size_t)4 * npp(8) * 16 + 640 * 16;   // 39.7 KB: 4 workgroups per CU
+  const int ntiles = a.tiles_x * a.tiles_y, grid = ntiles < 4 * num_cus() ? ntiles : 4 * num_cus();
+  hipLaunchKernelGGL(enc_head_kernel, dim3(grid), dim3(256), lds, s, a);
   return hipGetLastError();
 }
 

@@ -230,6 +230,30 @@ float pack_weights_f16(const float* w, int cout, int cin, int cout_pad, int taps
   return std::ldexp(1.f, -ex);
 }
 
+// split-f16 packing of the 3-channel first conv for the fused encoder head (conv3x3_f16.hip, enc_head_kernel):
+// K = 64 in 8-half slots, slot s = 4 kb + kq -> image row dy = s >> 1, pixels 2 (s & 1) + {0, 1}, channels RGB0;
+// layout [kb][hi/lo][kq][16 couts] x 8 halfs.  in3: the fp32 packing [tap][4][16] (conv0 already folded).  Returns 2^-e.
+float pack_head_f16(const std::vector<float>& in3, std::vector<_Float16>& out) {
+  float mx = 0.f;
+  for (float x : in3) mx = std::max(mx, std::fabs(x));
+  int ex = 0;
+  if (mx > 0.f && std::isfinite(mx)) { (void)std::frexp(mx, &ex); ex = 9 - ex; }
+  const float scale = std::ldexp(1.f, ex);
+  out.assign((size_t)2 * 2 * 4 * 16 * 8, (_Float16)0.f);
+  for (int kb = 0; kb < 2; ++kb)
+    for (int kq = 0; kq < 4; ++kq)
+      for (int o = 0; o < 16; ++o)
+        for (int j = 0; j < 8; ++j) {
+          const int s = kb * 4 + kq, dy = s >> 1, px = 2 * (s & 1) + (j >> 2), ch = j & 3;
+          if (dy > 2 || px > 2 || ch > 2) continue;
+          const float x = in3[((size_t)(dy * 3 + px) * 4 + ch) * 16 + o] * scale;
+          const _Float16 h = (_Float16)x;
+          out[((((size_t)kb * 2 + 0) * 4 + kq) * 16 + o) * 8 + j] = h;
+          out[((((size_t)kb * 2 + 1) * 4 + kq) * 16 + o) * 8 + j] = (_Float16)(x - (float)h);
+        }
+  return std::ldexp(1.f, -ex);
+}
+
 int upload(wct_ctx* ctx, float** dst, const std::vector<float>& v) {
   HIPCHK(ctx, hipMalloc(reinterpret_cast<void**>(dst), v.size() * sizeof(float)));
   HIPCHK(ctx, hipMemcpy(*dst, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -577,6 +601,13 @@ int wct_load_module(wct_ctx* ctx, int kind, int level, int n_layers, const wct_l
     if (int rc = upload(ctx, &ld.wpk, wpk)) return rc;
     if (int rc = upload(ctx, &ld.bias, bias)) return rc;
     ld.d.wpk = ld.wpk; ld.d.bias = ld.bias;
+    if (in3 && ld.d.cout_pad == 16) {
+      std::vector<_Float16> w16;
+      ld.d.inv_scale = pack_head_f16(wpk, w16);
+      HIPCHK(ctx, hipMalloc(&ld.wpk16, w16.size() * sizeof(_Float16)));
+      HIPCHK(ctx, hipMemcpy(ld.wpk16, w16.data(), w16.size() * sizeof(_Float16), hipMemcpyHostToDevice));
+      ld.d.wpk16 = ld.wpk16;
+    }
     if (!in3) {
       std::vector<_Float16> w16;
       const int taps = ld.d.cout_pad == 16 ? 10 : 9;

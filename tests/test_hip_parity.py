@@ -144,20 +144,25 @@ def test_unfused_reference_sequence_matches_fused(torch_cuda, wct16, golden):
         assert rel_err(fused, unfused) < 2e-5, k
 
 
-def test_fused_ends_bitwise_equal_unfused(torch_cuda, weights16x, monkeypatch):
-    """The fused conv11+conv12+pool / conv12+conv11 kernels keep the unfused kernels' arithmetic and summation
-    order, so whole-level outputs are bitwise identical with and without them (odd sizes, image-border tiles)."""
+def test_fused_ends_match_unfused(torch_cuda, weights16x, monkeypatch):
+    """Fused ends vs the layer-by-layer path (odd sizes, image-border tiles).
+    Decoder tail (conv12+conv11): same arithmetic and summation order as the unfused kernels -> bitwise identical.
+    Encoder head (conv11+conv12+pool): conv11 runs as f16x3 there and as exact-fp32 MFMA unfused -> fp32-class
+    agreement (the tolerance is relative to max|y|, as in the golden tests)."""
     from wct_hip import WCT
     torch = torch_cuda
     g = torch.Generator(device="cuda").manual_seed(21)
     c = torch.rand((1, 3, 203, 333), device="cuda", generator=g)
-    s = torch.rand((1, 3, 150, 170), device="cuda", generator=g)
+    f5 = torch.rand((1, 128, 12, 20), device="cuda", generator=g)
+    f2 = torch.rand((1, 32, 101, 166), device="cuda", generator=g)
     outs = {}
     for fuse in ("1", "0"):
         monkeypatch.setenv("WCT_FUSE", fuse)
         w = WCT(types.SimpleNamespace(mode="16x", alpha=1.0), weights=weights16x)
-        outs[fuse] = [w.encode(5, c).clone(), w.encode(2, c).clone()] + [w.style_transfer_level(k, c, s).clone() for k in (5, 3, 2)]
-    for a, b in zip(outs["1"], outs["0"]):
+        outs[fuse] = ([w.e5(c).clone(), w.e2(c).clone(), w.e3(c[..., :64, :32]).clone()], [w.d5(f5).clone(), w.d2(f2).clone()])
+    for a, b in zip(outs["1"][0], outs["0"][0]):
+        assert float((a - b).abs().max() / b.abs().max()) < 3e-6
+    for a, b in zip(outs["1"][1], outs["0"][1]):
         assert torch.equal(a, b)
 
 
