@@ -202,17 +202,20 @@ __global__ __launch_bounds__(32 * TH) void conv3x3_f16_kernel(F16Args a) {
         bh[p] = __builtin_bit_cast(f16x8, act[(0 * 2 + kh) * NPP + pix]);
         bl[p] = __builtin_bit_cast(f16x8, act[(1 * 2 + kh) * NPP + pix]);
       }
+      // the three split terms of one accumulator are issued CT * 2 MFMAs apart (independent accumulators in between)
+      f16x8 ah[CT], al[CT];
 #pragma unroll
       for (int c = 0; c < CT; ++c) {
-        const f16x8 ah = __builtin_bit_cast(f16x8, wgt[((tap * 2 + 0) * 2 + kh) * COW + c * 32 + li]);
-        const f16x8 al = __builtin_bit_cast(f16x8, wgt[((tap * 2 + 1) * 2 + kh) * COW + c * 32 + li]);
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-          acc[c][p] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[p], acc[c][p], 0, 0, 0);
-          acc[c][p] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[p], acc[c][p], 0, 0, 0);
-          acc[c][p] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[p], acc[c][p], 0, 0, 0);
-        }
+        ah[c] = __builtin_bit_cast(f16x8, wgt[((tap * 2 + 0) * 2 + kh) * COW + c * 32 + li]);
+        al[c] = __builtin_bit_cast(f16x8, wgt[((tap * 2 + 1) * 2 + kh) * COW + c * 32 + li]);
       }
+#pragma unroll
+      for (int term = 0; term < 3; ++term)
+#pragma unroll
+        for (int c = 0; c < CT; ++c)
+#pragma unroll
+          for (int p = 0; p < 2; ++p)
+            acc[c][p] = __builtin_amdgcn_mfma_f32_32x32x16_f16(term == 2 ? al[c] : ah[c], term == 1 ? bl[p] : bh[p], acc[c][p], 0, 0, 0);
     }
   }
 
@@ -295,17 +298,22 @@ __global__ __launch_bounds__(256) void conv3x3_f16_c16_kernel(F16Args a) {
       const int dy = tc / 3, dx = tc - dy * 3;
       const f16x8 ah = __builtin_bit_cast(f16x8, wgt[((tap * 2 + 0) * 2 + kh) * 16 + li]);
       const f16x8 al = __builtin_bit_cast(f16x8, wgt[((tap * 2 + 1) * 2 + kh) * 16 + li]);
+      f16x8 bh[2][2], bl[2][2];
 #pragma unroll
       for (int r = 0; r < 2; ++r)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           const int pix = (wave * 2 + r + dy) * FHW + h * 16 + li + dx;
-          const f16x8 bh = __builtin_bit_cast(f16x8, act[(0 * 2 + kh) * NPP + pix]);
-          const f16x8 bl = __builtin_bit_cast(f16x8, act[(1 * 2 + kh) * NPP + pix]);
-          acc[r][h] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc[r][h], 0, 0, 0);
-          acc[r][h] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc[r][h], 0, 0, 0);
-          acc[r][h] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc[r][h], 0, 0, 0);
+          bh[r][h] = __builtin_bit_cast(f16x8, act[(0 * 2 + kh) * NPP + pix]);
+          bl[r][h] = __builtin_bit_cast(f16x8, act[(1 * 2 + kh) * NPP + pix]);
         }
+#pragma unroll
+      for (int term = 0; term < 3; ++term)   // dependent MFMAs 4 apart
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+          for (int h = 0; h < 2; ++h)
+            acc[r][h] = __builtin_amdgcn_mfma_f32_16x16x32_f16(term == 2 ? al : ah, term == 1 ? bl[r][h] : bh[r][h], acc[r][h], 0, 0, 0);
     }
   }
 
@@ -442,17 +450,22 @@ __device__ __forceinline__ void c16_compute(const u32x4* act, const u32x4* wgt, 
     const int dy = tc / 3, dx = tc - dy * 3;
     const f16x8 ah = __builtin_bit_cast(f16x8, wgt[((tap * 2 + 0) * 2 + kh) * 16 + li]);
     const f16x8 al = __builtin_bit_cast(f16x8, wgt[((tap * 2 + 1) * 2 + kh) * 16 + li]);
+    f16x8 bh[2][2], bl[2][2];
 #pragma unroll
     for (int r = 0; r < 2; ++r)
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int pix = (wave * 2 + r + dy) * FHW + h * 16 + li + dx;
-        const f16x8 bh = __builtin_bit_cast(f16x8, act[(0 * 2 + kh) * NPP + pix]);
-        const f16x8 bl = __builtin_bit_cast(f16x8, act[(1 * 2 + kh) * NPP + pix]);
-        acc[r][h] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc[r][h], 0, 0, 0);
-        acc[r][h] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc[r][h], 0, 0, 0);
-        acc[r][h] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc[r][h], 0, 0, 0);
+        bh[r][h] = __builtin_bit_cast(f16x8, act[(0 * 2 + kh) * NPP + pix]);
+        bl[r][h] = __builtin_bit_cast(f16x8, act[(1 * 2 + kh) * NPP + pix]);
       }
+#pragma unroll
+    for (int term = 0; term < 3; ++term)   // dependent MFMAs 4 apart
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+          acc[r][h] = __builtin_amdgcn_mfma_f32_16x16x32_f16(term == 2 ? al : ah, term == 1 ? bl[r][h] : bh[r][h], acc[r][h], 0, 0, 0);
   }
 }
 
@@ -507,6 +520,7 @@ __global__ __launch_bounds__(256, 4) void enc_head_kernel(HeadArgs a) {
 #pragma unroll 1
     for (int i = 0; i < 6; i += 2) {
       f32x4 acc[2];
+      f16x8 bhs[2][2], bls[2][2];
       int pixs[2];
       bool ok[2];
 #pragma unroll
@@ -525,11 +539,16 @@ __global__ __launch_bounds__(256, 4) void enc_head_kernel(HeadArgs a) {
           const u32x2 h0 = imgH[e0], h1 = imgH[e0 + 1], l0 = imgL[e0], l1 = imgL[e0 + 1];
           const f16x8 bh = __builtin_bit_cast(f16x8, u32x4{h0[0], h0[1], h1[0], h1[1]});
           const f16x8 bl = __builtin_bit_cast(f16x8, u32x4{l0[0], l0[1], l1[0], l1[1]});
-          acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a11[kb][0], bh, acc[u], 0, 0, 0);
-          acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a11[kb][0], bl, acc[u], 0, 0, 0);
-          acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a11[kb][1], bh, acc[u], 0, 0, 0);
+          bhs[u][kb] = bh; bls[u][kb] = bl;
         }
       }
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int term = 0; term < 3; ++term)
+#pragma unroll
+          for (int u = 0; u < 2; ++u)
+            acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a11[kb][term == 2], term == 1 ? bls[u][kb] : bhs[u][kb], acc[u], 0, 0, 0);
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         f32x4 x;
@@ -572,22 +591,29 @@ struct TailArgs {   // conv12 (16->16 on the nearest-x2 upsampled input) + ReLU 
   int H, W, inW, up_in, tiles_x, tiles_y;
 };
 
-__global__ __launch_bounds__(256) void dec_tail_kernel(TailArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int NPP = npp(8), NPH = nph(8);
-  u32x4* act0 = reinterpret_cast<u32x4*>(smem);   // [4][432]  input of conv12 (two halo rings)
-  u32x4* wg12 = act0 + 4 * NPI2;                  // [640]
-  u32x4* wg11 = wg12 + 640;                       // [640]
-  u32x4* act1 = wg11 + 640;                       // [4][NPP]  conv12 output on the 34 x 10 halo
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int li = lane & 15, kq = lane >> 4, kh = kq & 1, ts = kq >> 1;
-  const int tile = xcd_swizzle(blockIdx.x, a.tiles_x * a.tiles_y);
+constexpr int TAIL_SL = (NPI2 * 2 + 255) / 256;  // 4 register slots of 8 channels per thread
+struct TailRegs { f32x4 v0[TAIL_SL], v1[TAIL_SL]; };
+
+// (uniform) true when the 36 x 12 input window of the tile lies inside the image: no reflection anywhere
+__device__ __forceinline__ bool tile_interior(int ty0, int tx0, int H, int W) {
+  return ty0 >= 2 && ty0 + 10 <= H && tx0 >= 2 && tx0 + 34 <= W;
+}
+
+// soff[k]: tile-independent element offset of slot k from the window origin, valid for interior tiles (the window
+// origin (ty0 - 2, tx0 - 2) is even, so the nearest-x2 shift distributes over origin + offset)
+__device__ __forceinline__ void tail_fetch(const TailArgs& a, TailRegs& r, const int (&soff)[TAIL_SL], int tile, int tid) {
   const int ty0 = (tile / a.tiles_x) * 8, tx0 = (tile % a.tiles_x) * FTW;
-  // ---- stage the 36 x 12 x 16 input (unconditional batched loads, then split)
-  constexpr int SL = (NPI2 * 2 + 255) / 256;  // 4
-  f32x4 v0[SL], v1[SL];
+  if (tile_interior(ty0, tx0, a.H, a.W)) {
+    const float* base = a.in + ((size_t)((ty0 - 2) >> a.up_in) * a.inW + ((tx0 - 2) >> a.up_in)) * 16;
 #pragma unroll
-  for (int k = 0; k < SL; ++k) {
+    for (int k = 0; k < TAIL_SL; ++k) {
+      r.v0[k] = *reinterpret_cast<const f32x4*>(base + soff[k]);
+      r.v1[k] = *reinterpret_cast<const f32x4*>(base + soff[k] + 4);
+    }
+    return;
+  }
+#pragma unroll
+  for (int k = 0; k < TAIL_SL; ++k) {
     int e = tid + 256 * k;
     e = e < NPI2 * 2 ? e : NPI2 * 2 - 1;
     const int h2 = e & 1, pix = e >> 1;
@@ -595,73 +621,147 @@ __global__ __launch_bounds__(256) void dec_tail_kernel(TailArgs a) {
     int gy = reflect_clamp(ty0 - 2 + py, a.H), gx = reflect_clamp(tx0 - 2 + px, a.W);
     if (a.up_in) { gy >>= 1; gx >>= 1; }
     const float* src = a.in + ((size_t)gy * a.inW + gx) * 16 + h2 * 8;
-    v0[k] = *reinterpret_cast<const f32x4*>(src);
-    v1[k] = *reinterpret_cast<const f32x4*>(src + 4);
+    r.v0[k] = *reinterpret_cast<const f32x4*>(src);
+    r.v1[k] = *reinterpret_cast<const f32x4*>(src + 4);
   }
-  for (int e = tid; e < 640; e += 256) { wg12[e] = a.w12[e]; wg11[e] = a.w11[e]; }
+}
+
+__device__ __forceinline__ void tail_commit(const TailRegs& r, u32x4* act0, int tid) {
 #pragma unroll
-  for (int k = 0; k < SL; ++k) {
+  for (int k = 0; k < TAIL_SL; ++k) {
     const int e = tid + 256 * k;
     if (e < NPI2 * 2) {
       f16x8 hi, lo;
-      split8(v0[k], v1[k], hi, lo);
+      split8(r.v0[k], r.v1[k], hi, lo);
       act0[(0 * 2 + (e & 1)) * NPI2 + (e >> 1)] = __builtin_bit_cast(u32x4, hi);
       act0[(1 * 2 + (e & 1)) * NPI2 + (e >> 1)] = __builtin_bit_cast(u32x4, lo);
     }
   }
-  __syncthreads();
-  // ---- conv12 on the 340 halo pixels (evaluated at their reflected image coordinates), into act1
+}
+
+// Persistent like enc_head_kernel: both weight slabs are staged once per workgroup, the 36 x 12 x 16 input window of
+// the NEXT tile is fetched into registers while this tile is on the matrix cores and split into LDS behind conv11.
+// Everything that depends only on the thread (slot offsets, halo-group pixel indices) is computed once; only tiles
+// that touch the image border recompute their reflected coordinates.
+__global__ __launch_bounds__(256, 2) void dec_tail_kernel(TailArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NPP = npp(8), NPH = nph(8), NG = 6;
+  u32x4* act0 = reinterpret_cast<u32x4*>(smem);   // [4][432]  input of conv12 (two halo rings)
+  u32x4* wg12 = act0 + 4 * NPI2;                  // [640]
+  u32x4* wg11 = wg12 + 640;                       // [640]
+  u32x4* act1 = wg11 + 640;                       // [4][NPP]  conv12 output on the 34 x 10 halo
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, kq = lane >> 4, kh = kq & 1, ts = kq >> 1;
+  const int ntiles = a.tiles_x * a.tiles_y;
+  for (int e = tid; e < 640; e += 256) { wg12[e] = a.w12[e]; wg11[e] = a.w11[e]; }
   const float inv12 = a.inv12_ptr ? *a.inv12_ptr : a.inv12;
   const f32x4 bias12 = *reinterpret_cast<const f32x4*>(a.b12 + 4 * kq);
-  for (int g = wave; g < NGRP; g += 4) {
-    const int pixr = g * 16 + li, pix = pixr < NPH ? pixr : NPH - 1;
-    const int py = pix / FHW, px = pix - py * FHW;
-    const int iy = reflect_clamp(ty0 - 1 + py, a.H) - (ty0 - 2), ix = reflect_clamp(tx0 - 1 + px, a.W) - (tx0 - 2);
-    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int s = 0; s < 5; ++s) {
-      const int tap = 2 * s + ts;
-      const int tc = tap > 8 ? 8 : tap;
-      const int dy = tc / 3, dx = tc - dy * 3;
-      const f16x8 ah = __builtin_bit_cast(f16x8, wg12[((tap * 2 + 0) * 2 + kh) * 16 + li]);
-      const f16x8 al = __builtin_bit_cast(f16x8, wg12[((tap * 2 + 1) * 2 + kh) * 16 + li]);
-      const int sp = (iy - 1 + dy) * I2W + ix - 1 + dx;
-      const f16x8 bh = __builtin_bit_cast(f16x8, act0[(0 * 2 + kh) * NPI2 + sp]);
-      const f16x8 bl = __builtin_bit_cast(f16x8, act0[(1 * 2 + kh) * NPI2 + sp]);
-      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc, 0, 0, 0);
-    }
-    f32x4 v;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] = fmaxf(acc[r] * inv12 + bias12[r], 0.f);
-    if (pixr < NPH) store_split4(act1, NPP, pix, kq, v);
-  }
-  __syncthreads();
-  // ---- conv11 (16 -> 3) + ReLU -> planar output (the arithmetic of conv3x3_f16_c16_kernel<OUT3>)
-  f32x4 acc[2][2];
-#pragma unroll
-  for (int r = 0; r < 2; ++r)
-#pragma unroll
-    for (int h = 0; h < 2; ++h) acc[r][h] = f32x4{0.f, 0.f, 0.f, 0.f};
-  c16_compute(act1, wg11, wave, li, kq, acc);
-  const f32x4 bias = *reinterpret_cast<const f32x4*>(a.b11);
+  const f32x4 bias11 = *reinterpret_cast<const f32x4*>(a.b11);
   const size_t plane = (size_t)a.H * a.W;
-  if (kq == 0) {
+
+  int soff[TAIL_SL];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int gx = tx0 + h * 16 + li;
+  for (int k = 0; k < TAIL_SL; ++k) {
+    int e = tid + 256 * k;
+    e = e < NPI2 * 2 ? e : NPI2 * 2 - 1;
+    const int pix = e >> 1, py = pix / I2W, px = pix - py * I2W;
+    soff[k] = ((py >> a.up_in) * a.inW + (px >> a.up_in)) * 16 + (e & 1) * 8;
+  }
+  // the wave's six 16-pixel groups of the 34 x 10 halo (group 5 exists for waves 0 and 1 only: 22 groups)
+  int gpix[NG], gpy[NG], gpx[NG];
+  bool gok[NG];
 #pragma unroll
-      for (int r2 = 0; r2 < 2; ++r2) {
-        const int gy = ty0 + wave * 2 + r2;
-        if (gy < a.H && gx < a.W) {
-          const size_t off = (size_t)gy * a.W + gx;
-          a.out[off] = fmaxf(acc[r2][h][0] * a.inv11 + bias[0], 0.f);
-          a.out[plane + off] = fmaxf(acc[r2][h][1] * a.inv11 + bias[1], 0.f);
-          a.out[2 * plane + off] = fmaxf(acc[r2][h][2] * a.inv11 + bias[2], 0.f);
+  for (int u = 0; u < NG; ++u) {
+    const int pixr = (wave + 4 * u) * 16 + li;
+    gok[u] = pixr < NPH;
+    gpix[u] = gok[u] ? pixr : NPH - 1;
+    gpy[u] = gpix[u] / FHW;
+    gpx[u] = gpix[u] - gpy[u] * FHW;
+  }
+
+  TailRegs tr;
+  int v = blockIdx.x;
+  if (v < ntiles) {
+    tail_fetch(a, tr, soff, xcd_swizzle(v, ntiles), tid);
+    tail_commit(tr, act0, tid);
+  }
+  for (; v < ntiles; v += gridDim.x) {
+    const int tile = xcd_swizzle(v, ntiles);
+    const int ty0 = (tile / a.tiles_x) * 8, tx0 = (tile % a.tiles_x) * FTW;
+    __syncthreads();   // act0 of this tile is in LDS; every wave is done with the previous tile's act1
+    const int vn = v + gridDim.x;
+    if (vn < ntiles) tail_fetch(a, tr, soff, xcd_swizzle(vn, ntiles), tid);
+    // ---- conv12 on the 340 halo pixels (evaluated at their reflected image coordinates), into act1.
+    //      All six groups are in flight together (tap loop outermost): the operand reads of the next tap pair overlap
+    //      the MFMAs of this one.
+    {
+      f32x4 acc[NG];
+      int sp0[NG];
+      if (tile_interior(ty0, tx0, a.H, a.W)) {
+#pragma unroll
+        for (int u = 0; u < NG; ++u) sp0[u] = gpy[u] * I2W + gpx[u];
+      } else {
+#pragma unroll
+        for (int u = 0; u < NG; ++u) {
+          const int iy = reflect_clamp(ty0 - 1 + gpy[u], a.H) - (ty0 - 2), ix = reflect_clamp(tx0 - 1 + gpx[u], a.W) - (tx0 - 2);
+          sp0[u] = (iy - 1) * I2W + ix - 1;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < NG; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < 5; ++s) {
+        const int tap = 2 * s + ts;
+        const int tc = tap > 8 ? 8 : tap;
+        const int dy = tc / 3, dx = tc - dy * 3;
+        const f16x8 ah = __builtin_bit_cast(f16x8, wg12[((tap * 2 + 0) * 2 + kh) * 16 + li]);
+        const f16x8 al = __builtin_bit_cast(f16x8, wg12[((tap * 2 + 1) * 2 + kh) * 16 + li]);
+        f16x8 bh[NG], bl[NG];
+#pragma unroll
+        for (int u = 0; u < NG; ++u) {
+          const int sp = sp0[u] + dy * I2W + dx;
+          bh[u] = __builtin_bit_cast(f16x8, act0[(0 * 2 + kh) * NPI2 + sp]);
+          bl[u] = __builtin_bit_cast(f16x8, act0[(1 * 2 + kh) * NPI2 + sp]);
+        }
+#pragma unroll
+        for (int term = 0; term < 3; ++term)
+#pragma unroll
+          for (int u = 0; u < NG; ++u)
+            acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(term == 2 ? al : ah, term == 1 ? bl[u] : bh[u], acc[u], 0, 0, 0);
+      }
+#pragma unroll
+      for (int u = 0; u < NG; ++u) {
+        f32x4 x;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) x[r] = fmaxf(acc[u][r] * inv12 + bias12[r], 0.f);
+        if (gok[u]) store_split4(act1, NPP, gpix[u], kq, x);
+      }
+    }
+    __syncthreads();
+    // ---- conv11 (16 -> 3) + ReLU -> planar output (the arithmetic of conv3x3_f16_c16_kernel<OUT3>)
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) acc[r][h] = f32x4{0.f, 0.f, 0.f, 0.f};
+    c16_compute(act1, wg11, wave, li, kq, acc);
+    if (kq == 0) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int gx = tx0 + h * 16 + li;
+#pragma unroll
+        for (int r2 = 0; r2 < 2; ++r2) {
+          const int gy = ty0 + wave * 2 + r2;
+          if (gy < a.H && gx < a.W) {
+            const size_t off = (size_t)gy * a.W + gx;
+            a.out[off] = fmaxf(acc[r2][h][0] * a.inv11 + bias11[0], 0.f);
+            a.out[plane + off] = fmaxf(acc[r2][h][1] * a.inv11 + bias11[1], 0.f);
+            a.out[2 * plane + off] = fmaxf(acc[r2][h][2] * a.inv11 + bias11[2], 0.f);
+          }
         }
       }
     }
+    if (vn < ntiles) tail_commit(tr, act0, tid);   // conv12 of this tile is behind the barrier above
   }
 }
 
@@ -764,7 +864,8 @@ hipError_t launch_dec_tail(const ConvDesc& d0, const ConvDesc& d1, const float* 
   const size_t lds = ((size_t)4 * NPI2 + 640 + (size_t)4 * npp(8) + 640) * 16;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(dec_tail_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(dec_tail_kernel, dim3(a.tiles_x * a.tiles_y), dim3(256), lds, s, a);
+  const int ntiles = a.tiles_x * a.tiles_y, grid = ntiles < 2 * num_cus() ? ntiles : 2 * num_cus();   // 70.6 KB: 2 per CU
+  hipLaunchKernelGGL(dec_tail_kernel, dim3(grid), dim3(256), lds, s, a);
   return hipGetLastError();
 }
 
