@@ -390,10 +390,24 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 constexpr int IMG_E = NPI2 + 4;   // 8-byte pixels per plane; the zeroed tail absorbs the "4th pixel" over-read of the last row
 
-// next tile's 36 x 12 x 3 image window -> 6 registers per thread (unconditional, clamped)
-__device__ __forceinline__ void head_fetch(const HeadArgs& a, float (&r)[2][3], int tile, int tid) {
+// (uniform) true when the 36 x 12 input window of the tile lies inside the image: no reflection anywhere
+__device__ __forceinline__ bool tile_interior(int ty0, int tx0, int H, int W) {
+  return ty0 >= 2 && ty0 + 10 <= H && tx0 >= 2 && tx0 + 34 <= W;
+}
+
+// next tile's 36 x 12 x 3 image window -> 6 registers per thread (unconditional, clamped).  soff[k]: tile-independent
+// offset of the thread's pixel k from the window origin, valid for interior tiles.
+__device__ __forceinline__ void head_fetch(const HeadArgs& a, float (&r)[2][3], const int (&soff)[2], int tile, int tid) {
   const int ty0 = (tile / a.tiles_x) * 8, tx0 = (tile % a.tiles_x) * FTW;
   const size_t plane = (size_t)a.H * a.W;
+  if (tile_interior(ty0, tx0, a.H, a.W)) {
+    const float* base = a.img + (size_t)(ty0 - 2) * a.W + (tx0 - 2);
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) r[k][c] = base[c * plane + soff[k]];
+    return;
+  }
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
     int e = tid + 256 * k;
@@ -475,7 +489,7 @@ __device__ __forceinline__ void c16_compute(const u32x4* act, const u32x4* wgt, 
 //   slot s = 4 kb + kq  ->  image row dy = s >> 1, pixels 2 (s & 1) + {0, 1}, 4 channels each (RGB0)
 // so that a lane's B operand is 16 contiguous bytes of the RGB0 f16 tile (ds_read2_b64); the 4th pixel / 4th channel /
 // 4th row slots carry zero weights.  (fp32 MFMA for this layer cost 9 x 32 issue cycles per 16 pixels, this 6 x 16.)
-__global__ __launch_bounds__(256, 4) void enc_head_kernel(HeadArgs a) {
+__global__ __launch_bounds__(256, 3) void enc_head_kernel(HeadArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NPP = npp(8), NPH = nph(8);
   u32x2* imgH = reinterpret_cast<u32x2*>(smem);                // [IMG_E] RGB0 hi
@@ -504,10 +518,29 @@ __global__ __launch_bounds__(256, 4) void enc_head_kernel(HeadArgs a) {
     scol[kb] = 2 * (s & 1);
   }
 
+  int soff[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    int e = tid + 256 * k;
+    e = e < NPI2 ? e : NPI2 - 1;
+    soff[k] = (e / I2W) * a.W + e % I2W;
+  }
+  // the wave's six 16-pixel groups of the 34 x 10 halo (group 5 exists for waves 0 and 1 only: 22 groups)
+  int gpix[6], gpy[6], gpx[6];
+  bool gok[6];
+#pragma unroll
+  for (int u = 0; u < 6; ++u) {
+    const int pixr = (wave + 4 * u) * 16 + li;
+    gok[u] = pixr < NPH;
+    gpix[u] = gok[u] ? pixr : NPH - 1;
+    gpy[u] = gpix[u] / FHW;
+    gpx[u] = gpix[u] - gpy[u] * FHW;
+  }
+
   float pxr[2][3];
   int v = blockIdx.x;
   if (v < ntiles) {
-    head_fetch(a, pxr, xcd_swizzle(v, ntiles), tid);
+    head_fetch(a, pxr, soff, xcd_swizzle(v, ntiles), tid);
     head_commit(pxr, imgH, imgL, tid);
   }
   for (; v < ntiles; v += gridDim.x) {
@@ -515,31 +548,29 @@ __global__ __launch_bounds__(256, 4) void enc_head_kernel(HeadArgs a) {
     const int ty0 = (tile / a.tiles_x) * 8, tx0 = (tile % a.tiles_x) * FTW;
     __syncthreads();   // image window of this tile is in LDS; every wave is done with the previous tile's planes
     const int vn = v + gridDim.x;
-    if (vn < ntiles) head_fetch(a, pxr, xcd_swizzle(vn, ntiles), tid);
-    // ---- conv11 on the 340 halo pixels, two 16-pixel groups in flight per wave
-#pragma unroll 1
-    for (int i = 0; i < 6; i += 2) {
-      f32x4 acc[2];
-      f16x8 bhs[2][2], bls[2][2];
-      int pixs[2];
-      bool ok[2];
+    if (vn < ntiles) head_fetch(a, pxr, soff, xcd_swizzle(vn, ntiles), tid);
+    const bool interior = tile_interior(ty0, tx0, a.H, a.W);
+    // ---- conv11 on the 340 halo pixels, three 16-pixel groups in flight per wave
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int g = wave + 4 * (i + u);
-        const int pixr = g * 16 + li, pix = pixr < NPH ? pixr : NPH - 1;
-        ok[u] = pixr < NPH;
-        pixs[u] = pix;
-        const int py = pix / FHW, px = pix - py * FHW;
-        const int iy = reflect_clamp(ty0 - 1 + py, a.H) - (ty0 - 2), ix = reflect_clamp(tx0 - 1 + px, a.W) - (tx0 - 2);
-        const int base = (iy - 1) * I2W + ix - 1;
+    for (int i = 0; i < 6; i += 3) {
+      f32x4 acc[3];
+      f16x8 bhs[3][2], bls[3][2];
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        int base;
+        if (interior) {
+          base = gpy[i + u] * I2W + gpx[i + u];
+        } else {
+          const int iy = reflect_clamp(ty0 - 1 + gpy[i + u], a.H) - (ty0 - 2), ix = reflect_clamp(tx0 - 1 + gpx[i + u], a.W) - (tx0 - 2);
+          base = (iy - 1) * I2W + ix - 1;
+        }
         acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
           const int e0 = base + srow[kb] * I2W + scol[kb];
           const u32x2 h0 = imgH[e0], h1 = imgH[e0 + 1], l0 = imgL[e0], l1 = imgL[e0 + 1];
-          const f16x8 bh = __builtin_bit_cast(f16x8, u32x4{h0[0], h0[1], h1[0], h1[1]});
-          const f16x8 bl = __builtin_bit_cast(f16x8, u32x4{l0[0], l0[1], l1[0], l1[1]});
-          bhs[u][kb] = bh; bls[u][kb] = bl;
+          bhs[u][kb] = __builtin_bit_cast(f16x8, u32x4{h0[0], h0[1], h1[0], h1[1]});
+          bls[u][kb] = __builtin_bit_cast(f16x8, u32x4{l0[0], l0[1], l1[0], l1[1]});
         }
       }
 #pragma unroll
@@ -547,14 +578,14 @@ __global__ __launch_bounds__(256, 4) void enc_head_kernel(HeadArgs a) {
 #pragma unroll
         for (int term = 0; term < 3; ++term)
 #pragma unroll
-          for (int u = 0; u < 2; ++u)
+          for (int u = 0; u < 3; ++u)
             acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a11[kb][term == 2], term == 1 ? bls[u][kb] : bhs[u][kb], acc[u], 0, 0, 0);
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
+      for (int u = 0; u < 3; ++u) {
         f32x4 x;
 #pragma unroll
         for (int r = 0; r < 4; ++r) x[r] = fmaxf(acc[u][r] * a.inv11 + bias11[r], 0.f);
-        if (ok[u]) store_split4(act, NPP, pixs[u], kq, x);
+        if (gok[i + u]) store_split4(act, NPP, gpix[i + u], kq, x);
       }
     }
     __syncthreads();
@@ -593,11 +624,6 @@ struct TailArgs {   // conv12 (16->16 on the nearest-x2 upsampled input) + ReLU 
 
 constexpr int TAIL_SL = (NPI2 * 2 + 255) / 256;  // 4 register slots of 8 channels per thread
 struct TailRegs { f32x4 v0[TAIL_SL], v1[TAIL_SL]; };
-
-// (uniform) true when the 36 x 12 input window of the tile lies inside the image: no reflection anywhere
-__device__ __forceinline__ bool tile_interior(int ty0, int tx0, int H, int W) {
-  return ty0 >= 2 && ty0 + 10 <= H && tx0 >= 2 && tx0 + 34 <= W;
-}
 
 // soff[k]: tile-independent element offset of slot k from the window origin, valid for interior tiles (the window
 // origin (ty0 - 2, tx0 - 2) is even, so the nearest-x2 shift distributes over origin + offset)
@@ -848,7 +874,7 @@ hipError_t launch_enc_head(const ConvDesc& d0, const ConvDesc& d1, const float* 
   a.w12 = reinterpret_cast<const u32x4*>(d1.wpk16); a.b12 = d1.bias; a.inv12 = d1.inv_scale;
   a.H = H; a.W = W; a.tiles_x = (W + FTW - 1) / FTW; a.tiles_y = (H + 7) / 8;
   const size_t lds = (size_t)2 * IMG_E * 8 + (size_t)4 * npp(8) * 16 + 640 * 16;   // 39.7 KB: 4 workgroups per CU
-  const int ntiles = a.tiles_x * a.tiles_y, grid = ntiles < 4 * num_cus() ? ntiles : 4 * num_cus();
+  const int ntiles = a.tiles_x * a.tiles_y, grid = ntiles < 3 * num_cus() ? ntiles : 3 * num_cus();
   hipLaunchKernelGGL(enc_head_kernel, dim3(grid), dim3(256), lds, s, a);
   return hipGetLastError();
 }
