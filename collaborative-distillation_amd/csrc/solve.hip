@@ -220,6 +220,110 @@ __global__ void ns_final_kernel(double* res, int C, int Cp, int inverse, NsWs w,
   res[eig_F_offset(C) + e] = v;
 }
 
+// ---- C <= 64: the whole coupled iteration in ONE workgroup, Y / Z / T resident in LDS (3 x 34 KB at Cp = 64).
+//      One launch replaces init + fill + 2 * NS_MAXIT stage launches + final: at these sizes a stage is a few hundred
+//      MFMAs, so the multi-launch schedule above is pure launch latency (~5 us per stage, ~250 us per solve), while
+//      one CU's fp64 matrix cores need 0.75 us (Cp = 32) / 6 us (Cp = 64) per iteration.
+//      One wave per 16x16 output tile; the arithmetic (operands, k order, residual test) is that of the stage kernels.
+template <int CP>
+__device__ __forceinline__ f64x4 tile_gemm_lds(const double* P, const double* Q, int i0, int j0, int lane) {
+  constexpr int LD = CP + 2;   // row stride == 2 (mod 32) doubles: the A-operand reads (16 rows x 4 columns) are bank-conflict free
+  const int li = lane & 15, kk = lane >> 4;
+  f64x4 acc = f64x4{0., 0., 0., 0.};
+  const double* pp = P + (i0 + li) * LD + kk;
+  const double* qq = Q + kk * LD + j0 + li;
+#pragma unroll 2
+  for (int k0 = 0; k0 < CP; k0 += 16) {
+    double a[4], b[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { a[u] = pp[k0 + 4 * u]; b[u] = qq[(k0 + 4 * u) * LD]; }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], acc, 0, 0, 0);
+  }
+  return acc;  // row = kk + 4 * reg, col = li
+}
+
+template <int CP>
+__global__ __launch_bounds__((CP / 16) * (CP / 16) * 64) void ns_lds_kernel(double* res, int C, int inverse, double eps_rel,
+                                                                               int maxit, int* ok_out, int* info) {
+  constexpr int LD = CP + 2, TPR = CP / 16, NW = TPR * TPR, NT = NW * 64;
+  extern __shared__ __attribute__((aligned(16))) char smem_ns[];
+  double* Y = reinterpret_cast<double*>(smem_ns);
+  double* Z = Y + CP * LD;
+  double* T = Z + CP * LD;
+  double* red = T + CP * LD;                       // [NW] + [1]
+  int* dead = reinterpret_cast<int*>(red + NW + 2);  // [CP]
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, kk = lane >> 4;
+  const int i0 = (wave / TPR) * 16, j0 = (wave % TPR) * 16;
+  const double floor_ = res[(size_t)C * C + 2 * C];
+  for (int j = tid; j < CP; j += NT) dead[j] = (j >= C) || !(res[(size_t)j * C + j] > floor_);   // padding = identity block too
+  __syncthreads();
+  // Frobenius norm of the live block
+  double sq = 0.;
+  for (int e = tid; e < C * C; e += NT) {
+    const int r = e / C, c = e - r * C;
+    if (!dead[r] && !dead[c]) sq += res[e] * res[e];
+  }
+  for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+  if (lane == 0) red[wave] = sq;
+  __syncthreads();
+  double f = 0.;
+  for (int w = 0; w < NW; ++w) f += red[w];
+  f = sqrt(f);
+  if (!(f > 0.)) f = 1.;                 // all channels dead: Y0 = I, result zeroed anyway
+  const double s = f * (1.0 + eps_rel), shift = eps_rel * f;   // spectrum of (A + eps f I)/s inside (0, 1]
+  for (int e = tid; e < CP * CP; e += NT) {
+    const int r = e / CP, c = e - r * CP;
+    double y = r == c ? 1.0 : 0.0;
+    if (!dead[r] && !dead[c]) y = (res[(size_t)r * C + c] + (r == c ? shift : 0.0)) / s;
+    Y[r * LD + c] = y;
+    Z[r * LD + c] = r == c ? 1.0 : 0.0;
+  }
+  __syncthreads();
+  int n = 0;
+  double prev = 1e300;   // residual measured before the last executed update
+  for (int it = 0; it < maxit; ++it) {
+    if (it > 0 && prev < NS_TOL) break;
+    // stage 1: T = 1.5 I - 0.5 Z Y, residual = max |Z Y - I|
+    const f64x4 zy = tile_gemm_lds<CP>(Z, Y, i0, j0, lane);
+    double m = 0.;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = i0 + kk + 4 * r, col = j0 + li;
+      const double d = zy[r] - (row == col ? 1.0 : 0.0);
+      m = (d == d) ? fmax(m, fabs(d)) : __longlong_as_double(0x7ff0000000000000ll);  // fmax would swallow a NaN
+      T[row * LD + col] = (row == col ? 1.5 : 0.0) - 0.5 * zy[r];
+    }
+    for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o));
+    if (lane == 0) red[wave] = m;
+    __syncthreads();
+    m = 0.;
+    for (int w = 0; w < NW; ++w) m = fmax(m, red[w]);   // +inf (from a NaN) survives fmax
+    prev = m;
+    // stage 2: Y <- Y T, Z <- T Z (tiles held in registers until every wave has read the old iterates)
+    const f64x4 yn = tile_gemm_lds<CP>(Y, T, i0, j0, lane);
+    const f64x4 zn = tile_gemm_lds<CP>(T, Z, i0, j0, lane);
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      Y[(i0 + kk + 4 * r) * LD + j0 + li] = yn[r];
+      Z[(i0 + kk + 4 * r) * LD + j0 + li] = zn[r];
+    }
+    __syncthreads();
+    n = it + 1;
+  }
+  const bool ok = n >= 1 && prev < NS_TOL;
+  if (tid == 0) { *ok_out = ok ? 1 : 0; if (info && ok) *info = n; }
+  if (!ok) return;
+  const double sc = inverse ? rsqrt(s) : sqrt(s);
+  const double* src = inverse ? Z : Y;
+  for (int e = tid; e < C * C; e += NT) {
+    const int r = e / C, c = e - r * C;
+    res[eig_F_offset(C) + e] = (!dead[r] && !dead[c]) ? src[r * LD + c] * sc : 0.;
+  }
+}
+
 // ---- all-reduce of an fp64 value over the LPP (4, 8 or 16) lanes of a pair with DPP moves (no LDS round trips):
 //      quad_perm[1,0,3,2], quad_perm[2,3,0,1] -> quad sums; row_half_mirror -> 8-lane sums; row_mirror -> 16.
 template <int CTRL>
@@ -491,14 +595,28 @@ hipError_t launch_eig(int C, double n, const double* sum, const double* sumsq, i
   w.dead = w.iters + 2;
   const bool big = C > 128;
   const int maxit = NS_MAXIT;
-  hipLaunchKernelGGL(ns_init_kernel, dim3(1), dim3(1024), 0, s, res, C, 1e-15, w, maxit);
-  hipLaunchKernelGGL(ns_fill_kernel, dim3((unsigned)((cp2 + 255) / 256)), dim3(256), 0, s, res, C, Cp, w);
-  const dim3 g1(Cp / 32, Cp / 32, 1), g2(Cp / 32, Cp / 32, 2);
-  for (int it = 0; it < maxit; ++it) {
-    hipLaunchKernelGGL(ns_stage1_kernel, g1, dim3(256), 0, s, w, Cp, it);
-    hipLaunchKernelGGL(ns_stage2_kernel, g2, dim3(256), 0, s, w, Cp, it);
+  if (Cp <= 64) {
+    // one workgroup, iterates in LDS (see ns_lds_kernel)
+    auto go = [&](auto kern, int cp) -> hipError_t {
+      const int nw = (cp / 16) * (cp / 16);
+      const size_t lds = (size_t)3 * cp * (cp + 2) * sizeof(double) + (size_t)(nw + 2) * sizeof(double) + (size_t)cp * sizeof(int);
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return e;
+      hipLaunchKernelGGL(kern, dim3(1), dim3((unsigned)nw * 64), lds, s, res, C, inverse, 1e-15, maxit, w.ok, info_dev);
+      return hipSuccess;
+    };
+    hipError_t e = Cp == 32 ? go(ns_lds_kernel<32>, 32) : go(ns_lds_kernel<64>, 64);
+    if (e != hipSuccess) return e;
+  } else {
+    hipLaunchKernelGGL(ns_init_kernel, dim3(1), dim3(1024), 0, s, res, C, 1e-15, w, maxit);
+    hipLaunchKernelGGL(ns_fill_kernel, dim3((unsigned)((cp2 + 255) / 256)), dim3(256), 0, s, res, C, Cp, w);
+    const dim3 g1(Cp / 32, Cp / 32, 1), g2(Cp / 32, Cp / 32, 2);
+    for (int it = 0; it < maxit; ++it) {
+      hipLaunchKernelGGL(ns_stage1_kernel, g1, dim3(256), 0, s, w, Cp, it);
+      hipLaunchKernelGGL(ns_stage2_kernel, g2, dim3(256), 0, s, w, Cp, it);
+    }
+    hipLaunchKernelGGL(ns_final_kernel, dim3((unsigned)((cc + 255) / 256)), dim3(256), 0, s, res, C, Cp, inverse, w, maxit, info_dev);
   }
-  hipLaunchKernelGGL(ns_final_kernel, dim3((unsigned)((cc + 255) / 256)), dim3(256), 0, s, res, C, Cp, inverse, w, maxit, info_dev);
   if (big) {
     // C > 128 has no single-CU Jacobi.  A singular covariance (fewer pixels than channels) needs the true
     // pseudo-inverse -- a regularised inverse would put gains of 1e6 into the folded decoder weights and lose
