@@ -21,19 +21,9 @@
 //   Cout >= 32: 32x32x16, A = 32 couts x 16 channels of one tap, B = 16 channels x 32 pixels of one tile row.
 //   Cout == 16 (and the 3-channel last conv, padded): 16x16x32, the 32-deep K holds TWO taps x 16 channels.
 #include "wct_common.h"
+#include "conv_f16_dev.h"
 
 namespace {
-
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-// native 16-byte vector for register staging: HIP's u32x4 is a struct of unions, arrays of which are not promoted to
-// registers (they land in scratch)
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-
-constexpr int FTW = 32;
-constexpr int FHW = FTW + 2;                  // halo tile is 34 x (TH + 2), TH = 8 (4 waves) or 16 (8 waves)
-constexpr int nph(int TH) { return FHW * (TH + 2); }                 // 340 / 612 halo pixels
-constexpr int npp(int TH) { return (nph(TH) + 15) / 16 * 16; }       // plane stride in 16-B units: 352 / 624
 
 struct F16Args {
   const float* in;
@@ -46,30 +36,8 @@ struct F16Args {
   int cin, cout, cin_chunks, cout_pad, taps;  // taps = 9 (32x32 path) or 10 (16x16x32 path, tap 9 = zeros)
   int tiles_x, tiles_y;
   int up_in, relu;
+  int in_sp, out_sp;   // SP16 input (16-byte groups taken as they are) / SP16 output (split in the epilogue)
 };
-
-__device__ __forceinline__ int reflect_clamp(int i, int n) {
-  if (i < 0) i = -i;
-  if (i >= n) i = 2 * n - 2 - i;
-  i = i < 0 ? 0 : i;
-  return i >= n ? n - 1 : i;
-}
-
-__device__ __forceinline__ int xcd_swizzle(int bid, int n) {
-  const int q = n >> 3, r = n & 7, xcd = bid & 7, idx = bid >> 3;
-  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-}
-
-__device__ __forceinline__ void split8(const f32x4& a, const f32x4& b, f16x8& hi, f16x8& lo) {
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    float x = j < 4 ? a[j] : b[j - 4];
-    x = fminf(fmaxf(x, -65504.f), 65504.f);
-    const _Float16 h = (_Float16)x;
-    hi[j] = h;
-    lo[j] = (_Float16)(x - (float)h);
-  }
-}
 
 // stage one 16-channel chunk of the halo tile, converting fp32 -> (hi, lo) f16 planes.
 // All of a thread's global loads (<= 3 slots x 2 float4) are issued back to back and UNCONDITIONALLY (addresses
@@ -109,8 +77,10 @@ __device__ __forceinline__ void commit_act(const F16Args& a, const ActRegs& r, u
     if (e < NPH * 2) {
       const int kh = e & 1, pix = e >> 1;
       const bool ok = cbase + kh * 8 + 8 <= a.cin;
+      const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f}, w0 = ok ? r.v0[k] : z, w1 = ok ? r.v1[k] : z;
       f16x8 hi, lo;
-      split8(ok ? r.v0[k] : f32x4{0.f, 0.f, 0.f, 0.f}, ok ? r.v1[k] : f32x4{0.f, 0.f, 0.f, 0.f}, hi, lo);
+      if (a.in_sp) { hi = __builtin_bit_cast(f16x8, w0); lo = __builtin_bit_cast(f16x8, w1); }   // the same 32 bytes hold [8 hi | 8 lo]
+      else split8(w0, w1, hi, lo);
       act[(0 * 2 + kh) * NPP + pix] = __builtin_bit_cast(u32x4, hi);
       act[(1 * 2 + kh) * NPP + pix] = __builtin_bit_cast(u32x4, lo);
     }
@@ -239,8 +209,13 @@ __global__ __launch_bounds__(32 * TH) void conv3x3_f16_kernel(F16Args a) {
           m[r] = a.relu ? fmaxf(v, 0.f) : v;
         }
         const int oy = (ty0 + wave * 2) >> 1, ox = gx >> 1;
-        if (!(li & 1) && oy < Hp && ox < Wp && co < a.cout)
+        const bool ok = !(li & 1) && oy < Hp && ox < Wp && co < a.cout;
+        if (a.out_sp) {
+          const u32x4 w = sp16_pair_exchange(m);
+          if (ok) *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(a.out) + ((size_t)oy * Wp + ox) * a.cout * 4 + (co >> 3) * 32 + kh * 16) = w;
+        } else if (ok) {
           *reinterpret_cast<f32x4*>(a.out + ((size_t)oy * Wp + ox) * a.cout + co) = m;
+        }
       } else {
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
@@ -251,8 +226,13 @@ __global__ __launch_bounds__(32 * TH) void conv3x3_f16_kernel(F16Args a) {
             v[r] = acc[c][p][4 * q + r] * inv + bias[r];
             if (a.relu) v[r] = fmaxf(v[r], 0.f);
           }
-          if (gy < a.H && gx < a.W && co < a.cout)
+          const bool ok = gy < a.H && gx < a.W && co < a.cout;
+          if (a.out_sp) {
+            const u32x4 w = sp16_pair_exchange(v);
+            if (ok) *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(a.out) + ((size_t)gy * a.W + gx) * a.cout * 4 + (co >> 3) * 32 + kh * 16) = w;
+          } else if (ok) {
             *reinterpret_cast<f32x4*>(a.out + ((size_t)gy * a.W + gx) * a.cout + co) = v;
+          }
         }
       }
     }
@@ -335,8 +315,10 @@ __global__ __launch_bounds__(256) void conv3x3_f16_c16_kernel(F16Args a) {
         m[r] = a.relu ? fmaxf(v, 0.f) : v;
       }
       const int oy = (ty0 + wave * 2) >> 1, ox = gx >> 1;
-      if (!(li & 1) && oy < Hp && ox < Wp && co < a.cout)
-        *reinterpret_cast<f32x4*>(a.out + ((size_t)oy * Wp + ox) * a.cout + co) = m;
+      if (!(li & 1) && oy < Hp && ox < Wp && co < a.cout) {
+        if (a.out_sp) sp16_store4(reinterpret_cast<char*>(a.out) + ((size_t)oy * Wp + ox) * a.cout * 4, kq, m);
+        else *reinterpret_cast<f32x4*>(a.out + ((size_t)oy * Wp + ox) * a.cout + co) = m;
+      }
     } else {
 #pragma unroll
       for (int r2 = 0; r2 < 2; ++r2) {
@@ -356,7 +338,8 @@ __global__ __launch_bounds__(256) void conv3x3_f16_c16_kernel(F16Args a) {
               a.out[2 * plane + off] = v[2];
             }
           } else if (co < a.cout) {
-            *reinterpret_cast<f32x4*>(a.out + ((size_t)gy * a.W + gx) * a.cout + co) = v;
+            if (a.out_sp) sp16_store4(reinterpret_cast<char*>(a.out) + ((size_t)gy * a.W + gx) * a.cout * 4, kq, v);
+            else *reinterpret_cast<f32x4*>(a.out + ((size_t)gy * a.W + gx) * a.cout + co) = v;
           }
         }
       }
@@ -384,10 +367,9 @@ struct HeadArgs {   // conv11 (3->16, conv0 folded) + ReLU -> conv12 (16->16) + 
   const u32x4* w11; const float* b11; float inv11;   // [kb][hi/lo][kq][16 couts] x 8 halfs (K layout below)
   const u32x4* w12; const float* b12; float inv12;
   int H, W, tiles_x, tiles_y;
+  int out_sp;
 };
 
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 constexpr int IMG_E = NPI2 + 4;   // 8-byte pixels per plane; the zeroed tail absorbs the "4th pixel" over-read of the last row
 
 // (uniform) true when the 36 x 12 input window of the tile lies inside the image: no reflection anywhere
@@ -609,7 +591,10 @@ __global__ __launch_bounds__(256, 3) void enc_head_kernel(HeadArgs a) {
         m[r] = fmaxf(x, 0.f);
       }
       const int oy = (ty0 + wave * 2) >> 1, ox = gx >> 1;
-      if (!(li & 1) && oy < Hp && ox < Wp) *reinterpret_cast<f32x4*>(a.out + ((size_t)oy * Wp + ox) * 16 + co) = m;
+      if (!(li & 1) && oy < Hp && ox < Wp) {
+        if (a.out_sp) sp16_store4(reinterpret_cast<char*>(a.out) + ((size_t)oy * Wp + ox) * 64, kq, m);
+        else *reinterpret_cast<f32x4*>(a.out + ((size_t)oy * Wp + ox) * 16 + co) = m;
+      }
     }
     if (vn < ntiles) head_commit(pxr, imgH, imgL, tid);   // conv11 of this tile is behind the barrier above
   }
@@ -620,6 +605,7 @@ struct TailArgs {   // conv12 (16->16 on the nearest-x2 upsampled input) + ReLU 
   const u32x4* w12; const float* b12; float inv12; const float* inv12_ptr;
   const u32x4* w11; const float* b11; float inv11;
   int H, W, inW, up_in, tiles_x, tiles_y;
+  int in_sp;
 };
 
 constexpr int TAIL_SL = (NPI2 * 2 + 255) / 256;  // 4 register slots of 8 channels per thread
@@ -652,13 +638,14 @@ __device__ __forceinline__ void tail_fetch(const TailArgs& a, TailRegs& r, const
   }
 }
 
-__device__ __forceinline__ void tail_commit(const TailRegs& r, u32x4* act0, int tid) {
+__device__ __forceinline__ void tail_commit(const TailRegs& r, u32x4* act0, int tid, int in_sp) {
 #pragma unroll
   for (int k = 0; k < TAIL_SL; ++k) {
     const int e = tid + 256 * k;
     if (e < NPI2 * 2) {
       f16x8 hi, lo;
-      split8(r.v0[k], r.v1[k], hi, lo);
+      if (in_sp) { hi = __builtin_bit_cast(f16x8, r.v0[k]); lo = __builtin_bit_cast(f16x8, r.v1[k]); }
+      else split8(r.v0[k], r.v1[k], hi, lo);
       act0[(0 * 2 + (e & 1)) * NPI2 + (e >> 1)] = __builtin_bit_cast(u32x4, hi);
       act0[(1 * 2 + (e & 1)) * NPI2 + (e >> 1)] = __builtin_bit_cast(u32x4, lo);
     }
@@ -709,7 +696,7 @@ __global__ __launch_bounds__(256, 2) void dec_tail_kernel(TailArgs a) {
   int v = blockIdx.x;
   if (v < ntiles) {
     tail_fetch(a, tr, soff, xcd_swizzle(v, ntiles), tid);
-    tail_commit(tr, act0, tid);
+    tail_commit(tr, act0, tid, a.in_sp);
   }
   for (; v < ntiles; v += gridDim.x) {
     const int tile = xcd_swizzle(v, ntiles);
@@ -787,7 +774,7 @@ __global__ __launch_bounds__(256, 2) void dec_tail_kernel(TailArgs a) {
         }
       }
     }
-    if (vn < ntiles) tail_commit(tr, act0, tid);   // conv12 of this tile is behind the barrier above
+    if (vn < ntiles) tail_commit(tr, act0, tid, a.in_sp);   // conv12 of this tile is behind the barrier above
   }
 }
 
@@ -857,15 +844,6 @@ bool conv_fusable_tail(const ConvDesc& d0, const ConvDesc& d1) {
          !(d1.flags & (CONV_UP_IN | CONV_NO_RELU)) && !d1.inv_scale_ptr;
 }
 
-int num_cus() {
-  static int n = [] {
-    int dev = 0, v = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v < 1) v = 256;
-    return v;
-  }();
-  return n;
-}
-
 hipError_t launch_enc_head(const ConvDesc& d0, const ConvDesc& d1, const float* img, float* out, int H, int W, hipStream_t s) {
   if (!conv_fusable_head(d0, d1) || H < 2 || W < 2) return hipErrorInvalidValue;
   HeadArgs a;
@@ -873,6 +851,7 @@ hipError_t launch_enc_head(const ConvDesc& d0, const ConvDesc& d1, const float* 
   a.w11 = reinterpret_cast<const u32x4*>(d0.wpk16); a.b11 = d0.bias; a.inv11 = d0.inv_scale;
   a.w12 = reinterpret_cast<const u32x4*>(d1.wpk16); a.b12 = d1.bias; a.inv12 = d1.inv_scale;
   a.H = H; a.W = W; a.tiles_x = (W + FTW - 1) / FTW; a.tiles_y = (H + 7) / 8;
+  a.out_sp = (d1.flags & CONV_OUT_SP16) ? 1 : 0;
   const size_t lds = (size_t)2 * IMG_E * 8 + (size_t)4 * npp(8) * 16 + 640 * 16;   // 39.7 KB: 4 workgroups per CU
   const int ntiles = a.tiles_x * a.tiles_y, grid = ntiles < 3 * num_cus() ? ntiles : 3 * num_cus();
   hipLaunchKernelGGL(enc_head_kernel, dim3(grid), dim3(256), lds, s, a);
@@ -886,6 +865,7 @@ hipError_t launch_dec_tail(const ConvDesc& d0, const ConvDesc& d1, const float* 
   a.w12 = reinterpret_cast<const u32x4*>(d0.wpk16); a.b12 = d0.bias; a.inv12 = d0.inv_scale; a.inv12_ptr = d0.inv_scale_ptr;
   a.w11 = reinterpret_cast<const u32x4*>(d1.wpk16); a.b11 = d1.bias; a.inv11 = d1.inv_scale;
   a.H = H; a.W = W; a.up_in = (d0.flags & CONV_UP_IN) ? 1 : 0; a.inW = a.up_in ? W / 2 : W;
+  a.in_sp = (d0.flags & CONV_IN_SP16) ? 1 : 0;
   a.tiles_x = (W + FTW - 1) / FTW; a.tiles_y = (H + 7) / 8;
   const size_t lds = ((size_t)4 * NPI2 + 640 + (size_t)4 * npp(8) + 640) * 16;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(dec_tail_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -923,7 +903,9 @@ hipError_t launch_conv3x3_f16(const ConvDesc& d, const float* in, float* out, in
   a.cin = d.cin; a.cout = d.cout; a.cin_chunks = d.cin_chunks; a.cout_pad = d.cout_pad;
   a.tiles_x = (W + FTW - 1) / FTW; a.tiles_y = (H + 7) / 8;
   a.relu = (d.flags & CONV_NO_RELU) ? 0 : 1;
+  a.in_sp = (d.flags & CONV_IN_SP16) ? 1 : 0; a.out_sp = (d.flags & CONV_OUT_SP16) ? 1 : 0;
   const bool pool = d.flags & CONV_POOL_OUT, out3 = d.flags & CONV_OUT_NCHW3;
+  if (out3 && a.out_sp) return hipErrorInvalidValue;
   const size_t act_b = (size_t)4 * npp(8) * 16;
   if (d.cout_pad == 16) {
     a.taps = 10;

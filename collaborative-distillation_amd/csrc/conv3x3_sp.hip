@@ -1,0 +1,256 @@
+// reflect-pad(1) + conv3x3 + bias + ReLU (+ fused nearest-x2 input / 2x2 max-pool output) on SP16 activations:
+// the interior layers of the encoders / decoders in f16x3 mode (conv3x3_f16.hip explains the split arithmetic;
+// conv_f16_dev.h the SP16 format).  Same results, bit for bit, as conv3x3_f16_kernel on the fp32 form of the input.
+//
+// What SP16 buys: the consumer no longer converts anything.  Activation halo tiles AND weight slabs go
+// global -> LDS by DMA (global_load_lds_dwordx4: per-lane global address, wave-uniform LDS base + lane * 16), so
+// staging costs no VGPRs, no VALU and no ds_write, and a 16-channel chunk can be in flight into the second LDS
+// stage while the matrix cores work on the first:
+//
+//   persistent workgroup (one per CU, 8 waves = 32 x 16 output pixels, wave w owns rows 2w, 2w+1), job list =
+//   (tile, cout group, 16-channel chunk) in that order; per job
+//       s_waitcnt vmcnt(0); s_barrier      -- this job's stage has landed for every wave, the other stage is free
+//       issue the DMA of the NEXT job      -- also across tile boundaries: no exposed prologue
+//       9 taps x CT x 2 x 3 MFMAs (32x32x16 f16) on this stage; epilogue after a tile's last chunk
+//   ONE barrier per chunk (the register-staged kernel needs two and converts between them).
+//
+// LDS (16-B units): stage = act[hl][kh][640] (612 halo pixels of the 34 x 18 tile, padded to 10 DMA blocks of 64)
+//                          + wgt[tap][hl][kh][COW];  2 stages + bias = 154 KB at COW = 64.
+// Plane / segment strides are multiples of 256 B and consecutive lanes read consecutive 16-B slots: every MFMA
+// operand is one conflict-free ds_read_b128, as in conv3x3_f16.hip.
+// 128 and more couts run as cout groups of 64 (the activation tile is re-read from L2 per group; a 128-wide weight
+// slab would not leave room for the second stage).
+#include "wct_common.h"
+#include "conv_f16_dev.h"
+
+namespace {
+
+constexpr int SPH = 16;
+constexpr int SP_NPH = FHW * (SPH + 2);      // 612
+constexpr int SP_NBLK = (SP_NPH + 63) / 64;  // 10
+constexpr int SP_NPP = SP_NBLK * 64;         // 640 (10240 B == 0 mod 256)
+constexpr int SP_ACT_DMA = 4 * SP_NBLK;      // 40 wave-instructions per chunk for the activations
+constexpr int SP_ACT_PER_WAVE = SP_ACT_DMA / 8;
+
+struct SpArgs {
+  const char* in;        // SP16 [inH * inW][cin / 8][hi 8 | lo 8] halfs
+  char* out;             // SP16 or fp32 NHWC
+  const u32x4* wpk;      // [chunk][9][hl][kh][cout_pad] x 16 B
+  const float* bias;     // [cout_pad]
+  const float* inv_scale_ptr;
+  float inv_scale;
+  int H, W, inW;
+  int cin, cout, cin_chunks, cout_pad, groups;
+  int tiles_x, tiles_y, up_in, relu;
+};
+
+typedef __attribute__((address_space(3))) void* lds_ptr;
+
+template <int CT, bool POOL, bool OUTF32>
+__global__ __launch_bounds__(512) void conv3x3_sp_kernel(SpArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int COW = CT * 32;
+  constexpr int STAGE16 = 4 * SP_NPP + 36 * COW;
+  constexpr int W_DMA = 36 * COW / 64;                 // weight wave-instructions per chunk (36 / 18)
+  constexpr int W_PER_WAVE = (W_DMA + 7) / 8;
+  u32x4* lds = reinterpret_cast<u32x4*>(smem);
+  float* biasL = reinterpret_cast<float*>(lds + 2 * STAGE16);   // [cout_pad]
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, kh = lane >> 5;
+  const int ntiles = a.tiles_x * a.tiles_y;
+  for (int e = tid; e < a.cout_pad; e += 512) biasL[e] = a.bias[e];
+  const float inv = a.inv_scale_ptr ? *a.inv_scale_ptr : a.inv_scale;
+  const size_t rec_in = (size_t)a.cin * 4;
+
+  // ---- DMA of one job into a stage.  Activations: wave-instruction idx = wave + 8 i covers pixel block idx % 10 of
+  // plane idx / 10; each lane's pixel offset for the wave's five blocks is recomputed when the tile changes.
+  size_t poff[SP_ACT_PER_WAVE];
+  auto tile_offsets = [&](int tile) {
+    const int ty0 = (tile / a.tiles_x) * SPH, tx0 = (tile % a.tiles_x) * FTW;
+#pragma unroll
+    for (int i = 0; i < SP_ACT_PER_WAVE; ++i) {
+      const int blk = (wave + 8 * i) % SP_NBLK;
+      int pix = blk * 64 + lane;
+      pix = pix < SP_NPH ? pix : SP_NPH - 1;
+      const int py = pix / FHW, px = pix - py * FHW;
+      int gy = reflect_clamp(ty0 - 1 + py, a.H), gx = reflect_clamp(tx0 - 1 + px, a.W);
+      if (a.up_in) { gy >>= 1; gx >>= 1; }
+      poff[i] = ((size_t)gy * a.inW + gx) * rec_in;
+    }
+  };
+  auto issue = [&](int ch, int grp, int stage) {
+    u32x4* act = lds + stage * STAGE16;
+    u32x4* wgt = act + 4 * SP_NPP;
+#pragma unroll
+    for (int i = 0; i < SP_ACT_PER_WAVE; ++i) {
+      const int idx = wave + 8 * i, blk = idx % SP_NBLK, q = idx / SP_NBLK;   // q = hl * 2 + kh
+      const char* g = a.in + poff[i] + ch * 64 + (q & 1) * 32 + (q >> 1) * 16;
+      __builtin_amdgcn_global_load_lds(g, (lds_ptr)(act + q * SP_NPP + blk * 64), 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < W_PER_WAVE; ++i) {
+      const int idx = wave + 8 * i;
+      if (idx < W_DMA) {
+        const u32x4* g;
+        if constexpr (COW == 64) g = a.wpk + ((size_t)(ch * 36 + idx) * a.cout_pad + grp * 64 + lane);
+        else g = a.wpk + ((size_t)(ch * 36 + idx * 2 + (lane >> 5)) * a.cout_pad + grp * 32 + (lane & 31));
+        __builtin_amdgcn_global_load_lds(g, (lds_ptr)(wgt + idx * 64), 16, 0, 0);
+      }
+    }
+  };
+
+  f32x16 acc[CT][2];
+  // job state (uniform): virtual tile index v (this workgroup walks v, v + grid, ...), cout group, chunk
+  int v = blockIdx.x, grp = 0, ch = 0, stage = 0;
+  if (v >= ntiles) return;
+  int tile = xcd_swizzle(v, ntiles);
+  int dma_tile = tile;          // tile the offsets in poff[] belong to
+  tile_offsets(tile);
+  issue(0, 0, 0);
+  while (true) {
+    // next job
+    int nv = v, ngrp = grp, nch = ch + 1;
+    if (nch == a.cin_chunks) { nch = 0; ++ngrp; if (ngrp == a.groups) { ngrp = 0; nv = v + gridDim.x; } }
+    const bool more = nv < ntiles;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (more) {
+      const int ntile = nv == v ? tile : xcd_swizzle(nv, ntiles);
+      if (ntile != dma_tile) { tile_offsets(ntile); dma_tile = ntile; }
+      issue(nch, ngrp, stage ^ 1);
+    }
+    if (ch == 0) {
+#pragma unroll
+      for (int c = 0; c < CT; ++c)
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[c][p][r] = 0.f;
+    }
+    const u32x4* act = lds + stage * STAGE16;
+    const u32x4* wgt = act + 4 * SP_NPP;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int dy = tap / 3, dx = tap - dy * 3;
+      f16x8 bh[2], bl[2];
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        const int pix = (wave * 2 + p + dy) * FHW + li + dx;
+        bh[p] = __builtin_bit_cast(f16x8, act[(0 * 2 + kh) * SP_NPP + pix]);
+        bl[p] = __builtin_bit_cast(f16x8, act[(1 * 2 + kh) * SP_NPP + pix]);
+      }
+      f16x8 ah[CT], al[CT];
+#pragma unroll
+      for (int c = 0; c < CT; ++c) {
+        ah[c] = __builtin_bit_cast(f16x8, wgt[((tap * 2 + 0) * 2 + kh) * COW + c * 32 + li]);
+        al[c] = __builtin_bit_cast(f16x8, wgt[((tap * 2 + 1) * 2 + kh) * COW + c * 32 + li]);
+      }
+#pragma unroll
+      for (int term = 0; term < 3; ++term)
+#pragma unroll
+        for (int c = 0; c < CT; ++c)
+#pragma unroll
+          for (int p = 0; p < 2; ++p)
+            acc[c][p] = __builtin_amdgcn_mfma_f32_32x32x16_f16(term == 2 ? al[c] : ah[c], term == 1 ? bl[p] : bh[p], acc[c][p], 0, 0, 0);
+    }
+
+    if (ch + 1 == a.cin_chunks) {
+      // ---- epilogue.  D: col = lane & 31 (pixel), row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) (cout)
+      const int ty0 = (tile / a.tiles_x) * SPH, tx0 = (tile % a.tiles_x) * FTW;
+      const int gx = tx0 + li;
+      const int oH = POOL ? a.H >> 1 : a.H, oW = POOL ? a.W >> 1 : a.W;
+#pragma unroll
+      for (int c = 0; c < CT; ++c) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int co = grp * COW + c * 32 + 8 * q + 4 * kh;
+          const f32x4 bias = *reinterpret_cast<const f32x4*>(biasL + co);
+          if constexpr (POOL) {
+            f32x4 m;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              float x = fmaxf(acc[c][0][4 * q + r], acc[c][1][4 * q + r]);
+              x = fmaxf(x, __shfl_xor(x, 1));
+              x = x * inv + bias[r];
+              m[r] = a.relu ? fmaxf(x, 0.f) : x;
+            }
+            const int oy = (ty0 + wave * 2) >> 1, ox = gx >> 1;
+            const bool ok = !(li & 1) && oy < oH && ox < oW && co < a.cout;
+            if constexpr (OUTF32) {
+              if (ok) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.out) + ((size_t)oy * oW + ox) * a.cout + co) = m;
+            } else {
+              const u32x4 w = sp16_pair_exchange(m);
+              if (ok) *reinterpret_cast<u32x4*>(a.out + ((size_t)oy * oW + ox) * a.cout * 4 + (co >> 3) * 32 + kh * 16) = w;
+            }
+          } else {
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+              const int gy = ty0 + wave * 2 + p;
+              f32x4 x;
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                x[r] = acc[c][p][4 * q + r] * inv + bias[r];
+                if (a.relu) x[r] = fmaxf(x[r], 0.f);
+              }
+              const bool ok = gy < oH && gx < oW && co < a.cout;
+              if constexpr (OUTF32) {
+                if (ok) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.out) + ((size_t)gy * oW + gx) * a.cout + co) = x;
+              } else {
+                const u32x4 w = sp16_pair_exchange(x);
+                if (ok) *reinterpret_cast<u32x4*>(a.out + ((size_t)gy * oW + gx) * a.cout * 4 + (co >> 3) * 32 + kh * 16) = w;
+              }
+            }
+          }
+        }
+      }
+    }
+    if (!more) break;
+    if (nv != v) { v = nv; tile = dma_tile; }
+    grp = ngrp; ch = nch; stage ^= 1;
+  }
+}
+
+template <typename K>
+hipError_t launch_sp(K k, const SpArgs& a, size_t lds, hipStream_t s) {
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  const int ntiles = a.tiles_x * a.tiles_y, grid = ntiles < num_cus() ? ntiles : num_cus();
+  hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds, s, a);
+  return hipGetLastError();
+}
+
+}  // namespace
+
+bool conv_sp_supported(const ConvDesc& d) {
+  return d.wpk16 && !(d.flags & (CONV_IN_NCHW3 | CONV_OUT_NCHW3)) && (d.cin % 16) == 0 && d.cout_pad >= 32 && (d.cout % 8) == 0 &&
+         d.cout_pad <= 512;
+}
+
+// in: SP16 (CONV_IN_SP16 must be set); out: SP16 (CONV_OUT_SP16) or fp32 NHWC
+hipError_t launch_conv3x3_sp(const ConvDesc& d, const void* in, void* out, int H, int W, hipStream_t s) {
+  if (H < 2 || W < 2 || !conv_sp_supported(d) || !(d.flags & CONV_IN_SP16)) return hipErrorInvalidValue;
+  SpArgs a;
+  a.in = reinterpret_cast<const char*>(in); a.out = reinterpret_cast<char*>(out);
+  a.wpk = reinterpret_cast<const u32x4*>(d.wpk16); a.bias = d.bias;
+  a.inv_scale_ptr = d.inv_scale_ptr; a.inv_scale = d.inv_scale;
+  a.H = H; a.W = W;
+  a.up_in = (d.flags & CONV_UP_IN) ? 1 : 0;
+  a.inW = a.up_in ? W / 2 : W;
+  a.cin = d.cin; a.cout = d.cout; a.cin_chunks = d.cin_chunks; a.cout_pad = d.cout_pad;
+  a.tiles_x = (W + FTW - 1) / FTW; a.tiles_y = (H + SPH - 1) / SPH;
+  a.relu = (d.flags & CONV_NO_RELU) ? 0 : 1;
+  const bool pool = d.flags & CONV_POOL_OUT, f32 = !(d.flags & CONV_OUT_SP16);
+  const int ct = (d.cout_pad % 64 == 0) ? 2 : 1;
+  a.groups = d.cout_pad / (ct * 32);
+  const size_t lds = (size_t)2 * (4 * SP_NPP + 36 * ct * 32) * 16 + (size_t)d.cout_pad * sizeof(float);
+#define WCT_SP_CASE(CTV)                                                                                              \
+  if (ct == CTV) {                                                                                                    \
+    if (pool) return f32 ? launch_sp(conv3x3_sp_kernel<CTV, true, true>, a, lds, s) : launch_sp(conv3x3_sp_kernel<CTV, true, false>, a, lds, s); \
+    return f32 ? launch_sp(conv3x3_sp_kernel<CTV, false, true>, a, lds, s) : launch_sp(conv3x3_sp_kernel<CTV, false, false>, a, lds, s);         \
+  }
+  WCT_SP_CASE(1)
+  WCT_SP_CASE(2)
+#undef WCT_SP_CASE
+  return hipErrorInvalidValue;
+}

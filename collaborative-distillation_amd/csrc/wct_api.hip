@@ -60,6 +60,7 @@ struct wct_ctx {
   // workspace
   DevBuf featC, featS, tmpT, wsAsm, small, foldW, foldW16, eigC, eigS[6];
   int cur_level = 0, cur_h = 0, cur_w = 0;  // content feature held in featC by wct_content_encode
+  int sp = 1;         // 1: intermediate activations of the f16x3 path in SP16 (split at the producer, DMA-staged consumers)
   int fuse = 1;       // 1: fused conv11+conv12+pool / conv12+conv11 kernels at the full-resolution ends of the 16x networks
   int overlap = 1;    // 1: style side on the side lane (overlaps the content side); 0: everything on the caller's stream
   int conv_mode = 1;  // 0: exact-fp32 MFMA everywhere; 1: split-f16 (f16x3) MFMA for all but the first conv
@@ -153,17 +154,25 @@ void prof_collect(wct_ctx* ctx) {
 }
 
 // ---- one conv launch, with algorithmic work accounting ---------------------------------------------
+bool conv_runs_f16(const wct_ctx* ctx, const ConvDesc& d) {
+  return ctx->conv_mode == 1 && d.wpk16 && !(d.flags & CONV_IN_NCHW3) && !(d.cin & 7);
+}
+
 int run_conv(wct_ctx* ctx, Lane& ln, const ConvDesc& d, const float* in, float* out, int H, int W) {
   char name[48];
-  const bool f16 = ctx->conv_mode == 1 && d.wpk16 && !(d.flags & CONV_IN_NCHW3) && !(d.cin & 7);
-  snprintf(name, sizeof name, "conv3x3%s<co=%d%s%s%s>", f16 ? "_f16x3" : "_f32", d.cout_pad > 128 ? 128 : d.cout_pad,
-           (d.flags & CONV_IN_NCHW3) ? ",in3" : "", (d.flags & CONV_POOL_OUT) ? ",pool" : "", (d.flags & CONV_OUT_NCHW3) ? ",out3" : "");
+  const bool f16 = conv_runs_f16(ctx, d);
+  const bool spk = f16 && (d.flags & CONV_IN_SP16) && conv_sp_supported(d);   // DMA-staged persistent kernel
+  if (!f16 && (d.flags & (CONV_IN_SP16 | CONV_OUT_SP16))) return fail(ctx, WCT_ERR_INVALID, "SP16 activations need the f16x3 path");
+  snprintf(name, sizeof name, "conv3x3%s<co=%d%s%s%s%s>", f16 ? "_f16x3" : "_f32", d.cout_pad > 128 ? 128 : d.cout_pad,
+           (d.flags & CONV_IN_NCHW3) ? ",in3" : "", (d.flags & CONV_POOL_OUT) ? ",pool" : "", (d.flags & CONV_OUT_NCHW3) ? ",out3" : "",
+           spk ? ",dma" : "");
   const double px = (double)H * W;
   const double in_px = (d.flags & CONV_UP_IN) ? px / 4 : px, out_px = (d.flags & CONV_POOL_OUT) ? px / 4 : px;
   const double flops = 2.0 * 9 * d.cin * d.cout * px;
   const double bytes = 4.0 * (in_px * d.cin + out_px * d.cout + 9.0 * d.cin * d.cout);
   ProfScope ps(ctx, ln.stream, name, flops, bytes);
-  if (f16) HIPCHK(ctx, launch_conv3x3_f16(d, in, out, H, W, ln.stream));
+  if (spk) HIPCHK(ctx, launch_conv3x3_sp(d, in, out, H, W, ln.stream));
+  else if (f16) HIPCHK(ctx, launch_conv3x3_f16(d, in, out, H, W, ln.stream));
   else HIPCHK(ctx, launch_conv3x3(d, in, out, H, W, ln.stream));
   return WCT_OK;
 }
@@ -302,13 +311,22 @@ int encode_impl(wct_ctx* ctx, Lane& ln, int level, const float* img, int H, int 
   const float* cur = img;
   int h = H, w = W;
   size_t i0 = 0;
+  // SP16 between f16x3 layers: a layer writes SP16 when it is not the last one and its consumer runs in f16x3
+  const bool sp = ctx->conv_mode == 1 && ctx->sp;
+  bool cur_sp = false;
+  auto wants_sp = [&](size_t i) {   // may layer i's output be SP16?
+    return sp && i + 1 < m.layers.size() && (m.layers[i].d.cout % 8) == 0 && conv_runs_f16(ctx, m.layers[i + 1].d);
+  };
   if (ctx->conv_mode == 1 && ctx->fuse && m.layers.size() >= 2 && conv_fusable_head(m.layers[0].d, m.layers[1].d)) {
     // conv11 + conv12 + pool in one kernel: the 64 B/px intermediate never leaves LDS
     const bool last = m.layers.size() == 2;
     float* dst = last ? feat_nhwc : reinterpret_cast<float*>(ln.actB.p);
     const double px = (double)h * w;
+    ConvDesc d1 = m.layers[1].d;
+    cur_sp = wants_sp(1);
+    if (cur_sp) d1.flags |= CONV_OUT_SP16;
     ProfScope ps(ctx, ln.stream, "enc_head_fused<3-16-16,pool>", 2.0 * 9 * (3 * 16 + 16 * 16) * px, 4.0 * (3 * px + 16 * px / 4));
-    HIPCHK(ctx, launch_enc_head(m.layers[0].d, m.layers[1].d, cur, dst, h, w, ln.stream));
+    HIPCHK(ctx, launch_enc_head(m.layers[0].d, d1, cur, dst, h, w, ln.stream));
     h /= 2; w /= 2;
     cur = dst;
     i0 = 2;
@@ -317,9 +335,14 @@ int encode_impl(wct_ctx* ctx, Lane& ln, int level, const float* img, int H, int 
     const auto& l = m.layers[i];
     const bool last = i + 1 == m.layers.size();
     float* dst = last ? feat_nhwc : reinterpret_cast<float*>((i & 1) ? ln.actB.p : ln.actA.p);
-    if (int rc = run_conv(ctx, ln, l.d, cur, dst, h, w)) return rc;
+    ConvDesc d = l.d;
+    const bool out_sp = conv_runs_f16(ctx, d) && wants_sp(i);
+    if (cur_sp) d.flags |= CONV_IN_SP16;
+    if (out_sp) d.flags |= CONV_OUT_SP16;
+    if (int rc = run_conv(ctx, ln, d, cur, dst, h, w)) return rc;
     if (l.pool_after) { h /= 2; w /= 2; }
     cur = dst;
+    cur_sp = out_sp;
   }
   if (ho) *ho = h;
   if (wo) *wo = w;
@@ -338,11 +361,14 @@ int decode_impl(wct_ctx* ctx, int level, const float* feat, int h, int w, const 
   const float* cur = feat;
   int ch = h, cw = w;
   const size_t n = m.layers.size();
+  const bool sp = ctx->conv_mode == 1 && ctx->sp;
+  bool cur_sp = false;
   for (size_t i = 0; i < n; ++i) {
     const auto& l = m.layers[i];
     const bool last = i + 1 == n;
     ConvDesc d = (i == 0 && first) ? *first : l.d;
     if (i > 0 && m.layers[i - 1].up_after) { ch *= 2; cw *= 2; }
+    if (cur_sp) d.flags |= CONV_IN_SP16;
     if (ctx->conv_mode == 1 && ctx->fuse && i + 2 == n && conv_fusable_tail(d, m.layers[i + 1].d)) {
       // conv12 + conv11 in one kernel: the 64 B/px intermediate never leaves LDS
       const double px = (double)ch * cw;
@@ -351,9 +377,12 @@ int decode_impl(wct_ctx* ctx, int level, const float* feat, int h, int w, const 
       HIPCHK(ctx, launch_dec_tail(d, m.layers[i + 1].d, cur, img, ch, cw, ln.stream));
       break;
     }
+    const bool out_sp = sp && !last && conv_runs_f16(ctx, d) && (d.cout % 8) == 0 && conv_runs_f16(ctx, m.layers[i + 1].d);
+    if (out_sp) d.flags |= CONV_OUT_SP16;
     float* dst = last ? img : reinterpret_cast<float*>((i & 1) ? ln.actB.p : ln.actA.p);
     if (int rc = run_conv(ctx, ln, d, cur, dst, ch, cw)) return rc;
     cur = dst;
+    cur_sp = out_sp;
   }
   return WCT_OK;
 }
@@ -520,6 +549,7 @@ int wct_create(int device, wct_ctx** out) {
   if (const char* m = getenv("WCT_CONV_MODE")) c->conv_mode = (m[0] == '0' || !strcmp(m, "fp32")) ? 0 : 1;
   if (const char* m = getenv("WCT_OVERLAP")) c->overlap = m[0] != '0';
   if (const char* m = getenv("WCT_FUSE")) c->fuse = m[0] != '0';
+  if (const char* m = getenv("WCT_SP")) c->sp = m[0] != '0';
   bool ok = hipStreamCreateWithFlags(&c->side.stream, hipStreamNonBlocking) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess;
   for (int l = 1; l <= 5 && ok; ++l) ok = hipEventCreateWithFlags(&c->ev_style[l], hipEventDisableTiming) == hipSuccess;

@@ -14,6 +14,8 @@ enum ConvFlags : int {
   CONV_POOL_OUT = 4,   // write max over 2x2 (floor mode) instead of the full-resolution output
   CONV_OUT_NCHW3 = 8,  // output is a planar 3xHxW image (last decoder conv)
   CONV_NO_RELU = 16,   // affine only (used by wct_apply: centre-tap 1x1)
+  CONV_IN_SP16 = 32,   // input is in the split-f16 SP16 format (conv_f16_dev.h) instead of fp32 NHWC
+  CONV_OUT_SP16 = 64,  // output is written in SP16
 };
 
 struct ConvDesc {
@@ -36,10 +38,13 @@ hipError_t launch_conv3x3(const ConvDesc& d, const float* in, float* out, int H,
 
 hipError_t launch_conv3x3_f16(const ConvDesc& d, const float* in, float* out, int H, int W, hipStream_t s);
 size_t conv_f16_weight_bytes(int cin, int cout_pad, int taps);
+// SP16-input layers with >= 32 couts: persistent DMA-staged kernel (conv3x3_sp.hip)
+bool conv_sp_supported(const ConvDesc& d);
+hipError_t launch_conv3x3_sp(const ConvDesc& d, const void* in, void* out, int H, int W, hipStream_t s);
 // fused full-resolution ends of the 16x networks (conv11+conv12+pool / conv12+conv11): see conv3x3_f16.hip
 bool conv_fusable_head(const ConvDesc& d0, const ConvDesc& d1);
 bool conv_fusable_tail(const ConvDesc& d0, const ConvDesc& d1);
-hipError_t launch_enc_head(const ConvDesc& d0, const ConvDesc& d1, const float* img, float* out, int H, int W, hipStream_t s);
+hipError_t launch_enc_head(const ConvDesc& d0, const ConvDesc& d1, const float* img, float* out, int H, int W, hipStream_t s);   // d1.flags & CONV_OUT_SP16
 hipError_t launch_dec_tail(const ConvDesc& d0, const ConvDesc& d1, const float* in, float* out, int H, int W, hipStream_t s);
 // fp32 packed weights (device) -> scaled split-f16 packed weights + inverse scale (device scalar)
 hipError_t launch_split_pack(const float* wpk32, int cin, int cout_pad, int taps, unsigned* maxbits_dev, void* out,
