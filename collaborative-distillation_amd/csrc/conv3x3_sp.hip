@@ -10,9 +10,13 @@
 //   persistent workgroup (one per CU, 8 waves = 32 x 16 output pixels, wave w owns rows 2w, 2w+1), job list =
 //   (tile, cout group, 16-channel chunk) in that order; per job
 //       s_waitcnt vmcnt(0); s_barrier      -- this job's stage has landed for every wave, the other stage is free
-//       issue the DMA of the NEXT job      -- also across tile boundaries: no exposed prologue
-//       9 taps x CT x 2 x 3 MFMAs (32x32x16 f16) on this stage; epilogue after a tile's last chunk
+//       9 taps x CT x 2 x 3 MFMAs (32x32x16 f16) on this stage, and INSIDE the tap loop, a slice per tap,
+//         - the DMA of the NEXT job (also across tile boundaries: no exposed prologue)
+//         - the epilogue of the PREVIOUS tile (its accumulators are parked in registers when its last chunk ends)
 //   ONE barrier per chunk (the register-staged kernel needs two and converts between them).
+//   Why the epilogue is deferred: persistent workgroups with equal job lists run in lockstep, so an epilogue at the
+//   tile boundary makes all 256 CUs store at once (measured: 20-45 k cycles per tile with the matrix cores idle, HBM
+//   write-bound) and then all compute with HBM idle.  Spread over the next tile's MFMAs the stores are free.
 //
 // LDS (16-B units): stage = act[hl][kh][640] (612 halo pixels of the 34 x 18 tile, padded to 10 DMA blocks of 64)
 //                          + wgt[tap][hl][kh][COW];  2 stages + bias = 154 KB at COW = 64.
@@ -22,6 +26,7 @@
 // slab would not leave room for the second stage).
 #include "wct_common.h"
 #include "conv_f16_dev.h"
+#include <cstdlib>
 
 namespace {
 
@@ -30,7 +35,6 @@ constexpr int SP_NPH = FHW * (SPH + 2);      // 612
 constexpr int SP_NBLK = (SP_NPH + 63) / 64;  // 10
 constexpr int SP_NPP = SP_NBLK * 64;         // 640 (10240 B == 0 mod 256)
 constexpr int SP_ACT_DMA = 4 * SP_NBLK;      // 40 wave-instructions per chunk for the activations
-constexpr int SP_ACT_PER_WAVE = SP_ACT_DMA / 8;
 
 struct SpArgs {
   const char* in;        // SP16 [inH * inW][cin / 8][hi 8 | lo 8] halfs
@@ -46,19 +50,24 @@ struct SpArgs {
 
 typedef __attribute__((address_space(3))) void* lds_ptr;
 
+// (A 16-wave variant -- each wave one cout tile, four waves per SIMD -- was measured 25 % SLOWER: spills at the 128
+// VGPR cap, 1.5x the LDS operand reads and a 16-wave barrier.  Kept out.)
 template <int CT, bool POOL, bool OUTF32>
 __global__ __launch_bounds__(512) void conv3x3_sp_kernel(SpArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int COW = CT * 32;
+  constexpr int NWV = 8, CPW = CT;                     // waves per workgroup, cout tiles per wave
   constexpr int STAGE16 = 4 * SP_NPP + 36 * COW;
   constexpr int W_DMA = 36 * COW / 64;                 // weight wave-instructions per chunk (36 / 18)
-  constexpr int W_PER_WAVE = (W_DMA + 7) / 8;
+  constexpr int W_PER_WAVE = (W_DMA + NWV - 1) / NWV;
+  constexpr int SP_ACT_PER_WAVE = (SP_ACT_DMA + NWV - 1) / NWV;
   u32x4* lds = reinterpret_cast<u32x4*>(smem);
   float* biasL = reinterpret_cast<float*>(lds + 2 * STAGE16);   // [cout_pad]
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, kh = lane >> 5;
+  const int rw = wave, c0 = 0;                               // row pair / first cout tile of this wave
   const int ntiles = a.tiles_x * a.tiles_y;
-  for (int e = tid; e < a.cout_pad; e += 512) biasL[e] = a.bias[e];
+  for (int e = tid; e < a.cout_pad; e += NWV * 64) biasL[e] = a.bias[e];
   const float inv = a.inv_scale_ptr ? *a.inv_scale_ptr : a.inv_scale;
   const size_t rec_in = (size_t)a.cin * 4;
 
@@ -69,7 +78,9 @@ __global__ __launch_bounds__(512) void conv3x3_sp_kernel(SpArgs a) {
     const int ty0 = (tile / a.tiles_x) * SPH, tx0 = (tile % a.tiles_x) * FTW;
 #pragma unroll
     for (int i = 0; i < SP_ACT_PER_WAVE; ++i) {
-      const int blk = (wave + 8 * i) % SP_NBLK;
+      int idx = wave + NWV * i;
+      idx = idx < SP_ACT_DMA ? idx : SP_ACT_DMA - 1;
+      const int blk = idx % SP_NBLK;
       int pix = blk * 64 + lane;
       pix = pix < SP_NPH ? pix : SP_NPH - 1;
       const int py = pix / FHW, px = pix - py * FHW;
@@ -78,35 +89,80 @@ __global__ __launch_bounds__(512) void conv3x3_sp_kernel(SpArgs a) {
       poff[i] = ((size_t)gy * a.inW + gx) * rec_in;
     }
   };
-  auto issue = [&](int ch, int grp, int stage) {
+  // slice i (0 .. SP_ACT_PER_WAVE - 1) of a job's DMA: one activation and (if any is left) one weight wave-instruction
+  auto issue_slice = [&](int i, int ch, int grp, int stage) {
     u32x4* act = lds + stage * STAGE16;
     u32x4* wgt = act + 4 * SP_NPP;
-#pragma unroll
-    for (int i = 0; i < SP_ACT_PER_WAVE; ++i) {
-      const int idx = wave + 8 * i, blk = idx % SP_NBLK, q = idx / SP_NBLK;   // q = hl * 2 + kh
+    {
+      int idx = wave + NWV * i;
+      idx = idx < SP_ACT_DMA ? idx : SP_ACT_DMA - 1;   // surplus waves re-send the last block (same bytes, same place)
+      const int blk = idx % SP_NBLK, q = idx / SP_NBLK;   // q = hl * 2 + kh
       const char* g = a.in + poff[i] + ch * 64 + (q & 1) * 32 + (q >> 1) * 16;
       __builtin_amdgcn_global_load_lds(g, (lds_ptr)(act + q * SP_NPP + blk * 64), 16, 0, 0);
     }
+    if (i < W_PER_WAVE) {
+      int idx = wave + NWV * i;
+      idx = idx < W_DMA ? idx : W_DMA - 1;
+      const u32x4* g;
+      if constexpr (COW == 64) g = a.wpk + ((size_t)(ch * 36 + idx) * a.cout_pad + grp * 64 + lane);
+      else g = a.wpk + ((size_t)(ch * 36 + idx * 2 + (lane >> 5)) * a.cout_pad + grp * 32 + (lane & 31));
+      __builtin_amdgcn_global_load_lds(g, (lds_ptr)(wgt + idx * 64), 16, 0, 0);
+    }
+  };
+  static_assert(W_PER_WAVE <= SP_ACT_PER_WAVE, "weight slices ride on the activation slices");
+
+  // ---- one piece (cout tile c, 8-channel group q, tile row p) of a finished tile's epilogue.
+  // D: col = lane & 31 (pixel), row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) (cout)
+  constexpr int NPIECE = CPW * 4 * (POOL ? 1 : 2);
+  constexpr int PPT = (NPIECE + 8) / 9;              // pieces per tap: 16 -> 2, 8 / 4 -> 1
+  auto epilogue_piece = [&](const f32x16 (&r)[CPW][2], int piece, int ptile, int pgrp) {
+    const int ty0 = (ptile / a.tiles_x) * SPH, tx0 = (ptile % a.tiles_x) * FTW;
+    const int gx = tx0 + li;
+    const int oH = POOL ? a.H >> 1 : a.H, oW = POOL ? a.W >> 1 : a.W;
+    const int p = POOL ? 0 : piece & 1, cq = POOL ? piece : piece >> 1, c = cq >> 2, q = cq & 3;
+    const int co = pgrp * COW + (c0 + c) * 32 + 8 * q + 4 * kh;
+    const f32x4 bias = *reinterpret_cast<const f32x4*>(biasL + co);
+    f32x4 x;
+    int oy, ox;
+    bool ok;
+    if constexpr (POOL) {
 #pragma unroll
-    for (int i = 0; i < W_PER_WAVE; ++i) {
-      const int idx = wave + 8 * i;
-      if (idx < W_DMA) {
-        const u32x4* g;
-        if constexpr (COW == 64) g = a.wpk + ((size_t)(ch * 36 + idx) * a.cout_pad + grp * 64 + lane);
-        else g = a.wpk + ((size_t)(ch * 36 + idx * 2 + (lane >> 5)) * a.cout_pad + grp * 32 + (lane & 31));
-        __builtin_amdgcn_global_load_lds(g, (lds_ptr)(wgt + idx * 64), 16, 0, 0);
+      for (int k = 0; k < 4; ++k) {
+        float t = fmaxf(r[c][0][4 * q + k], r[c][1][4 * q + k]);
+        t = fmaxf(t, __shfl_xor(t, 1));
+        t = t * inv + bias[k];
+        x[k] = a.relu ? fmaxf(t, 0.f) : t;
       }
+      oy = (ty0 + rw * 2) >> 1; ox = gx >> 1;
+      ok = !(li & 1) && oy < oH && ox < oW && co < a.cout;
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        x[k] = r[c][p][4 * q + k] * inv + bias[k];
+        if (a.relu) x[k] = fmaxf(x[k], 0.f);
+      }
+      oy = ty0 + rw * 2 + p; ox = gx;
+      ok = oy < oH && ox < oW && co < a.cout;
+    }
+    if constexpr (OUTF32) {
+      if (ok) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.out) + ((size_t)oy * oW + ox) * a.cout + co) = x;
+    } else {
+      const u32x4 w = sp16_pair_exchange(x);
+      if (ok) *reinterpret_cast<u32x4*>(a.out + ((size_t)oy * oW + ox) * a.cout * 4 + (co >> 3) * 32 + kh * 16) = w;
     }
   };
 
-  f32x16 acc[CT][2];
+  f32x16 acc[CPW][2], pend[CPW][2];
   // job state (uniform): virtual tile index v (this workgroup walks v, v + grid, ...), cout group, chunk
   int v = blockIdx.x, grp = 0, ch = 0, stage = 0;
   if (v >= ntiles) return;
   int tile = xcd_swizzle(v, ntiles);
   int dma_tile = tile;          // tile the offsets in poff[] belong to
+  int ptile = 0, pgrp = 0;      // tile / group whose finished accumulators wait in pend[]
+  bool have_pend = false;
   tile_offsets(tile);
-  issue(0, 0, 0);
+#pragma unroll
+  for (int i = 0; i < SP_ACT_PER_WAVE; ++i) issue_slice(i, 0, 0, 0);
   while (true) {
     // next job
     int nv = v, ngrp = grp, nch = ch + 1;
@@ -118,11 +174,10 @@ __global__ __launch_bounds__(512) void conv3x3_sp_kernel(SpArgs a) {
     if (more) {
       const int ntile = nv == v ? tile : xcd_swizzle(nv, ntiles);
       if (ntile != dma_tile) { tile_offsets(ntile); dma_tile = ntile; }
-      issue(nch, ngrp, stage ^ 1);
     }
     if (ch == 0) {
 #pragma unroll
-      for (int c = 0; c < CT; ++c)
+      for (int c = 0; c < CPW; ++c)
 #pragma unroll
         for (int p = 0; p < 2; ++p)
 #pragma unroll
@@ -136,93 +191,69 @@ __global__ __launch_bounds__(512) void conv3x3_sp_kernel(SpArgs a) {
       f16x8 bh[2], bl[2];
 #pragma unroll
       for (int p = 0; p < 2; ++p) {
-        const int pix = (wave * 2 + p + dy) * FHW + li + dx;
+        const int pix = (rw * 2 + p + dy) * FHW + li + dx;
         bh[p] = __builtin_bit_cast(f16x8, act[(0 * 2 + kh) * SP_NPP + pix]);
         bl[p] = __builtin_bit_cast(f16x8, act[(1 * 2 + kh) * SP_NPP + pix]);
       }
-      f16x8 ah[CT], al[CT];
+      f16x8 ah[CPW], al[CPW];
 #pragma unroll
-      for (int c = 0; c < CT; ++c) {
-        ah[c] = __builtin_bit_cast(f16x8, wgt[((tap * 2 + 0) * 2 + kh) * COW + c * 32 + li]);
-        al[c] = __builtin_bit_cast(f16x8, wgt[((tap * 2 + 1) * 2 + kh) * COW + c * 32 + li]);
+      for (int c = 0; c < CPW; ++c) {
+        ah[c] = __builtin_bit_cast(f16x8, wgt[((tap * 2 + 0) * 2 + kh) * COW + (c0 + c) * 32 + li]);
+        al[c] = __builtin_bit_cast(f16x8, wgt[((tap * 2 + 1) * 2 + kh) * COW + (c0 + c) * 32 + li]);
+      }
+      // riding on this tap: a slice of the next job's DMA and a slice of the previous tile's epilogue
+      if (tap < SP_ACT_PER_WAVE && more) issue_slice(tap, nch, ngrp, stage ^ 1);
+      if (have_pend) {
+#pragma unroll
+        for (int k = 0; k < PPT; ++k)
+          if (tap * PPT + k < NPIECE) epilogue_piece(pend, tap * PPT + k, ptile, pgrp);
       }
 #pragma unroll
       for (int term = 0; term < 3; ++term)
 #pragma unroll
-        for (int c = 0; c < CT; ++c)
+        for (int c = 0; c < CPW; ++c)
 #pragma unroll
           for (int p = 0; p < 2; ++p)
             acc[c][p] = __builtin_amdgcn_mfma_f32_32x32x16_f16(term == 2 ? al[c] : ah[c], term == 1 ? bl[p] : bh[p], acc[c][p], 0, 0, 0);
     }
-
-    if (ch + 1 == a.cin_chunks) {
-      // ---- epilogue.  D: col = lane & 31 (pixel), row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) (cout)
-      const int ty0 = (tile / a.tiles_x) * SPH, tx0 = (tile % a.tiles_x) * FTW;
-      const int gx = tx0 + li;
-      const int oH = POOL ? a.H >> 1 : a.H, oW = POOL ? a.W >> 1 : a.W;
+    have_pend = false;
+    if (ch + 1 == a.cin_chunks) {   // park the finished tile; its stores ride on the next job
 #pragma unroll
-      for (int c = 0; c < CT; ++c) {
+      for (int c = 0; c < CPW; ++c)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int co = grp * COW + c * 32 + 8 * q + 4 * kh;
-          const f32x4 bias = *reinterpret_cast<const f32x4*>(biasL + co);
-          if constexpr (POOL) {
-            f32x4 m;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              float x = fmaxf(acc[c][0][4 * q + r], acc[c][1][4 * q + r]);
-              x = fmaxf(x, __shfl_xor(x, 1));
-              x = x * inv + bias[r];
-              m[r] = a.relu ? fmaxf(x, 0.f) : x;
-            }
-            const int oy = (ty0 + wave * 2) >> 1, ox = gx >> 1;
-            const bool ok = !(li & 1) && oy < oH && ox < oW && co < a.cout;
-            if constexpr (OUTF32) {
-              if (ok) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.out) + ((size_t)oy * oW + ox) * a.cout + co) = m;
-            } else {
-              const u32x4 w = sp16_pair_exchange(m);
-              if (ok) *reinterpret_cast<u32x4*>(a.out + ((size_t)oy * oW + ox) * a.cout * 4 + (co >> 3) * 32 + kh * 16) = w;
-            }
-          } else {
-#pragma unroll
-            for (int p = 0; p < 2; ++p) {
-              const int gy = ty0 + wave * 2 + p;
-              f32x4 x;
-#pragma unroll
-              for (int r = 0; r < 4; ++r) {
-                x[r] = acc[c][p][4 * q + r] * inv + bias[r];
-                if (a.relu) x[r] = fmaxf(x[r], 0.f);
-              }
-              const bool ok = gy < oH && gx < oW && co < a.cout;
-              if constexpr (OUTF32) {
-                if (ok) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.out) + ((size_t)gy * oW + gx) * a.cout + co) = x;
-              } else {
-                const u32x4 w = sp16_pair_exchange(x);
-                if (ok) *reinterpret_cast<u32x4*>(a.out + ((size_t)gy * oW + gx) * a.cout * 4 + (co >> 3) * 32 + kh * 16) = w;
-              }
-            }
-          }
-        }
-      }
+        for (int p = 0; p < 2; ++p) pend[c][p] = acc[c][p];
+      ptile = tile; pgrp = grp; have_pend = true;
     }
     if (!more) break;
     if (nv != v) { v = nv; tile = dma_tile; }
     grp = ngrp; ch = nch; stage ^= 1;
   }
+  if (have_pend) {
+#pragma unroll
+    for (int k = 0; k < NPIECE; ++k) epilogue_piece(pend, k, ptile, pgrp);
+  }
 }
 
 template <typename K>
-hipError_t launch_sp(K k, const SpArgs& a, size_t lds, hipStream_t s) {
+hipError_t launch_sp(K k, const SpArgs& a, size_t lds, hipStream_t s, int threads) {
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   const int ntiles = a.tiles_x * a.tiles_y, grid = ntiles < num_cus() ? ntiles : num_cus();
-  hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds, s, a);
+  hipLaunchKernelGGL(k, dim3(grid), dim3(threads), lds, s, a);
   return hipGetLastError();
 }
 
 }  // namespace
 
 bool conv_sp_supported(const ConvDesc& d) {
+  // WCT_SP_DMA_MASK (experiments): which layer families take the DMA kernel -- 1: 32 couts, 2: 32 couts + pool,
+  // 4: 64 couts, 8: 64 couts + pool, 16: >= 128 couts.  Measured (4K bench, ms per step, DMA vs register-staged on the
+  // same SP16 input): 32: 1.29 / 1.30, 32+pool: 0.72 / 0.59, 64: 1.90 / 1.95, 64+pool: 0.33 / 0.33, >=128: 1.31 / 1.70
+  // -> default 29: everything but the pooled 32-cout layers.
+  static const int mask = [] { const char* e = getenv("WCT_SP_DMA_MASK"); return e ? atoi(e) : 29; }();
+  const bool pool = d.flags & CONV_POOL_OUT;
+  const int fam = d.cout_pad >= 128 ? 16 : d.cout_pad == 64 ? (pool ? 8 : 4) : (pool ? 2 : 1);
+  if (!(mask & fam)) return false;
   return d.wpk16 && !(d.flags & (CONV_IN_NCHW3 | CONV_OUT_NCHW3)) && (d.cin % 16) == 0 && d.cout_pad >= 32 && (d.cout % 8) == 0 &&
          d.cout_pad <= 512;
 }
@@ -246,8 +277,8 @@ hipError_t launch_conv3x3_sp(const ConvDesc& d, const void* in, void* out, int H
   const size_t lds = (size_t)2 * (4 * SP_NPP + 36 * ct * 32) * 16 + (size_t)d.cout_pad * sizeof(float);
 #define WCT_SP_CASE(CTV)                                                                                              \
   if (ct == CTV) {                                                                                                    \
-    if (pool) return f32 ? launch_sp(conv3x3_sp_kernel<CTV, true, true>, a, lds, s) : launch_sp(conv3x3_sp_kernel<CTV, true, false>, a, lds, s); \
-    return f32 ? launch_sp(conv3x3_sp_kernel<CTV, false, true>, a, lds, s) : launch_sp(conv3x3_sp_kernel<CTV, false, false>, a, lds, s);         \
+    if (pool) return f32 ? launch_sp(conv3x3_sp_kernel<CTV, true, true>, a, lds, s, 512) : launch_sp(conv3x3_sp_kernel<CTV, true, false>, a, lds, s, 512); \
+    return f32 ? launch_sp(conv3x3_sp_kernel<CTV, false, true>, a, lds, s, 512) : launch_sp(conv3x3_sp_kernel<CTV, false, false>, a, lds, s, 512);         \
   }
   WCT_SP_CASE(1)
   WCT_SP_CASE(2)

@@ -166,6 +166,8 @@ int run_conv(wct_ctx* ctx, Lane& ln, const ConvDesc& d, const float* in, float* 
   snprintf(name, sizeof name, "conv3x3%s<co=%d%s%s%s%s>", f16 ? "_f16x3" : "_f32", d.cout_pad > 128 ? 128 : d.cout_pad,
            (d.flags & CONV_IN_NCHW3) ? ",in3" : "", (d.flags & CONV_POOL_OUT) ? ",pool" : "", (d.flags & CONV_OUT_NCHW3) ? ",out3" : "",
            spk ? ",dma" : "");
+  static const bool shapes = getenv("WCT_PROF_SHAPES") != nullptr;   // one profile row per layer shape instead of per family
+  if (shapes) { const size_t n = strlen(name); snprintf(name + n, sizeof name - n, "@%dx%dx%d", H, W, d.cin); }
   const double px = (double)H * W;
   const double in_px = (d.flags & CONV_UP_IN) ? px / 4 : px, out_px = (d.flags & CONV_POOL_OUT) ? px / 4 : px;
   const double flops = 2.0 * 9 * d.cin * d.cout * px;

@@ -9,7 +9,8 @@ import os
 from ctypes import POINTER, byref, c_char_p, c_double, c_float, c_int, c_long, c_size_t, c_void_p
 
 _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB_PATH = os.path.join(_PKG, "libwct_hip.so")
+# WCT_LIB_PATH: load an instrumented build of the same library (tools/experiments/sp_timing.sh); default = the in-tree build
+LIB_PATH = os.environ.get("WCT_LIB_PATH") or os.path.join(_PKG, "libwct_hip.so")
 
 WCT_OK, WCT_ERR_INVALID, WCT_ERR_HIP, WCT_ERR_NOMEM, WCT_ERR_STATE = 0, -1, -2, -3, -4
 KIND_ENC, KIND_DEC = 0, 1
