@@ -14,7 +14,7 @@ The JSON line also carries
   roofline      dominant kernel family: algorithmic FLOP per launch / HIP-event duration vs the gfx950 fp32-MFMA peak
   passes        relu4_1 encode pass: algorithmic GB/s (364 B/px) and TFLOP/s (30 816 FLOP/px), SURVEY 8(d)
   cpu_baseline  the CPU oracle (oracle/: numpy + C/OpenMP port of the reference's op sequence) timed on the host
-                cores on a bounded sample (512x512 content + style, 5 levels); rank 0, N = 1 only.
+                cores on a bounded sample (1920x1080 content + 1024x1024 style, 5 levels); rank 0, N = 1 only.
 """
 import argparse
 import json
@@ -46,14 +46,23 @@ def pmc_traffic(family):
     if not os.path.exists(path):
         return None
     ks = json.load(open(path))["kernels"]
-    m = re.match(r"conv3x3_f16x3<co=(\d+)(,pool)?(,out3)?>", family)
+    m = re.match(r"conv3x3_f16x3<co=(\d+)(,pool)?(,out3)?(,dma)?>", family)
     if not m:
         return None
-    co, pool, out3 = int(m.group(1)), bool(m.group(2)), bool(m.group(3))
+    co, pool, out3, dma = int(m.group(1)), bool(m.group(2)), bool(m.group(3)), bool(m.group(4))
+    tf = lambda b: "true" if b else "false"
+    if dma:     # <CT, POOL, OUTF32, GROUPS>: both output formats of the family
+        pre = "void conv3x3_sp_kernel<%d, %s, " % (1 if co == 32 else 2, tf(pool))
+        rows = [v for k, v in ks.items() if k.startswith(pre) and k.endswith(", %s>(SpArgs)" % tf(co >= 128))]
+        if not rows:
+            return None
+        n = sum(r["calls"] for r in rows)
+        return {"hbm_bytes_per_launch": round(sum((r["read_MB_per_launch"] + r["write_MB_per_launch"]) * r["calls"] for r in rows) / n * 1e6),
+                "source": "profiles/hbm_traffic_latest.json", "pmc_avg_launch_us": round(sum(r["avg_us"] * r["calls"] for r in rows) / n, 2)}
     if co == 16:
-        name = "void conv3x3_f16_c16_kernel<%s, %s>(F16Args)" % ("true" if pool else "false", "true" if out3 else "false")
+        name = "void conv3x3_f16_c16_kernel<%s, %s>(F16Args)" % (tf(pool), tf(out3))
     else:
-        name = "void conv3x3_f16_kernel<%d, %s, %d>(F16Args)" % (co // 32, "true" if pool else "false", 16 if co == 128 else 8)
+        name = "void conv3x3_f16_kernel<%d, %s, %d>(F16Args)" % (min(co, 128) // 32, tf(pool), 16 if co >= 128 else 8)
     e = ks.get(name)
     if not e:
         return None
@@ -63,22 +72,24 @@ def pmc_traffic(family):
 
 def cpu_baseline(weights):
     """The oracle (a CPU port of the reference's op sequence: fp32 convs, fp64 two-GEMM WCT with SVD) on a bounded
-    sample of the same workload.  This is the ONLY place bench.py touches oracle/."""
+    sample of the same workload.  This is the ONLY place bench.py touches oracle/.
+    Threads: the C/OpenMP convolutions stop scaling at ~8-32 threads on the GPU box's host (1.3 s at 8..32 threads,
+    3.8 s at 128, 23.6 s at 256 for a 512x512 sample: oversubscription), so min(cores, 32) are used and reported."""
     from oracle import wct_oracle
-    cores = os.cpu_count() or 1
-    wct_oracle.set_num_threads(cores)
+    threads = min(os.cpu_count() or 1, 32)
+    wct_oracle.set_num_threads(threads)
     mods = wct_oracle.Modules("16x", weights)
     rng = np.random.default_rng(0)
-    n = 512
-    c = rng.random((3, n, n), dtype=np.float32)
-    s = rng.random((3, n, n), dtype=np.float32)
+    hc, wc, hs, ws = 1080, 1920, 1024, 1024     # a quarter of the benchmark's content / style pixels
+    c = rng.random((3, hc, wc), dtype=np.float32)
+    s = rng.random((3, hs, ws), dtype=np.float32)
     t0 = time.perf_counter()
     out = wct_oracle.stylize(mods, c, s, 1.0)
     dt = time.perf_counter() - t0
     assert np.isfinite(out).all()
-    return {"value": round(n * n / 1e6 / dt, 5), "unit": "MP/s", "cores": cores, "kind": "port",
-            "sample": "5-level 16x WCT, %dx%d content + %dx%d style (uniform noise), %.1f s wall, conv threads=%d, "
-                      "numpy/OpenBLAS for the fp64 transform" % (n, n, n, n, dt, wct_oracle.num_threads())}, out, (c, s)
+    return {"value": round(hc * wc / 1e6 / dt, 5), "unit": "MP/s", "cores": threads, "kind": "port",
+            "sample": "5-level 16x WCT, %dx%d content + %dx%d style (uniform noise), %.1f s wall, %d OpenMP threads for the "
+                      "convolutions (of %d host cores), numpy/OpenBLAS for the fp64 transform" % (wc, hc, ws, hs, dt, wct_oracle.num_threads(), os.cpu_count() or 1)}, out, (c, s)
 
 
 def main():

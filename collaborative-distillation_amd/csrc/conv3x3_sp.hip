@@ -52,7 +52,9 @@ typedef __attribute__((address_space(3))) void* lds_ptr;
 
 // (A 16-wave variant -- each wave one cout tile, four waves per SIMD -- was measured 25 % SLOWER: spills at the 128
 // VGPR cap, 1.5x the LDS operand reads and a 16-wave barrier.  Kept out.)
-template <int CT, bool POOL, bool OUTF32>
+// GROUPS (more than one cout group, i.e. >= 128 couts) changes no code: it gives those launches their own kernel name
+// so that profiler rows (rocprofv3, PMC) can be matched to the library's profile families.
+template <int CT, bool POOL, bool OUTF32, bool GROUPS>
 __global__ __launch_bounds__(512) void conv3x3_sp_kernel(SpArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int COW = CT * 32;
@@ -275,13 +277,14 @@ hipError_t launch_conv3x3_sp(const ConvDesc& d, const void* in, void* out, int H
   const int ct = (d.cout_pad % 64 == 0) ? 2 : 1;
   a.groups = d.cout_pad / (ct * 32);
   const size_t lds = (size_t)2 * (4 * SP_NPP + 36 * ct * 32) * 16 + (size_t)d.cout_pad * sizeof(float);
-#define WCT_SP_CASE(CTV)                                                                                              \
-  if (ct == CTV) {                                                                                                    \
-    if (pool) return f32 ? launch_sp(conv3x3_sp_kernel<CTV, true, true>, a, lds, s, 512) : launch_sp(conv3x3_sp_kernel<CTV, true, false>, a, lds, s, 512); \
-    return f32 ? launch_sp(conv3x3_sp_kernel<CTV, false, true>, a, lds, s, 512) : launch_sp(conv3x3_sp_kernel<CTV, false, false>, a, lds, s, 512);         \
+#define WCT_SP_CASE(CTV, GV)                                                                                          \
+  if (ct == CTV && (a.groups > 1) == GV) {                                                                            \
+    if (pool) return f32 ? launch_sp(conv3x3_sp_kernel<CTV, true, true, GV>, a, lds, s, 512) : launch_sp(conv3x3_sp_kernel<CTV, true, false, GV>, a, lds, s, 512); \
+    return f32 ? launch_sp(conv3x3_sp_kernel<CTV, false, true, GV>, a, lds, s, 512) : launch_sp(conv3x3_sp_kernel<CTV, false, false, GV>, a, lds, s, 512);         \
   }
-  WCT_SP_CASE(1)
-  WCT_SP_CASE(2)
+  WCT_SP_CASE(1, false)
+  WCT_SP_CASE(2, false)
+  WCT_SP_CASE(2, true)
 #undef WCT_SP_CASE
   return hipErrorInvalidValue;
 }
