@@ -880,12 +880,14 @@ size_t conv_f16_weight_bytes(int cin, int cout_pad, int taps) {
 }
 
 hipError_t launch_split_pack(const float* wpk32, int cin, int cout_pad, int taps, unsigned* maxbits_dev, void* out,
-                             float* inv_scale_out, hipStream_t s) {
+                             float* inv_scale_out, hipStream_t s, bool have_max) {
   const int chunks = (cin + 15) / 16;
-  hipError_t e = hipMemsetAsync(maxbits_dev, 0, sizeof(unsigned), s);
-  if (e != hipSuccess) return e;
-  const long n = (long)chunks * 36 * cout_pad * 4;
-  hipLaunchKernelGGL(absmax_kernel, dim3(64), dim3(256), 0, s, wpk32, n, maxbits_dev);
+  if (!have_max) {
+    hipError_t e = hipMemsetAsync(maxbits_dev, 0, sizeof(unsigned), s);
+    if (e != hipSuccess) return e;
+    const long n = (long)chunks * 36 * cout_pad * 4;
+    hipLaunchKernelGGL(absmax_kernel, dim3(64), dim3(256), 0, s, wpk32, n, maxbits_dev);
+  }
   const long total = (long)chunks * taps * 4 * cout_pad;
   hipLaunchKernelGGL(split_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, wpk32, chunks, cout_pad, taps,
                      maxbits_dev, reinterpret_cast<u32x4*>(out), inv_scale_out);

@@ -20,40 +20,44 @@ __global__ void transpose_kernel(const float* in, float* out, int rows, int cols
   }
 }
 
-// W'[o][i][t] = sum_c W[o][c][t] M[c][i]  written straight into the conv kernel's packed layout
-// [chunk][tap][kq][cout_pad][4]  (i = chunk*16 + kq*4 + r); accumulated in fp64.
-__global__ void fold_affine_kernel(const float* w, int cout, int cin, int cout_pad, const double* M, float* wpk) {
-  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  const int chunks = (cin + 15) / 16;
-  const long total = (long)chunks * 36 * cout_pad * 4;
-  if (e >= total) return;
-  const int r = (int)(e & 3);
-  long t = e >> 2;
-  const int o = (int)(t % cout_pad); t /= cout_pad;
-  const int kq = (int)(t & 3); t >>= 2;
-  const int tap = (int)(t % 9);
-  const int chunk = (int)(t / 9);
-  const int i = chunk * 16 + kq * 4 + r;
-  double s = 0.;
-  if (o < cout && i < cin) {
-    for (int c = 0; c < cin; ++c) s += (double)w[((size_t)o * cin + c) * 9 + tap] * M[(size_t)c * cin + i];
+// Fold csF = M x + b into the decoder's first conv, one workgroup per output channel o (fp64 accumulate):
+//   W'[o][i][t] = sum_c W[o][c][t] M[c][i]  -> the conv kernel's packed layout [chunk][tap][kq][cout_pad][4]
+//   b'[o]       = bias[o] + sum_c (sum_t W[o][c][t]) b[c]
+//   maxbits     = max |W'| as float bits (atomicMax), the input of the split-f16 scale (split_pack_kernel)
+// The weight row W[o][:][:] (cin x 9 floats) is staged in LDS; the M reads are coalesced over i.
+__global__ __launch_bounds__(256) void fold_row_kernel(const float* w, const float* bias, int cout, int cin, int cout_pad,
+                                                         const double* M, const double* b, float* wpk, float* bias_out, unsigned* maxbits) {
+  extern __shared__ float wrow[];          // [cin * 9]
+  __shared__ double red[256];
+  const int o = blockIdx.x, tid = threadIdx.x;
+  const int chunks = (cin + 15) / 16, ipad = chunks * 16;
+  const bool live = o < cout;
+  if (live) for (int e = tid; e < cin * 9; e += 256) wrow[e] = w[(size_t)o * cin * 9 + e];
+  __syncthreads();
+  float mx = 0.f;
+  for (int e = tid; e < 9 * ipad; e += 256) {
+    const int tap = e / ipad, i = e - tap * ipad;
+    double s = 0.;
+    if (live && i < cin)
+      for (int c = 0; c < cin; ++c) s += (double)wrow[c * 9 + tap] * M[(size_t)c * cin + i];
+    const float v = (float)s;
+    mx = fmaxf(mx, fabsf(v));
+    const int chunk = i >> 4, kq = (i >> 2) & 3, r = i & 3;
+    wpk[((((size_t)chunk * 9 + tap) * 4 + kq) * cout_pad + o) * 4 + r] = v;
   }
-  wpk[e] = (float)s;
-}
-
-__global__ void fold_bias_kernel(const float* w, const float* bias, int cout, int cin, int cout_pad, const double* b, float* bias_out) {
-  const int o = blockIdx.x * blockDim.x + threadIdx.x;
-  if (o >= cout_pad) return;
-  double s = 0.;
-  if (o < cout) {
-    s = bias[o];
-    for (int c = 0; c < cin; ++c) {
+  double part = 0.;
+  if (live)
+    for (int c = tid; c < cin; c += 256) {
       double ws = 0.;
-      for (int t = 0; t < 9; ++t) ws += (double)w[((size_t)o * cin + c) * 9 + t];
-      s += ws * b[c];
+      for (int t = 0; t < 9; ++t) ws += (double)wrow[c * 9 + t];
+      part += ws * b[c];
     }
-  }
-  bias_out[o] = (float)s;
+  red[tid] = part;
+  __syncthreads();
+  for (int k = 128; k > 0; k >>= 1) { if (tid < k) red[tid] += red[tid + k]; __syncthreads(); }
+  if (tid == 0) bias_out[o] = live ? (float)((double)bias[o] + red[0]) : 0.f;
+  for (int k = 32; k > 0; k >>= 1) mx = fmaxf(mx, __shfl_xor(mx, k));
+  if (maxbits && (tid & 63) == 0) atomicMax(maxbits, __float_as_uint(mx));
 }
 
 // 1x1 affine as a centre-tap-only 3x3: used by wct_apply / wct_transform (the un-fused drop-in surface)
@@ -86,11 +90,13 @@ hipError_t launch_nchw_to_nhwc(const float* in, float* out, int C, int npix, hip
 }
 
 hipError_t launch_fold_affine(const float* w, const float* bias, int cout, int cin, int cout_pad, const double* M,
-                              const double* b, float* wpk_out, float* bias_out, hipStream_t s) {
-  const int chunks = (cin + 15) / 16;
-  const long total = (long)chunks * 36 * cout_pad * 4;
-  hipLaunchKernelGGL(fold_affine_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, cout, cin, cout_pad, M, wpk_out);
-  hipLaunchKernelGGL(fold_bias_kernel, dim3((cout_pad + 63) / 64), dim3(64), 0, s, w, bias, cout, cin, cout_pad, b, bias_out);
+                              const double* b, float* wpk_out, float* bias_out, unsigned* maxbits_dev, hipStream_t s) {
+  if (maxbits_dev) {
+    hipError_t e = hipMemsetAsync(maxbits_dev, 0, sizeof(unsigned), s);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(fold_row_kernel, dim3((unsigned)cout_pad), dim3(256), (size_t)cin * 9 * sizeof(float), s, w, bias, cout, cin, cout_pad, M, b,
+                     wpk_out, bias_out, maxbits_dev);
   return hipGetLastError();
 }
 

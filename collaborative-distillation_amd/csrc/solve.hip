@@ -551,22 +551,6 @@ __global__ __launch_bounds__(256) void sym_power_kernel(double* res, int n, doub
   out[e] = s;
 }
 
-struct FinArgs {
-  int C;
-  double alpha;
-  const double* Ss; const double* Wc; const double* mu_c; const double* mu_s;
-  double* M64; double* b64; double* T;
-};
-
-__global__ void bias_kernel(FinArgs f) {  // b = alpha (mu_s - T mu_c)
-  const int a = blockIdx.x * blockDim.x + threadIdx.x;
-  const int C = f.C;
-  if (a >= C) return;
-  double s = 0.;
-  for (int k = 0; k < C; ++k) s += f.T[(size_t)a * C + k] * f.mu_c[k];
-  f.b64[a] = f.alpha * (f.mu_s[a] - s);
-}
-
 }  // namespace
 
 size_t eig_result_bytes(int C) { return eig_doubles(C) * sizeof(double); }
@@ -659,14 +643,27 @@ hipError_t launch_eig(int C, double n, const double* sum, const double* sumsq, i
 }
 
 namespace {
-__global__ void matmul_T_kernel2(int C, double alpha, const double* Ss, const double* Wc, double* T, double* M) {
-  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= (long)C * C) return;
-  const int a = (int)(e / C), b = (int)(e % C);
-  double s = 0.;
-  for (int k = 0; k < C; ++k) s += Ss[(size_t)a * C + k] * Wc[(size_t)k * C + b];
-  T[e] = s;
-  M[e] = alpha * s + (a == b ? 1.0 - alpha : 0.0);
+// one workgroup per row a:  T[a][:] = Ss[a][:] Wc,  M[a][:] = alpha T[a][:] + (1 - alpha) I[a][:],
+// b[a] = alpha (mu_s[a] - T[a][:] mu_c)   -- the whole assembly in ONE launch (was: element-wise matmul + bias kernel)
+__global__ __launch_bounds__(256) void assemble_row_kernel(int C, double alpha, const double* Ss, const double* Wc, const double* mu_c,
+                                                             const double* mu_s, double* T, double* M, double* bvec) {
+  __shared__ double srow[512];
+  __shared__ double red[256];
+  const int a = blockIdx.x, tid = threadIdx.x;
+  for (int k = tid; k < C; k += 256) srow[k] = Ss[(size_t)a * C + k];
+  __syncthreads();
+  double dot = 0.;
+  for (int b0 = tid; b0 < C; b0 += 256) {
+    double s = 0.;
+    for (int k = 0; k < C; ++k) s += srow[k] * Wc[(size_t)k * C + b0];
+    T[(size_t)a * C + b0] = s;
+    M[(size_t)a * C + b0] = alpha * s + (a == b0 ? 1.0 - alpha : 0.0);
+    dot += s * mu_c[b0];
+  }
+  red[tid] = dot;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
+  if (tid == 0) bvec[a] = alpha * (mu_s[a] - red[0]);
 }
 }  // namespace
 
@@ -676,11 +673,7 @@ hipError_t launch_assemble(int C, const double* eig_c, const double* eig_s, doub
   if (ws_bytes < assemble_workspace_bytes(C)) return hipErrorOutOfMemory;
   const size_t cc = (size_t)C * C;
   double* T = reinterpret_cast<double*>(ws);
-  const unsigned nb = (unsigned)((cc + 255) / 256);
-  hipLaunchKernelGGL(matmul_T_kernel2, dim3(nb), dim3(256), 0, s, C, alpha, eig_s + eig_F_offset(C), eig_c + eig_F_offset(C), T, M);
-  FinArgs f;
-  f.C = C; f.alpha = alpha; f.Ss = nullptr; f.Wc = nullptr; f.mu_c = eig_c + cc + C; f.mu_s = eig_s + cc + C;
-  f.M64 = M; f.b64 = b; f.T = T;
-  hipLaunchKernelGGL(bias_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, s, f);
+  hipLaunchKernelGGL(assemble_row_kernel, dim3((unsigned)C), dim3(256), 0, s, C, alpha, eig_s + eig_F_offset(C), eig_c + eig_F_offset(C),
+                     eig_c + cc + C, eig_s + cc + C, T, M, b);
   return hipGetLastError();
 }

@@ -449,7 +449,6 @@ int fold_impl(wct_ctx* ctx, int level, const double* M, const double* b, ConvDes
   float* wpk = reinterpret_cast<float*>(ctx->foldW.p);
   float* bias = wpk + wbytes / sizeof(float);
   ProfScope ps(ctx, st, "fold_affine", 0, 0);
-  HIPCHK(ctx, launch_fold_affine(l.w_oihw, l.bias_raw, l.d.cout, l.d.cin, l.d.cout_pad, M, b, wpk, bias, st));
   out = l.d;
   out.wpk = wpk;
   out.bias = bias;
@@ -462,9 +461,12 @@ int fold_impl(wct_ctx* ctx, int level, const double* M, const double* b, ConvDes
     char* base = reinterpret_cast<char*>(ctx->foldW16.p);
     float* inv = reinterpret_cast<float*>(base + b16);
     unsigned* maxbits = reinterpret_cast<unsigned*>(base + b16 + 16);
-    HIPCHK(ctx, launch_split_pack(wpk, l.d.cin, l.d.cout_pad, taps, maxbits, base, inv, st));
+    HIPCHK(ctx, launch_fold_affine(l.w_oihw, l.bias_raw, l.d.cout, l.d.cin, l.d.cout_pad, M, b, wpk, bias, maxbits, st));
+    HIPCHK(ctx, launch_split_pack(wpk, l.d.cin, l.d.cout_pad, taps, maxbits, base, inv, st, true));
     out.wpk16 = base;
     out.inv_scale_ptr = inv;
+  } else {
+    HIPCHK(ctx, launch_fold_affine(l.w_oihw, l.bias_raw, l.d.cout, l.d.cin, l.d.cout_pad, M, b, wpk, bias, nullptr, st));
   }
   return WCT_OK;
 }

@@ -47,8 +47,9 @@ bool conv_fusable_tail(const ConvDesc& d0, const ConvDesc& d1);
 hipError_t launch_enc_head(const ConvDesc& d0, const ConvDesc& d1, const float* img, float* out, int H, int W, hipStream_t s);   // d1.flags & CONV_OUT_SP16
 hipError_t launch_dec_tail(const ConvDesc& d0, const ConvDesc& d1, const float* in, float* out, int H, int W, hipStream_t s);
 // fp32 packed weights (device) -> scaled split-f16 packed weights + inverse scale (device scalar)
+//   have_max: *maxbits_dev already holds max |w| (written by launch_fold_affine); otherwise it is computed here
 hipError_t launch_split_pack(const float* wpk32, int cin, int cout_pad, int taps, unsigned* maxbits_dev, void* out,
-                             float* inv_scale_out, hipStream_t s);
+                             float* inv_scale_out, hipStream_t s, bool have_max = false);
 
 // ---- layout
 hipError_t launch_nhwc_to_nchw(const float* in, float* out, int C, int npix, hipStream_t s);
@@ -72,9 +73,10 @@ hipError_t launch_assemble(int C, const double* eig_c, const double* eig_s, doub
 
 // ---- fold csF = M x + b into a decoder's first conv:  W' = W o M, b' = bias + W o b
 //      w_oihw: device [cout][cin][3][3] fp32 (original weights), out: packed weights + bias for ConvDesc
+//      maxbits_dev (optional): receives max |W'| as float bits for launch_split_pack(..., have_max = true)
 hipError_t launch_fold_affine(const float* w_oihw, const float* bias, int cout, int cin, int cout_pad,
                               const double* M, const double* b, float* wpk_out, float* bias_out,
-                              hipStream_t s);
+                              unsigned* maxbits_dev, hipStream_t s);
 // pack [cout][cin][3][3] (+ bias) into the conv kernel's layout (device side, used for the apply conv)
 hipError_t launch_pack_center_tap(const double* M, const double* b, int C, int cout_pad, float* wpk_out,
                                   float* bias_out, hipStream_t s);
