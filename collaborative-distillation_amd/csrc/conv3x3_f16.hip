@@ -358,10 +358,6 @@ __global__ __launch_bounds__(256) void conv3x3_f16_c16_kernel(F16Args a) {
 // The intermediate's own reflect padding: a halo pixel OUTSIDE the image must hold the intermediate value of its
 // mirror pixel (not the first conv evaluated outside the image), so every halo pixel is evaluated at its reflected
 // image coordinate -- whose 3x3 input window is inside the staged tile -- and stored at the halo position.
-constexpr int I2W = FTW + 4, I2H = 8 + 4;       // 36 x 12: input tile of the first conv (two halo rings)
-constexpr int NPI2 = I2W * I2H;                 // 432 (a multiple of 16)
-constexpr int NGRP = (nph(8) + 15) / 16;        // 22 groups of 16 halo pixels
-
 struct HeadArgs {   // conv11 (3->16, conv0 folded) + ReLU -> conv12 (16->16) + ReLU -> 2x2 max-pool, both f16x3
   const float* img; float* out;
   const u32x4* w11; const float* b11; float inv11;   // [kb][hi/lo][kq][16 couts] x 8 halfs (K layout below)
@@ -369,101 +365,6 @@ struct HeadArgs {   // conv11 (3->16, conv0 folded) + ReLU -> conv12 (16->16) + 
   int H, W, tiles_x, tiles_y;
   int out_sp;
 };
-
-constexpr int IMG_E = NPI2 + 4;   // 8-byte pixels per plane; the zeroed tail absorbs the "4th pixel" over-read of the last row
-
-// (uniform) true when the 36 x 12 input window of the tile lies inside the image: no reflection anywhere
-__device__ __forceinline__ bool tile_interior(int ty0, int tx0, int H, int W) {
-  return ty0 >= 2 && ty0 + 10 <= H && tx0 >= 2 && tx0 + 34 <= W;
-}
-
-// next tile's 36 x 12 x 3 image window -> 6 registers per thread (unconditional, clamped).  soff[k]: tile-independent
-// offset of the thread's pixel k from the window origin, valid for interior tiles.
-__device__ __forceinline__ void head_fetch(const HeadArgs& a, float (&r)[2][3], const int (&soff)[2], int tile, int tid) {
-  const int ty0 = (tile / a.tiles_x) * 8, tx0 = (tile % a.tiles_x) * FTW;
-  const size_t plane = (size_t)a.H * a.W;
-  if (tile_interior(ty0, tx0, a.H, a.W)) {
-    const float* base = a.img + (size_t)(ty0 - 2) * a.W + (tx0 - 2);
-#pragma unroll
-    for (int k = 0; k < 2; ++k)
-#pragma unroll
-      for (int c = 0; c < 3; ++c) r[k][c] = base[c * plane + soff[k]];
-    return;
-  }
-#pragma unroll
-  for (int k = 0; k < 2; ++k) {
-    int e = tid + 256 * k;
-    e = e < NPI2 ? e : NPI2 - 1;
-    const int py = e / I2W, px = e - py * I2W;
-    const size_t off = (size_t)reflect_clamp(ty0 - 2 + py, a.H) * a.W + reflect_clamp(tx0 - 2 + px, a.W);
-#pragma unroll
-    for (int c = 0; c < 3; ++c) r[k][c] = a.img[c * plane + off];
-  }
-}
-
-__device__ __forceinline__ void head_commit(const float (&r)[2][3], u32x2* imgH, u32x2* imgL, int tid) {
-#pragma unroll
-  for (int k = 0; k < 2; ++k) {
-    const int e = tid + 256 * k;
-    if (e < NPI2) {
-      f16x4 h = {0, 0, 0, 0}, l = {0, 0, 0, 0};
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        const float x = fminf(fmaxf(r[k][c], -65504.f), 65504.f);
-        h[c] = (_Float16)x;
-        l[c] = (_Float16)(x - (float)h[c]);
-      }
-      imgH[e] = __builtin_bit_cast(u32x2, h);
-      imgL[e] = __builtin_bit_cast(u32x2, l);
-    }
-  }
-}
-
-__device__ __forceinline__ void store_split4(u32x4* planes, int npp, int pix, int kq, const f32x4& v) {
-  // 4 consecutive channels 4kq..4kq+3 of halo pixel `pix` -> 8 bytes in the hi plane and 8 in the lo plane
-  _Float16 h[4], l[4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const float x = fminf(fmaxf(v[r], -65504.f), 65504.f);
-    h[r] = (_Float16)x;
-    l[r] = (_Float16)(x - (float)h[r]);
-  }
-  typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-  f16x4* ph = reinterpret_cast<f16x4*>(planes + (0 * 2 + (kq >> 1)) * npp + pix) + (kq & 1);
-  f16x4* pl = reinterpret_cast<f16x4*>(planes + (1 * 2 + (kq >> 1)) * npp + pix) + (kq & 1);
-  *ph = f16x4{h[0], h[1], h[2], h[3]};
-  *pl = f16x4{l[0], l[1], l[2], l[3]};
-}
-
-// 16->16 conv on the [4][NPP] planes of a 34 x 10 halo tile for the wave's 2 rows x 32 px (the c16 kernel's body)
-__device__ __forceinline__ void c16_compute(const u32x4* act, const u32x4* wgt, int wave, int li, int kq, f32x4 (&acc)[2][2]) {
-  constexpr int NPP = npp(8);
-  const int kh = kq & 1, ts = kq >> 1;
-#pragma unroll
-  for (int s = 0; s < 5; ++s) {
-    const int tap = 2 * s + ts;
-    const int tc = tap > 8 ? 8 : tap;
-    const int dy = tc / 3, dx = tc - dy * 3;
-    const f16x8 ah = __builtin_bit_cast(f16x8, wgt[((tap * 2 + 0) * 2 + kh) * 16 + li]);
-    const f16x8 al = __builtin_bit_cast(f16x8, wgt[((tap * 2 + 1) * 2 + kh) * 16 + li]);
-    f16x8 bh[2][2], bl[2][2];
-#pragma unroll
-    for (int r = 0; r < 2; ++r)
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int pix = (wave * 2 + r + dy) * FHW + h * 16 + li + dx;
-        bh[r][h] = __builtin_bit_cast(f16x8, act[(0 * 2 + kh) * NPP + pix]);
-        bl[r][h] = __builtin_bit_cast(f16x8, act[(1 * 2 + kh) * NPP + pix]);
-      }
-#pragma unroll
-    for (int term = 0; term < 3; ++term)   // dependent MFMAs 4 apart
-#pragma unroll
-      for (int r = 0; r < 2; ++r)
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-          acc[r][h] = __builtin_amdgcn_mfma_f32_16x16x32_f16(term == 2 ? al : ah, term == 1 ? bl[r][h] : bh[r][h], acc[r][h], 0, 0, 0);
-  }
-}
 
 // Persistent: a workgroup walks tiles v, v + grid, ...; the image window of the NEXT tile is fetched into registers
 // while the current tile is on the matrix cores and written to LDS behind conv12, conv12's weights are staged once.
@@ -522,7 +423,7 @@ __global__ __launch_bounds__(256, 3) void enc_head_kernel(HeadArgs a) {
   float pxr[2][3];
   int v = blockIdx.x;
   if (v < ntiles) {
-    head_fetch(a, pxr, soff, xcd_swizzle(v, ntiles), tid);
+    head_fetch(a.img, a.H, a.W, a.tiles_x, pxr, soff, xcd_swizzle(v, ntiles), tid);
     head_commit(pxr, imgH, imgL, tid);
   }
   for (; v < ntiles; v += gridDim.x) {
@@ -530,7 +431,7 @@ __global__ __launch_bounds__(256, 3) void enc_head_kernel(HeadArgs a) {
     const int ty0 = (tile / a.tiles_x) * 8, tx0 = (tile % a.tiles_x) * FTW;
     __syncthreads();   // image window of this tile is in LDS; every wave is done with the previous tile's planes
     const int vn = v + gridDim.x;
-    if (vn < ntiles) head_fetch(a, pxr, soff, xcd_swizzle(vn, ntiles), tid);
+    if (vn < ntiles) head_fetch(a.img, a.H, a.W, a.tiles_x, pxr, soff, xcd_swizzle(vn, ntiles), tid);
     const bool interior = tile_interior(ty0, tx0, a.H, a.W);
     // ---- conv11 on the 340 halo pixels, three 16-pixel groups in flight per wave
 #pragma unroll

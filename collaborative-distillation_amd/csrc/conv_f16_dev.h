@@ -82,6 +82,147 @@ __device__ __forceinline__ void sp16_store4(char* record, int kq, const f32x4& v
   *reinterpret_cast<u32x2*>(g + 16) = lo;
 }
 
+// ---- shared by the fused full-resolution kernels (conv3x3_f16.hip: enc_head / dec_tail, level1.hip)
+constexpr int I2W = FTW + 4, I2H = 8 + 4;       // 36 x 12: input tile of the first conv (two halo rings)
+constexpr int NPI2 = I2W * I2H;                 // 432 (a multiple of 16)
+constexpr int NGRP = (nph(8) + 15) / 16;        // 22 groups of 16 halo pixels
+
+constexpr int IMG_E = NPI2 + 4;   // 8-byte pixels per plane; the zeroed tail absorbs the "4th pixel" over-read of the last row
+
+// (uniform) true when the 36 x 12 input window of the tile lies inside the image: no reflection anywhere
+__device__ __forceinline__ bool tile_interior(int ty0, int tx0, int H, int W) {
+  return ty0 >= 2 && ty0 + 10 <= H && tx0 >= 2 && tx0 + 34 <= W;
+}
+
+
+// next tile's 36 x 12 x 3 image window -> 6 registers per thread (unconditional, clamped).  soff[k]: tile-independent
+// offset of the thread's pixel k from the window origin, valid for interior tiles.
+__device__ __forceinline__ void head_fetch(const float* img, int H, int W, int tiles_x, float (&r)[2][3], const int (&soff)[2], int tile, int tid) {
+  const int ty0 = (tile / tiles_x) * 8, tx0 = (tile % tiles_x) * FTW;
+  const size_t plane = (size_t)H * W;
+  if (tile_interior(ty0, tx0, H, W)) {
+    const float* base = img + (size_t)(ty0 - 2) * W + (tx0 - 2);
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) r[k][c] = base[c * plane + soff[k]];
+    return;
+  }
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    int e = tid + 256 * k;
+    e = e < NPI2 ? e : NPI2 - 1;
+    const int py = e / I2W, px = e - py * I2W;
+    const size_t off = (size_t)reflect_clamp(ty0 - 2 + py, H) * W + reflect_clamp(tx0 - 2 + px, W);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) r[k][c] = img[c * plane + off];
+  }
+}
+
+__device__ __forceinline__ void head_commit(const float (&r)[2][3], u32x2* imgH, u32x2* imgL, int tid) {
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int e = tid + 256 * k;
+    if (e < NPI2) {
+      f16x4 h = {0, 0, 0, 0}, l = {0, 0, 0, 0};
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float x = fminf(fmaxf(r[k][c], -65504.f), 65504.f);
+        h[c] = (_Float16)x;
+        l[c] = (_Float16)(x - (float)h[c]);
+      }
+      imgH[e] = __builtin_bit_cast(u32x2, h);
+      imgL[e] = __builtin_bit_cast(u32x2, l);
+    }
+  }
+}
+
+__device__ __forceinline__ void store_split4(u32x4* planes, int npp, int pix, int kq, const f32x4& v) {
+  // 4 consecutive channels 4kq..4kq+3 of halo pixel `pix` -> 8 bytes in the hi plane and 8 in the lo plane
+  _Float16 h[4], l[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float x = fminf(fmaxf(v[r], -65504.f), 65504.f);
+    h[r] = (_Float16)x;
+    l[r] = (_Float16)(x - (float)h[r]);
+  }
+  typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+  f16x4* ph = reinterpret_cast<f16x4*>(planes + (0 * 2 + (kq >> 1)) * npp + pix) + (kq & 1);
+  f16x4* pl = reinterpret_cast<f16x4*>(planes + (1 * 2 + (kq >> 1)) * npp + pix) + (kq & 1);
+  *ph = f16x4{h[0], h[1], h[2], h[3]};
+  *pl = f16x4{l[0], l[1], l[2], l[3]};
+}
+
+// 16->16 conv on the [4][NPP] planes of a 34 x 10 halo tile for the wave's 2 rows x 32 px (the c16 kernel's body)
+__device__ __forceinline__ void c16_compute(const u32x4* act, const u32x4* wgt, int wave, int li, int kq, f32x4 (&acc)[2][2]) {
+  constexpr int NPP = npp(8);
+  const int kh = kq & 1, ts = kq >> 1;
+#pragma unroll
+  for (int s = 0; s < 5; ++s) {
+    const int tap = 2 * s + ts;
+    const int tc = tap > 8 ? 8 : tap;
+    const int dy = tc / 3, dx = tc - dy * 3;
+    const f16x8 ah = __builtin_bit_cast(f16x8, wgt[((tap * 2 + 0) * 2 + kh) * 16 + li]);
+    const f16x8 al = __builtin_bit_cast(f16x8, wgt[((tap * 2 + 1) * 2 + kh) * 16 + li]);
+    f16x8 bh[2][2], bl[2][2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int pix = (wave * 2 + r + dy) * FHW + h * 16 + li + dx;
+        bh[r][h] = __builtin_bit_cast(f16x8, act[(0 * 2 + kh) * NPP + pix]);
+        bl[r][h] = __builtin_bit_cast(f16x8, act[(1 * 2 + kh) * NPP + pix]);
+      }
+#pragma unroll
+    for (int term = 0; term < 3; ++term)   // dependent MFMAs 4 apart
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+          acc[r][h] = __builtin_amdgcn_mfma_f32_16x16x32_f16(term == 2 ? al : ah, term == 1 ? bl[r][h] : bh[r][h], acc[r][h], 0, 0, 0);
+  }
+}
+
+// ---- conv11 of the level-1 / head encoders (3 channels in, <= 32 out) as f16x3 16x16x32 MFMA pairs.
+// K layout: 8-half slots, slot s = 4 kb + kq -> image row dy = s >> 1, pixels 2 (s & 1) + {0, 1}, channels RGB0; the 4th
+// pixel / 4th channel / 4th row slots carry zero weights.  Weights: [cout tile][kb][hi/lo][kq][16 couts] x 8 halfs.
+struct L1Conv { const u32x4* w; const float* b; float inv; };
+struct L1Weights { f16x8 a[2][2][2]; f32x4 bias[2]; float inv; };
+
+__device__ __forceinline__ void l1_load_weights(const L1Conv& c, int li, int kq, L1Weights& w) {
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct) {
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int hl = 0; hl < 2; ++hl) w.a[ct][kb][hl] = __builtin_bit_cast(f16x8, c.w[(((ct * 2 + kb) * 2 + hl) * 4 + kq) * 16 + li]);
+    w.bias[ct] = *reinterpret_cast<const f32x4*>(c.b + ct * 16 + 4 * kq);
+  }
+  w.inv = c.inv;
+}
+
+// relu(conv11) of 16 pixels (lane & 15; `base` = index of the pixel's 3x3 window's top-left in the 36-wide RGB0 tile)
+// x 16 couts of tile ct:  result rows = couts ct * 16 + 4 kq + {0..3}
+__device__ __forceinline__ f32x4 l1_conv_group(const u32x2* imgH, const u32x2* imgL, int base, int kq, const L1Weights& w, int ct) {
+  f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb) {
+    const int s = kb * 4 + kq;
+    const int row = (s >> 1) > 2 ? 2 : (s >> 1);
+    const int e0 = base + row * I2W + 2 * (s & 1);
+    const u32x2 h0 = imgH[e0], h1 = imgH[e0 + 1], l0 = imgL[e0], l1 = imgL[e0 + 1];
+    const f16x8 bh = __builtin_bit_cast(f16x8, u32x4{h0[0], h0[1], h1[0], h1[1]});
+    const f16x8 bl = __builtin_bit_cast(f16x8, u32x4{l0[0], l0[1], l1[0], l1[1]});
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w.a[ct][kb][0], bh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w.a[ct][kb][0], bl, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w.a[ct][kb][1], bh, acc, 0, 0, 0);
+  }
+  f32x4 x;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) x[r] = fmaxf(acc[r] * w.inv + w.bias[ct][r], 0.f);
+  return x;
+}
+
 inline int num_cus() {
   static int n = [] {
     int dev = 0, v = 0;

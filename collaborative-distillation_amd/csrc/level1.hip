@@ -1,0 +1,208 @@
+// Level 1 of the 16x cascade without materialising relu1_1.
+//
+// The level-1 encoder is ONE convolution (conv0 folded into conv11: 3 -> 24 channels, model_cd.py:724-727) and the
+// level-1 decoder is ONE convolution (conv11: 24 -> 3, model_cd.py:291-293), both at full image resolution.  Run layer
+// by layer the 24-channel feature map (96 B/px: 796 MB at 4K) is written by the encoder, read by the moments kernel and
+// read again by the decoder -- 2.4 GB of HBM traffic around 1.5 kFLOP/px of arithmetic.  Here relu1_1 only ever exists
+// as a tile in LDS:
+//     l1_moments_kernel (moments.hip)   image -> conv11 -> fp64 moments               12 B/px read
+//     l1_decode_kernel                  image -> conv11 -> folded conv11' -> image    12 B/px read + 12 B/px written
+//     l1_encode_kernel                  image -> conv11 -> relu1_1 (the API's wct_encode(1); same conv11 arithmetic)
+// conv11 runs as f16x3 with the K = 27 products in the RGB0 slot layout of enc_head_kernel (conv3x3_f16.hip); the
+// three kernels share l1_conv_group(), so their relu1_1 values are bit-identical.
+#include "wct_common.h"
+#include "conv_f16_dev.h"
+
+namespace {
+
+struct L1DecArgs {
+  const float* img; float* out;
+  L1Conv c;                                  // conv11 of the encoder (f16x3 slot layout, 2 cout tiles)
+  const u32x4* w2; const float* b2;          // folded decoder conv: [2 chunks][10 taps][hl][kh][16] x 16 B, bias [16]
+  const float* inv2_ptr; float inv2;
+  int H, W, tiles_x, tiles_y;
+};
+
+struct L1EncArgs {
+  const float* img; float* out;              // out: NHWC fp32 [H*W][C]
+  L1Conv c;
+  int C, H, W, tiles_x, tiles_y;
+};
+
+// image -> relu1_1 (NHWC fp32)
+__global__ __launch_bounds__(256, 3) void l1_encode_kernel(L1EncArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  u32x2* imgH = reinterpret_cast<u32x2*>(smem);
+  u32x2* imgL = imgH + IMG_E;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, kq = lane >> 4;
+  const int ntiles = a.tiles_x * a.tiles_y;
+  if (tid < 4) { imgH[NPI2 + tid] = u32x2{0u, 0u}; imgL[NPI2 + tid] = u32x2{0u, 0u}; }
+  L1Weights w;
+  l1_load_weights(a.c, li, kq, w);
+  int soff[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    int e = tid + 256 * k;
+    e = e < NPI2 ? e : NPI2 - 1;
+    soff[k] = (e / I2W) * a.W + e % I2W;
+  }
+  float pxr[2][3];
+  int v = blockIdx.x;
+  if (v < ntiles) {
+    head_fetch(a.img, a.H, a.W, a.tiles_x, pxr, soff, xcd_swizzle(v, ntiles), tid);
+    head_commit(pxr, imgH, imgL, tid);
+  }
+  for (; v < ntiles; v += gridDim.x) {
+    const int tile = xcd_swizzle(v, ntiles);
+    const int ty0 = (tile / a.tiles_x) * 8, tx0 = (tile % a.tiles_x) * FTW;
+    __syncthreads();
+    const int vn = v + gridDim.x;
+    if (vn < ntiles) head_fetch(a.img, a.H, a.W, a.tiles_x, pxr, soff, xcd_swizzle(vn, ntiles), tid);
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int py = wave * 2 + r, px = h * 16 + li;
+        const int base = (py + 1) * I2W + px + 1;   // top-left of the 3x3 window in the 36 x 12 tile (origin -2, -2)
+        const int gy = ty0 + py, gx = tx0 + px;
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+          const f32x4 x = l1_conv_group(imgH, imgL, base, kq, w, ct);
+          const int co = ct * 16 + 4 * kq;
+          if (gy < a.H && gx < a.W && co < a.C) *reinterpret_cast<f32x4*>(a.out + ((size_t)gy * a.W + gx) * a.C + co) = x;
+        }
+      }
+    __syncthreads();
+    if (vn < ntiles) head_commit(pxr, imgH, imgL, tid);
+  }
+}
+
+// image -> relu1_1 on the 34 x 10 halo (LDS, split f16) -> folded decoder conv (24 -> 3) + ReLU -> planar image
+__global__ __launch_bounds__(256, 2) void l1_decode_kernel(L1DecArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NPP = npp(8), NPH = nph(8), NG = 6;
+  u32x2* imgH = reinterpret_cast<u32x2*>(smem);
+  u32x2* imgL = imgH + IMG_E;
+  u32x4* act = reinterpret_cast<u32x4*>(imgL + IMG_E);   // [2 chunks][4][NPP]
+  u32x4* wgt = act + 2 * 4 * NPP;                         // [2 chunks][640]
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, kq = lane >> 4;
+  const int ntiles = a.tiles_x * a.tiles_y;
+  for (int e = tid; e < 2 * 640; e += 256) wgt[e] = a.w2[e];
+  if (tid < 4) { imgH[NPI2 + tid] = u32x2{0u, 0u}; imgL[NPI2 + tid] = u32x2{0u, 0u}; }
+  L1Weights w;
+  l1_load_weights(a.c, li, kq, w);
+  const float inv2 = a.inv2_ptr ? *a.inv2_ptr : a.inv2;
+  const f32x4 bias2 = *reinterpret_cast<const f32x4*>(a.b2);
+  const size_t plane = (size_t)a.H * a.W;
+  int soff[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    int e = tid + 256 * k;
+    e = e < NPI2 ? e : NPI2 - 1;
+    soff[k] = (e / I2W) * a.W + e % I2W;
+  }
+  int gpix[NG], gpy[NG], gpx[NG];
+  bool gok[NG];
+#pragma unroll
+  for (int u = 0; u < NG; ++u) {
+    const int pixr = (wave + 4 * u) * 16 + li;
+    gok[u] = pixr < NPH;
+    gpix[u] = gok[u] ? pixr : NPH - 1;
+    gpy[u] = gpix[u] / FHW;
+    gpx[u] = gpix[u] - gpy[u] * FHW;
+  }
+  float pxr[2][3];
+  int v = blockIdx.x;
+  if (v < ntiles) {
+    head_fetch(a.img, a.H, a.W, a.tiles_x, pxr, soff, xcd_swizzle(v, ntiles), tid);
+    head_commit(pxr, imgH, imgL, tid);
+  }
+  for (; v < ntiles; v += gridDim.x) {
+    const int tile = xcd_swizzle(v, ntiles);
+    const int ty0 = (tile / a.tiles_x) * 8, tx0 = (tile % a.tiles_x) * FTW;
+    __syncthreads();   // image window in LDS; previous tile's planes consumed
+    const int vn = v + gridDim.x;
+    if (vn < ntiles) head_fetch(a.img, a.H, a.W, a.tiles_x, pxr, soff, xcd_swizzle(vn, ntiles), tid);
+    const bool interior = tile_interior(ty0, tx0, a.H, a.W);
+    // ---- relu1_1 on the 340 halo pixels, each evaluated at its REFLECTED image coordinate (the decoder's own padding)
+#pragma unroll
+    for (int u = 0; u < NG; ++u) {
+      int base;
+      if (interior) {
+        base = gpy[u] * I2W + gpx[u];
+      } else {
+        const int iy = reflect_clamp(ty0 - 1 + gpy[u], a.H) - (ty0 - 2), ix = reflect_clamp(tx0 - 1 + gpx[u], a.W) - (tx0 - 2);
+        base = (iy - 1) * I2W + ix - 1;
+      }
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) {
+        const f32x4 x = l1_conv_group(imgH, imgL, base, kq, w, ct);
+        if (gok[u]) store_split4(act + ct * 4 * NPP, NPP, gpix[u], kq, x);
+      }
+    }
+    __syncthreads();
+    // ---- folded decoder conv on the two 16-channel chunks (the arithmetic of conv3x3_f16_c16_kernel<OUT3>)
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) acc[r][h] = f32x4{0.f, 0.f, 0.f, 0.f};
+    c16_compute(act, wgt, wave, li, kq, acc);
+    c16_compute(act + 4 * NPP, wgt + 640, wave, li, kq, acc);
+    if (kq == 0) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int gx = tx0 + h * 16 + li;
+#pragma unroll
+        for (int r2 = 0; r2 < 2; ++r2) {
+          const int gy = ty0 + wave * 2 + r2;
+          if (gy < a.H && gx < a.W) {
+            const size_t off = (size_t)gy * a.W + gx;
+            a.out[off] = fmaxf(acc[r2][h][0] * inv2 + bias2[0], 0.f);
+            a.out[plane + off] = fmaxf(acc[r2][h][1] * inv2 + bias2[1], 0.f);
+            a.out[2 * plane + off] = fmaxf(acc[r2][h][2] * inv2 + bias2[2], 0.f);
+          }
+        }
+      }
+    }
+    if (vn < ntiles) head_commit(pxr, imgH, imgL, tid);
+  }
+}
+
+}  // namespace
+
+bool l1_capable(const ConvDesc& enc0) {
+  return (enc0.flags & CONV_IN_NCHW3) && !(enc0.flags & (CONV_POOL_OUT | CONV_NO_RELU)) && enc0.l1w16 && enc0.cout <= 32 && (enc0.cout % 4) == 0;
+}
+
+hipError_t launch_l1_encode(const ConvDesc& e, const float* img, float* out, int H, int W, hipStream_t s) {
+  if (!l1_capable(e) || H < 2 || W < 2) return hipErrorInvalidValue;
+  L1EncArgs a;
+  a.img = img; a.out = out;
+  a.c.w = reinterpret_cast<const u32x4*>(e.l1w16); a.c.b = e.l1bias; a.c.inv = e.l1inv;
+  a.C = e.cout; a.H = H; a.W = W; a.tiles_x = (W + FTW - 1) / FTW; a.tiles_y = (H + 7) / 8;
+  const size_t lds = (size_t)2 * IMG_E * 8;
+  const int ntiles = a.tiles_x * a.tiles_y, grid = ntiles < 3 * num_cus() ? ntiles : 3 * num_cus();
+  hipLaunchKernelGGL(l1_encode_kernel, dim3(grid), dim3(256), lds, s, a);
+  return hipGetLastError();
+}
+
+// dec0: the decoder's only conv with the WCT map folded in (split-f16 packed, 10 taps, cout_pad 16)
+hipError_t launch_l1_decode(const ConvDesc& e, const ConvDesc& dec0, const float* img, float* out, int H, int W, hipStream_t s) {
+  if (!l1_capable(e) || H < 2 || W < 2 || !dec0.wpk16 || dec0.cout != 3 || dec0.cout_pad != 16 || dec0.cin != e.cout ||
+      dec0.cin_chunks != 2 || !(dec0.flags & CONV_OUT_NCHW3) || (dec0.flags & (CONV_UP_IN | CONV_NO_RELU | CONV_POOL_OUT)))
+    return hipErrorInvalidValue;
+  L1DecArgs a;
+  a.img = img; a.out = out;
+  a.c.w = reinterpret_cast<const u32x4*>(e.l1w16); a.c.b = e.l1bias; a.c.inv = e.l1inv;
+  a.w2 = reinterpret_cast<const u32x4*>(dec0.wpk16); a.b2 = dec0.bias; a.inv2_ptr = dec0.inv_scale_ptr; a.inv2 = dec0.inv_scale;
+  a.H = H; a.W = W; a.tiles_x = (W + FTW - 1) / FTW; a.tiles_y = (H + 7) / 8;
+  const size_t lds = (size_t)2 * IMG_E * 8 + ((size_t)2 * 4 * npp(8) + 2 * 640) * 16;   // 72.5 KB: 2 per CU
+  hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(l1_decode_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (err != hipSuccess) return err;
+  const int ntiles = a.tiles_x * a.tiles_y, grid = ntiles < 2 * num_cus() ? ntiles : 2 * num_cus();
+  hipLaunchKernelGGL(l1_decode_kernel, dim3(grid), dim3(256), lds, s, a);
+  return hipGetLastError();
+}

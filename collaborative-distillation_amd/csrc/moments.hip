@@ -15,6 +15,7 @@
 // operand reads (lane = channel l&15 of pixel l>>4) bank-conflict free.  Partial tiles go to a workspace and a
 // second kernel adds them in a fixed order -> bitwise reproducible, no atomics.
 #include "wct_common.h"
+#include "conv_f16_dev.h"
 #include <algorithm>
 #include <cstdlib>
 
@@ -184,6 +185,100 @@ __global__ __launch_bounds__(256, 2) void moments_kernel(MomArgs a) {
   }
 }
 
+// ---- level 1 of the 16x cascade: moments of relu1_1 = relu(conv11(image)) WITHOUT the feature map in HBM (level1.hip).
+// A persistent workgroup walks 32 x 8 image tiles: conv11 (f16x3, l1_conv_group) writes the tile's 256 x C features
+// into the LDS tile the pair loop above consumes (pixel split: every wave owns all three tile pairs for a quarter of
+// the pixels); pixels outside the window [x0, x1) x [0, H) are written as zeros.  Partials: one set per workgroup.
+struct L1MomArgs {
+  const float* img;
+  L1Conv c;
+  int H, W, x0, x1, tiles_x, tiles_y;
+  int Cs;                // LDS row stride (floats): 48
+  double* part_sq;       // [grid][3][256]
+  double* part_sum;      // [grid][32]
+};
+
+__global__ __launch_bounds__(256, 2) void l1_moments_kernel(L1MomArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NP = 3, T = 2, MP = 256;
+  u32x2* imgH = reinterpret_cast<u32x2*>(smem);
+  u32x2* imgL = imgH + IMG_E;
+  float* feat = reinterpret_cast<float*>(imgL + IMG_E);   // [256][Cs]; reused for the cross-wave reduction at the end
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, kq = lane >> 4;     // conv roles; the pair loop uses the same split (c = li, pk = kq)
+  const int ntiles = a.tiles_x * a.tiles_y;
+  if (tid < 4) { imgH[NPI2 + tid] = u32x2{0u, 0u}; imgL[NPI2 + tid] = u32x2{0u, 0u}; }
+  for (int e = tid; e < MP * a.Cs; e += 256) feat[e] = 0.f;   // columns >= 32 are never written
+  L1Weights w;
+  l1_load_weights(a.c, li, kq, w);
+  // the three tile pairs (0,0), (0,1), (1,1) of the 32 padded channels
+  int offA[3] = {li, li, 16 + li}, offB[3] = {li, 16 + li, 16 + li};
+  f64x4 acc[3];
+  double s[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) { acc[j] = f64x4{0., 0., 0., 0.}; s[j] = 0.; }
+  int soff[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    int e = tid + 256 * k;
+    e = e < NPI2 ? e : NPI2 - 1;
+    soff[k] = (e / I2W) * a.W + e % I2W;
+  }
+  const int xhi = a.x1 < a.W ? a.x1 : a.W;
+  float pxr[2][3];
+  int v = blockIdx.x;
+  if (v < ntiles) {
+    head_fetch(a.img, a.H, a.W, a.tiles_x, pxr, soff, xcd_swizzle(v, ntiles), tid);
+    head_commit(pxr, imgH, imgL, tid);
+  }
+  for (; v < ntiles; v += gridDim.x) {
+    const int tile = xcd_swizzle(v, ntiles);
+    const int ty0 = (tile / a.tiles_x) * 8, tx0 = (tile % a.tiles_x) * FTW;
+    __syncthreads();   // image window in LDS; the previous tile's features consumed
+    const int vn = v + gridDim.x;
+    if (vn < ntiles) head_fetch(a.img, a.H, a.W, a.tiles_x, pxr, soff, xcd_swizzle(vn, ntiles), tid);
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int py = wave * 2 + r, px = h * 16 + li;
+        const int base = (py + 1) * I2W + px + 1;
+        const int gy = ty0 + py, gx = tx0 + px;
+        const bool in = gy < a.H && gx >= a.x0 && gx < xhi;
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+          const f32x4 x = l1_conv_group(imgH, imgL, base, kq, w, ct);
+          *reinterpret_cast<f32x4*>(feat + (py * 32 + px) * a.Cs + ct * 16 + 4 * kq) = in ? x : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+      }
+    __syncthreads();
+    const int st0 = wave * (MP / 16);
+    tile_steps3(feat, a.Cs, st0, st0 + MP / 16, kq, offA, offB, acc[0], acc[1], acc[2], s[0], s[1], s[2]);
+    if (vn < ntiles) head_commit(pxr, imgH, imgL, tid);
+  }
+  // add the four waves' partial sets through LDS, fixed order (as moments_kernel's pixel-split tail)
+  __syncthreads();
+  double* red = reinterpret_cast<double*>(feat);   // [4][NP][256] + [4][T*16]
+  double* reds = red + (size_t)4 * NP * 256;
+#pragma unroll
+  for (int j = 0; j < NP; ++j) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[((size_t)wave * NP + j) * 256 + (kq + 4 * r) * 16 + li] = acc[j][r];
+    if (j != 1) {   // diagonal pairs own the channel sums of their tile
+      double t = s[j];
+      t += __shfl_xor(t, 16);
+      t += __shfl_xor(t, 32);
+      if (kq == 0) reds[wave * T * 16 + offA[j]] = t;
+    }
+  }
+  __syncthreads();
+  const int nsq = NP * 256, ns = T * 16;
+  for (int e = tid; e < nsq; e += 256)
+    a.part_sq[(size_t)blockIdx.x * nsq + e] = (red[e] + red[nsq + e]) + (red[2 * nsq + e] + red[3 * nsq + e]);
+  for (int e = tid; e < ns; e += 256)
+    a.part_sum[(size_t)blockIdx.x * ns + e] = (reds[e] + reds[ns + e]) + (reds[2 * ns + e] + reds[3 * ns + e]);
+}
+
 // partial -> final, fixed summation order (bitwise reproducible): a 256-thread block owns 16 consecutive output
 // elements x 16 slices of the chunk index; slices are combined through LDS in slice order.
 __global__ __launch_bounds__(256) void moments_reduce_kernel(MomArgs a, double* sum, double* sumsq) {
@@ -285,5 +380,30 @@ hipError_t launch_moments(const float* feat, int C, int h, int wfull, int x0, in
   if (le != hipSuccess) return le;
   const long ne = (long)a.NP * 256 + a.T * 16;
   hipLaunchKernelGGL(moments_reduce_kernel, dim3((unsigned)((ne + 15) / 16)), dim3(256), 0, s, a, sum, sumsq);
+  return hipGetLastError();
+}
+
+size_t l1_moments_workspace_bytes() { return (size_t)2 * num_cus() * (3 * 256 + 32) * sizeof(double); }
+
+hipError_t launch_l1_moments(const ConvDesc& e, const float* img, int H, int W, int x0, int x1, double* sum, double* sumsq,
+                             void* ws, size_t ws_bytes, hipStream_t s) {
+  if (!l1_capable(e) || H < 2 || W < 2 || x0 < 0 || x1 > W || x1 <= x0) return hipErrorInvalidValue;
+  if (ws_bytes < l1_moments_workspace_bytes()) return hipErrorOutOfMemory;
+  L1MomArgs a;
+  a.img = img;
+  a.c.w = reinterpret_cast<const u32x4*>(e.l1w16); a.c.b = e.l1bias; a.c.inv = e.l1inv;
+  a.H = H; a.W = W; a.x0 = x0; a.x1 = x1; a.tiles_x = (W + FTW - 1) / FTW; a.tiles_y = (H + 7) / 8;
+  a.Cs = 48;
+  const int ntiles = a.tiles_x * a.tiles_y, grid = ntiles < 2 * num_cus() ? ntiles : 2 * num_cus();
+  a.part_sq = reinterpret_cast<double*>(ws);
+  a.part_sum = a.part_sq + (size_t)grid * 3 * 256;
+  const size_t lds = (size_t)2 * IMG_E * 8 + (size_t)256 * a.Cs * sizeof(float);   // 56 KB (the reduction needs 25 KB of it)
+  hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(l1_moments_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (err != hipSuccess) return err;
+  hipLaunchKernelGGL(l1_moments_kernel, dim3(grid), dim3(256), lds, s, a);
+  MomArgs m{};
+  m.C = e.cout; m.T = 2; m.NP = 3; m.NPC = grid; m.part_sq = a.part_sq; m.part_sum = a.part_sum;
+  const long ne = (long)m.NP * 256 + m.T * 16;
+  hipLaunchKernelGGL(moments_reduce_kernel, dim3((unsigned)((ne + 15) / 16)), dim3(256), 0, s, m, sum, sumsq);
   return hipGetLastError();
 }

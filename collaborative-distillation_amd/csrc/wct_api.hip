@@ -28,6 +28,8 @@ struct LayerDev {
   float* wpk = nullptr;
   float* bias = nullptr;
   void* wpk16 = nullptr;  // split-f16 weights (all but the 3-channel first conv)
+  void* l1w16 = nullptr;  // 3-channel first conv with <= 32 couts: f16x3 slot packing for the level-1 kernels
+  float* l1bias = nullptr;
 };
 
 struct Module {
@@ -60,6 +62,9 @@ struct wct_ctx {
   // workspace
   DevBuf featC, featS, tmpT, wsAsm, small, foldW, foldW16, eigC, eigS[6];
   int cur_level = 0, cur_h = 0, cur_w = 0;  // content feature held in featC by wct_content_encode
+  DevBuf l1img;       // level 1 fused: copy of the content image between wct_content_encode and wct_content_decode
+  int cur_H = 0, cur_W = 0;
+  int l1fuse = 1;     // 1: level 1 of the 16x cascade without materialising relu1_1 (level1.hip)
   int sp = 1;         // 1: intermediate activations of the f16x3 path in SP16 (split at the producer, DMA-staged consumers)
   int fuse = 1;       // 1: fused conv11+conv12+pool / conv12+conv11 kernels at the full-resolution ends of the 16x networks
   int overlap = 1;    // 1: style side on the side lane (overlaps the content side); 0: everything on the caller's stream
@@ -244,24 +249,27 @@ float pack_weights_f16(const float* w, int cout, int cin, int cout_pad, int taps
 // split-f16 packing of the 3-channel first conv for the fused encoder head (conv3x3_f16.hip, enc_head_kernel):
 // K = 64 in 8-half slots, slot s = 4 kb + kq -> image row dy = s >> 1, pixels 2 (s & 1) + {0, 1}, channels RGB0;
 // layout [kb][hi/lo][kq][16 couts] x 8 halfs.  in3: the fp32 packing [tap][4][16] (conv0 already folded).  Returns 2^-e.
-float pack_head_f16(const std::vector<float>& in3, std::vector<_Float16>& out) {
+float pack_head_f16(const std::vector<float>& in3, int cout_pad, int ntile, std::vector<_Float16>& out) {
+  // in3: [tap][4][cout_pad]; out: [cout tile][kb][hi/lo][kq][16 couts] x 8 halfs (couts beyond cout_pad: zeros)
   float mx = 0.f;
   for (float x : in3) mx = std::max(mx, std::fabs(x));
   int ex = 0;
   if (mx > 0.f && std::isfinite(mx)) { (void)std::frexp(mx, &ex); ex = 9 - ex; }
   const float scale = std::ldexp(1.f, ex);
-  out.assign((size_t)2 * 2 * 4 * 16 * 8, (_Float16)0.f);
-  for (int kb = 0; kb < 2; ++kb)
-    for (int kq = 0; kq < 4; ++kq)
-      for (int o = 0; o < 16; ++o)
-        for (int j = 0; j < 8; ++j) {
-          const int s = kb * 4 + kq, dy = s >> 1, px = 2 * (s & 1) + (j >> 2), ch = j & 3;
-          if (dy > 2 || px > 2 || ch > 2) continue;
-          const float x = in3[((size_t)(dy * 3 + px) * 4 + ch) * 16 + o] * scale;
-          const _Float16 h = (_Float16)x;
-          out[((((size_t)kb * 2 + 0) * 4 + kq) * 16 + o) * 8 + j] = h;
-          out[((((size_t)kb * 2 + 1) * 4 + kq) * 16 + o) * 8 + j] = (_Float16)(x - (float)h);
-        }
+  out.assign((size_t)ntile * 2 * 2 * 4 * 16 * 8, (_Float16)0.f);
+  for (int ct = 0; ct < ntile; ++ct)
+    for (int kb = 0; kb < 2; ++kb)
+      for (int kq = 0; kq < 4; ++kq)
+        for (int oo = 0; oo < 16; ++oo)
+          for (int j = 0; j < 8; ++j) {
+            const int s = kb * 4 + kq, dy = s >> 1, px = 2 * (s & 1) + (j >> 2), ch = j & 3, o = ct * 16 + oo;
+            if (dy > 2 || px > 2 || ch > 2 || o >= cout_pad) continue;
+            const float x = in3[((size_t)(dy * 3 + px) * 4 + ch) * cout_pad + o] * scale;
+            const _Float16 h = (_Float16)x;
+            const size_t base = ((size_t)ct * 2 + kb) * 2;
+            out[(((base + 0) * 4 + kq) * 16 + oo) * 8 + j] = h;
+            out[(((base + 1) * 4 + kq) * 16 + oo) * 8 + j] = (_Float16)(x - (float)h);
+          }
   return std::ldexp(1.f, -ex);
 }
 
@@ -277,6 +285,8 @@ void free_module(Module& m) {
     if (l.bias_raw) (void)hipFree(l.bias_raw);
     if (l.wpk) (void)hipFree(l.wpk);
     if (l.wpk16) (void)hipFree(l.wpk16);
+    if (l.l1w16) (void)hipFree(l.l1w16);
+    if (l.l1bias) (void)hipFree(l.l1bias);
     if (l.bias) (void)hipFree(l.bias);
   }
   m.layers.clear();
@@ -332,6 +342,14 @@ int encode_impl(wct_ctx* ctx, Lane& ln, int level, const float* img, int H, int 
     h /= 2; w /= 2;
     cur = dst;
     i0 = 2;
+  }
+  if (i0 == 0 && ctx->conv_mode == 1 && ctx->fuse && ctx->l1fuse && m.layers.size() == 1 && l1_capable(m.layers[0].d)) {
+    // the level-1 encoder on its own (API): same conv11 arithmetic as the fused level-1 kernels
+    const ConvDesc& d = m.layers[0].d;
+    const double px = (double)h * w;
+    ProfScope ps(ctx, ln.stream, "l1_encode<3-24>", 2.0 * 27.0 * d.cout * px, 4.0 * (3 + d.cout) * px);
+    HIPCHK(ctx, launch_l1_encode(d, cur, feat_nhwc, h, w, ln.stream));
+    i0 = 1;
   }
   for (size_t i = i0; i < m.layers.size(); ++i) {
     const auto& l = m.layers[i];
@@ -476,6 +494,35 @@ void level_dims(int level, int H, int W, int& h, int& w) {
   for (int i = 1; i < level; ++i) { h /= 2; w /= 2; }
 }
 
+// level 1 of the 16x cascade without relu1_1 in HBM: single-conv encoder (3 -> <= 32) and single-conv decoder (-> 3)
+bool l1_fused(const wct_ctx* ctx, int level) {
+  if (ctx->conv_mode != 1 || !ctx->fuse || !ctx->l1fuse) return false;
+  const Module& me = ctx->mod[WCT_KIND_ENC][level];
+  const Module& md = ctx->mod[WCT_KIND_DEC][level];
+  if (!me.loaded || !md.loaded || me.layers.size() != 1 || md.layers.size() != 1) return false;
+  const ConvDesc& e = me.layers[0].d;
+  const ConvDesc& d = md.layers[0].d;
+  return l1_capable(e) && d.cin == e.cout && d.cout == 3 && d.cout_pad == 16 && d.cin_chunks == 2 && (d.flags & CONV_OUT_NCHW3);
+}
+
+int l1_moments_impl(wct_ctx* ctx, Lane& ln, int level, const float* img, int H, int W, int x0, int x1, double* sum, double* sumsq) {
+  const ConvDesc& e = ctx->mod[WCT_KIND_ENC][level].layers[0].d;
+  if (H < 2 || W < 2 || x0 < 0 || x1 > W || x1 <= x0) return fail(ctx, WCT_ERR_INVALID, "moments: bad window %dx%d [%d,%d)", H, W, x0, x1);
+  if (int rc = ensure(ctx, ln.wsMom, l1_moments_workspace_bytes())) return rc;
+  const double px = (double)H * W;
+  ProfScope ps(ctx, ln.stream, "l1_moments_fused<3-24>", 2.0 * (27.0 * e.cout + (double)e.cout * e.cout) * px, 12.0 * px);
+  HIPCHK(ctx, launch_l1_moments(e, img, H, W, x0, x1, sum, sumsq, ln.wsMom.p, ln.wsMom.cap, ln.stream));
+  return WCT_OK;
+}
+
+int l1_decode_impl(wct_ctx* ctx, int level, const float* img, int H, int W, const ConvDesc& first, float* out) {
+  const ConvDesc& e = ctx->mod[WCT_KIND_ENC][level].layers[0].d;
+  const double px = (double)H * W;
+  ProfScope ps(ctx, ctx->main.stream, "l1_decode_fused<3-24-3>", 2.0 * 27.0 * e.cout * px * 2, 24.0 * px);
+  HIPCHK(ctx, launch_l1_decode(e, first, img, out, H, W, ctx->main.stream));
+  return WCT_OK;
+}
+
 // style side of one level on the SIDE lane: sF = encoder(styleImg) (WCT.py:100), its moments and eigen-decomposition.
 // Independent of the content, so it is enqueued first and overlaps the content side.  Leaves eigS[level] + ev_style[level].
 int style_side(wct_ctx* ctx, int level, const float* style, int Hs, int Ws) {
@@ -489,8 +536,12 @@ int style_side(wct_ctx* ctx, int level, const float* style, int Hs, int Ws) {
   SumsView sv;
   if (int rc = sums_view(ctx, ln, sv)) return rc;
   float* fS = reinterpret_cast<float*>(ctx->featS.p);
-  if (int rc = encode_impl(ctx, ln, level, style, Hs, Ws, fS, nullptr, nullptr)) return rc;
-  if (int rc = moments_impl(ctx, ln, fS, C, hs, ws, 0, ws, sv.sum, sv.sumsq)) return rc;
+  if (l1_fused(ctx, level)) {
+    if (int rc = l1_moments_impl(ctx, ln, level, style, Hs, Ws, 0, Ws, sv.sum, sv.sumsq)) return rc;
+  } else {
+    if (int rc = encode_impl(ctx, ln, level, style, Hs, Ws, fS, nullptr, nullptr)) return rc;
+    if (int rc = moments_impl(ctx, ln, fS, C, hs, ws, 0, ws, sv.sum, sv.sumsq)) return rc;
+  }
   if (int rc = eig_impl(ctx, ln, C, (double)hs * ws, sv.sum, sv.sumsq, 0, ctx->eigS[level], sv.info + 1)) return rc;
   HIPCHK(ctx, hipEventRecord(ctx->ev_style[level], ln.stream));
   return WCT_OK;
@@ -519,8 +570,13 @@ int content_side(wct_ctx* ctx, int level, const float* content, int H, int W, fl
   if (int rc = mb_view(ctx, &M, &b)) return rc;
   float* fC = reinterpret_cast<float*>(ctx->featC.p);
   // cF = encoder(contentImg)                                  (WCT.py:101)
-  if (int rc = encode_impl(ctx, ln, level, content, H, W, fC, nullptr, nullptr)) return rc;
-  if (int rc = moments_impl(ctx, ln, fC, C, h, w, 0, w, sv.sum, sv.sumsq)) return rc;
+  const bool l1 = l1_fused(ctx, level);
+  if (l1) {
+    if (int rc = l1_moments_impl(ctx, ln, level, content, H, W, 0, W, sv.sum, sv.sumsq)) return rc;
+  } else {
+    if (int rc = encode_impl(ctx, ln, level, content, H, W, fC, nullptr, nullptr)) return rc;
+    if (int rc = moments_impl(ctx, ln, fC, C, h, w, 0, w, sv.sum, sv.sumsq)) return rc;
+  }
   if (int rc = eig_impl(ctx, ln, C, (double)h * w, sv.sum, sv.sumsq, 1, ctx->eigC, sv.info)) return rc;
   // csF = wct.transform(cF, sF, csF, alpha)                  (WCT.py:104) -- as an affine map
   HIPCHK(ctx, hipStreamWaitEvent(ln.stream, ctx->ev_style[level], 0));
@@ -528,7 +584,11 @@ int content_side(wct_ctx* ctx, int level, const float* content, int H, int W, fl
   // Img = decoder(csF)                                       (WCT.py:105) -- M, b folded into the first conv
   ConvDesc first;
   if (int rc = fold_impl(ctx, level, M, b, first)) return rc;
-  if (int rc = decode_impl(ctx, level, fC, h, w, &first, out)) return rc;
+  if (l1) {
+    if (int rc = l1_decode_impl(ctx, level, content, H, W, first, out)) return rc;
+  } else {
+    if (int rc = decode_impl(ctx, level, fC, h, w, &first, out)) return rc;
+  }
   if (Ho) *Ho = h << (level - 1);
   if (Wo) *Wo = w << (level - 1);
   return WCT_OK;
@@ -554,6 +614,7 @@ int wct_create(int device, wct_ctx** out) {
   if (const char* m = getenv("WCT_OVERLAP")) c->overlap = m[0] != '0';
   if (const char* m = getenv("WCT_FUSE")) c->fuse = m[0] != '0';
   if (const char* m = getenv("WCT_SP")) c->sp = m[0] != '0';
+  if (const char* m = getenv("WCT_L1FUSE")) c->l1fuse = m[0] != '0';
   bool ok = hipStreamCreateWithFlags(&c->side.stream, hipStreamNonBlocking) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess;
   for (int l = 1; l <= 5 && ok; ++l) ok = hipEventCreateWithFlags(&c->ev_style[l], hipEventDisableTiming) == hipSuccess;
@@ -572,7 +633,7 @@ void wct_destroy(wct_ctx* ctx) {
     for (int l = 0; l < 6; ++l) free_module(ctx->mod[k][l]);
   for (Lane* ln : {&ctx->main, &ctx->side})
     for (DevBuf* b : {&ln->actA, &ln->actB, &ln->wsMom, &ln->wsEig, &ln->sums}) release(*b);
-  for (DevBuf* b : {&ctx->featC, &ctx->featS, &ctx->tmpT, &ctx->wsAsm, &ctx->small, &ctx->foldW, &ctx->foldW16, &ctx->eigC}) release(*b);
+  for (DevBuf* b : {&ctx->featC, &ctx->featS, &ctx->tmpT, &ctx->wsAsm, &ctx->small, &ctx->foldW, &ctx->foldW16, &ctx->eigC, &ctx->l1img}) release(*b);
   for (int l = 0; l < 6; ++l) {
     release(ctx->eigS[l]);
     if (ctx->ev_style[l]) (void)hipEventDestroy(ctx->ev_style[l]);
@@ -635,9 +696,19 @@ int wct_load_module(wct_ctx* ctx, int kind, int level, int n_layers, const wct_l
     if (int rc = upload(ctx, &ld.wpk, wpk)) return rc;
     if (int rc = upload(ctx, &ld.bias, bias)) return rc;
     ld.d.wpk = ld.wpk; ld.d.bias = ld.bias;
+    if (in3 && ld.d.cout_pad <= 32) {   // level-1 kernels (level1.hip): two cout tiles, bias padded to 32
+      std::vector<_Float16> w16;
+      ld.d.l1inv = pack_head_f16(wpk, ld.d.cout_pad, 2, w16);
+      HIPCHK(ctx, hipMalloc(&ld.l1w16, w16.size() * sizeof(_Float16)));
+      HIPCHK(ctx, hipMemcpy(ld.l1w16, w16.data(), w16.size() * sizeof(_Float16), hipMemcpyHostToDevice));
+      std::vector<float> b32(32, 0.f);
+      for (int o = 0; o < ld.d.cout_pad && o < 32; ++o) b32[o] = bias[o];
+      if (int rc = upload(ctx, &ld.l1bias, b32)) return rc;
+      ld.d.l1w16 = ld.l1w16; ld.d.l1bias = ld.l1bias;
+    }
     if (in3 && ld.d.cout_pad == 16) {
       std::vector<_Float16> w16;
-      ld.d.inv_scale = pack_head_f16(wpk, w16);
+      ld.d.inv_scale = pack_head_f16(wpk, 16, 1, w16);
       HIPCHK(ctx, hipMalloc(&ld.wpk16, w16.size() * sizeof(_Float16)));
       HIPCHK(ctx, hipMemcpy(ld.wpk16, w16.data(), w16.size() * sizeof(_Float16), hipMemcpyHostToDevice));
       ld.d.wpk16 = ld.wpk16;
@@ -813,11 +884,19 @@ int wct_content_encode(wct_ctx* ctx, int level, const float* content, int H, int
   int h, w;
   level_dims(level, H, W, h, w);
   if (x1 < 0) x1 = w;
-  if (int rc = ensure(ctx, ctx->featC, (size_t)h * w * C * sizeof(float))) return rc;
-  float* fC = reinterpret_cast<float*>(ctx->featC.p);
-  if (int rc = encode_impl(ctx, ctx->main, level, content, H, W, fC, nullptr, nullptr)) return rc;
-  if (int rc = moments_impl(ctx, ctx->main, fC, C, h, w, x0, x1, sum, sumsq)) return rc;
-  ctx->cur_level = level; ctx->cur_h = h; ctx->cur_w = w;
+  if (l1_fused(ctx, level)) {
+    // relu1_1 is never materialised: keep a copy of the image for wct_content_decode (12 B/px, device to device)
+    const size_t ib = (size_t)3 * H * W * sizeof(float);
+    if (int rc = ensure(ctx, ctx->l1img, ib)) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->l1img.p, content, ib, hipMemcpyDeviceToDevice, ctx->main.stream));
+    if (int rc = l1_moments_impl(ctx, ctx->main, level, content, H, W, x0, x1, sum, sumsq)) return rc;
+  } else {
+    if (int rc = ensure(ctx, ctx->featC, (size_t)h * w * C * sizeof(float))) return rc;
+    float* fC = reinterpret_cast<float*>(ctx->featC.p);
+    if (int rc = encode_impl(ctx, ctx->main, level, content, H, W, fC, nullptr, nullptr)) return rc;
+    if (int rc = moments_impl(ctx, ctx->main, fC, C, h, w, x0, x1, sum, sumsq)) return rc;
+  }
+  ctx->cur_level = level; ctx->cur_h = h; ctx->cur_w = w; ctx->cur_H = H; ctx->cur_W = W;
   if (h_out) *h_out = h;
   if (w_out) *w_out = w;
   return WCT_OK;
@@ -844,7 +923,11 @@ int wct_content_decode(wct_ctx* ctx, int level, const double* M, const double* b
   if (ctx->cur_level != level) return fail(ctx, WCT_ERR_STATE, "content_decode: wct_content_encode(level %d) has not run", level);
   ConvDesc first;
   if (int rc = fold_impl(ctx, level, M, b, first)) return rc;
-  if (int rc = decode_impl(ctx, level, reinterpret_cast<float*>(ctx->featC.p), ctx->cur_h, ctx->cur_w, &first, out)) return rc;
+  if (l1_fused(ctx, level)) {
+    if (int rc = l1_decode_impl(ctx, level, reinterpret_cast<const float*>(ctx->l1img.p), ctx->cur_H, ctx->cur_W, first, out)) return rc;
+  } else {
+    if (int rc = decode_impl(ctx, level, reinterpret_cast<float*>(ctx->featC.p), ctx->cur_h, ctx->cur_w, &first, out)) return rc;
+  }
   if (Ho) *Ho = ctx->cur_h << (level - 1);
   if (Wo) *Wo = ctx->cur_w << (level - 1);
   return WCT_OK;

@@ -30,6 +30,10 @@ struct ConvDesc {
   const void* wpk16 = nullptr;
   float inv_scale = 1.f;
   const float* inv_scale_ptr = nullptr;
+  // 3-channel first conv with <= 32 couts (level-1 encoder): f16x3 slot packing for level1.hip, [2 cout tiles] (device)
+  const void* l1w16 = nullptr;
+  const float* l1bias = nullptr;   // [32], zero padded
+  float l1inv = 1.f;
 };
 
 // Launch one conv layer.  (H, W) = spatial size the convolution runs at (after the fused upsample,
@@ -46,6 +50,13 @@ bool conv_fusable_head(const ConvDesc& d0, const ConvDesc& d1);
 bool conv_fusable_tail(const ConvDesc& d0, const ConvDesc& d1);
 hipError_t launch_enc_head(const ConvDesc& d0, const ConvDesc& d1, const float* img, float* out, int H, int W, hipStream_t s);   // d1.flags & CONV_OUT_SP16
 hipError_t launch_dec_tail(const ConvDesc& d0, const ConvDesc& d1, const float* in, float* out, int H, int W, hipStream_t s);
+// level 1 without materialising relu1_1 (level1.hip, moments.hip)
+bool l1_capable(const ConvDesc& enc0);
+hipError_t launch_l1_encode(const ConvDesc& enc0, const float* img, float* out, int H, int W, hipStream_t s);
+hipError_t launch_l1_decode(const ConvDesc& enc0, const ConvDesc& dec0_folded, const float* img, float* out, int H, int W, hipStream_t s);
+size_t l1_moments_workspace_bytes();
+hipError_t launch_l1_moments(const ConvDesc& enc0, const float* img, int H, int W, int x0, int x1, double* sum, double* sumsq,
+                             void* workspace, size_t workspace_bytes, hipStream_t s);
 // fp32 packed weights (device) -> scaled split-f16 packed weights + inverse scale (device scalar)
 //   have_max: *maxbits_dev already holds max |w| (written by launch_fold_affine); otherwise it is computed here
 hipError_t launch_split_pack(const float* wpk32, int cin, int cout_pad, int taps, unsigned* maxbits_dev, void* out,

@@ -166,6 +166,31 @@ def test_fused_ends_match_unfused(torch_cuda, weights16x, monkeypatch):
         assert torch.equal(a, b)
 
 
+def test_level1_fused_matches_layerwise(torch_cuda, weights16x, monkeypatch):
+    """Level 1 without relu1_1 in HBM (level1.hip: image -> conv11 -> moments, image -> conv11 -> folded conv -> image)
+    vs the layer-by-layer path (fp32-MFMA conv11, moments kernel, c16 decoder conv).  conv11 is f16x3 in the fused
+    kernels and exact-fp32 MFMA layer-wise: fp32-class agreement, tolerance relative to max|y| as in the golden tests.
+    Odd sizes put image-border tiles, partial tiles and the reflected halo ring on the path."""
+    from wct_hip import WCT
+    torch = torch_cuda
+    g = torch.Generator(device="cuda").manual_seed(5)
+    c = torch.rand((1, 3, 203, 333), device="cuda", generator=g)
+    s = torch.rand((1, 3, 97, 131), device="cuda", generator=g)
+    res = {}
+    for fuse in ("1", "0"):
+        monkeypatch.setenv("WCT_L1FUSE", fuse)
+        w = WCT(types.SimpleNamespace(mode="16x", alpha=1.0), weights=weights16x)
+        h, wd, sm, sq = w.content_encode(1, c, 16, 240)          # windowed moments (the sharded path's call)
+        res[fuse] = (w.e1(c).clone(), sm.clone(), sq.clone(), w.style_transfer_level(1, c, s).clone(),
+                     w.style_transfer_level(1, c, s, 0.6).clone())
+    a, b = res["1"], res["0"]
+    assert float((a[0] - b[0]).abs().max() / b[0].abs().max()) < 3e-6          # relu1_1 (API)
+    assert float((a[1] - b[1]).abs().max() / b[1].abs().max()) < 1e-6          # sum over the window
+    assert float((a[2] - b[2]).abs().max() / b[2].abs().max()) < 1e-6          # sum of products over the window
+    for k in (3, 4):
+        assert float((a[k] - b[k]).abs().max() / b[k].abs().max()) < 2e-5, k  # through the whitening (cond ~1e3)
+
+
 # --------------------------------------------------------------------------- G6 original arch, G7 config 1
 def test_g6_original_arch(torch_cuda, golden):
     """--mode original graph (C = 512/512/256/128/64: multi-group conv launches, global-memory Jacobi)."""
