@@ -77,7 +77,73 @@ __global__ void pack_center_kernel(const double* M, const double* b, int C, int 
   wpk[e] = (tap == 4 && o < C && i < C) ? (float)M[(size_t)o * C + i] : 0.f;
 }
 
+// ---- image edge: the reference's ToTensor (data_loader.py:57-58: uint8 HWC -> float CHW / 255) and
+// save_image (WCT.py:128 -> torchvision 0.2.1: mul(255).clamp(0,255).byte(), i.e. truncation) on the device, so that
+// a frame crosses PCIe as 3 B/px instead of 12.  4 pixels per thread: 12 contiguous bytes in, three 16-byte stores out.
+__global__ void u8_to_planar_kernel(const uint8_t* in, long npix, float* out) {
+  const long p0 = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (p0 >= npix) return;
+  if (p0 + 4 <= npix) {
+    const uint8_t* src = in + p0 * 3;   // 4-byte aligned: p0 is a multiple of 4
+    const unsigned w0 = *reinterpret_cast<const unsigned*>(src), w1 = *reinterpret_cast<const unsigned*>(src + 4),
+                   w2 = *reinterpret_cast<const unsigned*>(src + 8);
+    const unsigned b[12] = {w0 & 255u, (w0 >> 8) & 255u, (w0 >> 16) & 255u, w0 >> 24, w1 & 255u, (w1 >> 8) & 255u,
+                            (w1 >> 16) & 255u, w1 >> 24, w2 & 255u, (w2 >> 8) & 255u, (w2 >> 16) & 255u, w2 >> 24};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      f32x4 v;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = (float)b[k * 3 + c] / 255.0f;   // IEEE division, as torch's .div(255)
+      float* dst = out + (size_t)c * npix + p0;
+      if ((reinterpret_cast<size_t>(dst) & 15) == 0) *reinterpret_cast<f32x4*>(dst) = v;
+      else { dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2]; dst[3] = v[3]; }
+    }
+  } else {
+    for (long p = p0; p < npix; ++p)
+      for (int c = 0; c < 3; ++c) out[(size_t)c * npix + p] = (float)in[p * 3 + c] / 255.0f;
+  }
+}
+
+// round_mode 0: truncation (torchvision 0.2.1, the reference's pin); 1: add 0.5 first (torchvision >= 0.4)
+__global__ void planar_to_u8_kernel(const float* in, long npix, uint8_t* out, int round_mode) {
+  const long p0 = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (p0 >= npix) return;
+  const int n = npix - p0 < 4 ? (int)(npix - p0) : 4;
+  unsigned b[12];
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float x = k < n ? in[(size_t)c * npix + p0 + k] * 255.0f : 0.f;
+      if (round_mode) x += 0.5f;
+      x = fminf(fmaxf(x, 0.f), 255.f);     // NaN -> 0 (fmaxf), like clamp on the host
+      b[k * 3 + c] = (unsigned)x;          // truncation toward zero
+    }
+  if (n == 4) {
+    unsigned* dst = reinterpret_cast<unsigned*>(out + p0 * 3);
+    dst[0] = b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24);
+    dst[1] = b[4] | (b[5] << 8) | (b[6] << 16) | (b[7] << 24);
+    dst[2] = b[8] | (b[9] << 8) | (b[10] << 16) | (b[11] << 24);
+  } else {
+    for (int k = 0; k < n * 3; ++k) out[p0 * 3 + k] = (uint8_t)b[k];
+  }
+}
+
 }  // namespace
+
+hipError_t launch_u8_to_planar(const uint8_t* in, long npix, float* out, hipStream_t s) {
+  if ((reinterpret_cast<size_t>(in) & 3) != 0) return hipErrorInvalidValue;
+  const long nt = (npix + 3) / 4;
+  hipLaunchKernelGGL(u8_to_planar_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, s, in, npix, out);
+  return hipGetLastError();
+}
+
+hipError_t launch_planar_to_u8(const float* in, long npix, uint8_t* out, int round_mode, hipStream_t s) {
+  if ((reinterpret_cast<size_t>(out) & 3) != 0) return hipErrorInvalidValue;
+  const long nt = (npix + 3) / 4;
+  hipLaunchKernelGGL(planar_to_u8_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, s, in, npix, out, round_mode);
+  return hipGetLastError();
+}
 
 hipError_t launch_nhwc_to_nchw(const float* in, float* out, int C, int npix, hipStream_t s) {
   hipLaunchKernelGGL(transpose_kernel, dim3((C + 31) / 32, (npix + 31) / 32), dim3(256), 0, s, in, out, npix, C);

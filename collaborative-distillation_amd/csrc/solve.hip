@@ -554,6 +554,7 @@ __global__ __launch_bounds__(256) void sym_power_kernel(double* res, int n, doub
 }  // namespace
 
 size_t eig_result_bytes(int C) { return eig_doubles(C) * sizeof(double); }
+size_t eig_result_F_offset(size_t C) { return eig_F_offset((int)C); }
 static inline int ns_pad(int C) { return (C + 31) / 32 * 32; }
 size_t eig_workspace_bytes(int C) {
   const size_t cp2 = (size_t)ns_pad(C) * ns_pad(C);

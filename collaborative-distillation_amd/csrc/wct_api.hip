@@ -62,6 +62,7 @@ struct wct_ctx {
   // workspace
   DevBuf featC, featS, tmpT, wsAsm, small, foldW, foldW16, eigC, eigS[6];
   int cur_level = 0, cur_h = 0, cur_w = 0;  // content feature held in featC by wct_content_encode
+  DevBuf u8c, u8s, u8o;   // fp32 planar staging of wct_stylize_u8 (content, style, result)
   DevBuf l1img;       // level 1 fused: copy of the content image between wct_content_encode and wct_content_decode
   int cur_H = 0, cur_W = 0;
   int l1fuse = 1;     // 1: level 1 of the 16x cascade without materialising relu1_1 (level1.hip)
@@ -633,7 +634,7 @@ void wct_destroy(wct_ctx* ctx) {
     for (int l = 0; l < 6; ++l) free_module(ctx->mod[k][l]);
   for (Lane* ln : {&ctx->main, &ctx->side})
     for (DevBuf* b : {&ln->actA, &ln->actB, &ln->wsMom, &ln->wsEig, &ln->sums}) release(*b);
-  for (DevBuf* b : {&ctx->featC, &ctx->featS, &ctx->tmpT, &ctx->wsAsm, &ctx->small, &ctx->foldW, &ctx->foldW16, &ctx->eigC, &ctx->l1img}) release(*b);
+  for (DevBuf* b : {&ctx->featC, &ctx->featS, &ctx->tmpT, &ctx->wsAsm, &ctx->small, &ctx->foldW, &ctx->foldW16, &ctx->eigC, &ctx->l1img, &ctx->u8c, &ctx->u8s, &ctx->u8o}) release(*b);
   for (int l = 0; l < 6; ++l) {
     release(ctx->eigS[l]);
     if (ctx->ev_style[l]) (void)hipEventDestroy(ctx->ev_style[l]);
@@ -864,13 +865,54 @@ int wct_style_transfer_level(wct_ctx* ctx, int level, const float* content, int 
 
 // ---- split form of a level, for content-sharded runs (wct_hip/sharded.py): the caller all-reduces the moments
 //      between wct_content_encode and wct_content_solve and may broadcast (M, b) before wct_content_decode.
-int wct_style_prepare(wct_ctx* ctx, const float* style, int Hs, int Ws) {
+int wct_style_prepare_levels(wct_ctx* ctx, const float* style, int Hs, int Ws, unsigned level_mask) {
   if (!ctx) return WCT_ERR_INVALID;
   if (!style) return fail(ctx, WCT_ERR_INVALID, "style_prepare: NULL style");
   if (int rc = fork_side(ctx)) return rc;
   for (int level = 5; level >= 1; --level)
-    if (ctx->mod[WCT_KIND_ENC][level].loaded)
+    if ((level_mask >> level & 1u) && ctx->mod[WCT_KIND_ENC][level].loaded)
       if (int rc = style_side(ctx, level, style, Hs, Ws)) return rc;
+  return WCT_OK;
+}
+
+int wct_style_prepare(wct_ctx* ctx, const float* style, int Hs, int Ws) { return wct_style_prepare_levels(ctx, style, Hs, Ws, 0x3eu); }
+
+int wct_style_stats_count(const wct_ctx* ctx, int level, size_t* n_doubles) {
+  if (!ctx || !valid_level(level) || !n_doubles) return WCT_ERR_INVALID;
+  const Module& me = ctx->mod[WCT_KIND_ENC][level];
+  if (!me.loaded) return WCT_ERR_STATE;
+  const size_t C = me.layers.back().d.cout;
+  *n_doubles = C * C + C;
+  return WCT_OK;
+}
+
+// stats = cov_s^(1/2) [C*C] | mu_s [C]  (the two parts of the EigResult that launch_assemble consumes)
+int wct_style_export(wct_ctx* ctx, int level, double* stats) {
+  if (!ctx) return WCT_ERR_INVALID;
+  if (!valid_level(level) || !stats) return fail(ctx, WCT_ERR_INVALID, "style_export: bad arguments");
+  Module& me = ctx->mod[WCT_KIND_ENC][level];
+  if (!me.loaded || !ctx->eigS[level].p) return fail(ctx, WCT_ERR_STATE, "style_export: wct_style_prepare has not run for level %d", level);
+  const size_t C = me.layers.back().d.cout, cc = C * C;
+  const double* res = reinterpret_cast<const double*>(ctx->eigS[level].p);
+  hipStream_t st = ctx->main.stream;
+  HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_style[level], 0));
+  HIPCHK(ctx, hipMemcpyAsync(stats, res + eig_result_F_offset(C), cc * sizeof(double), hipMemcpyDeviceToDevice, st));
+  HIPCHK(ctx, hipMemcpyAsync(stats + cc, res + cc + C, C * sizeof(double), hipMemcpyDeviceToDevice, st));
+  return WCT_OK;
+}
+
+int wct_style_import(wct_ctx* ctx, int level, const double* stats) {
+  if (!ctx) return WCT_ERR_INVALID;
+  if (!valid_level(level) || !stats) return fail(ctx, WCT_ERR_INVALID, "style_import: bad arguments");
+  Module& me = ctx->mod[WCT_KIND_ENC][level];
+  if (!me.loaded) return fail(ctx, WCT_ERR_STATE, "encoder %d not loaded", level);
+  const size_t C = me.layers.back().d.cout, cc = C * C;
+  if (int rc = ensure(ctx, ctx->eigS[level], eig_result_bytes((int)C))) return rc;
+  double* res = reinterpret_cast<double*>(ctx->eigS[level].p);
+  hipStream_t st = ctx->main.stream;
+  HIPCHK(ctx, hipMemcpyAsync(res + eig_result_F_offset(C), stats, cc * sizeof(double), hipMemcpyDeviceToDevice, st));
+  HIPCHK(ctx, hipMemcpyAsync(res + cc + C, stats + cc, C * sizeof(double), hipMemcpyDeviceToDevice, st));
+  HIPCHK(ctx, hipEventRecord(ctx->ev_style[level], st));   // what content_side / wct_content_solve wait for
   return WCT_OK;
 }
 
@@ -933,15 +975,9 @@ int wct_content_decode(wct_ctx* ctx, int level, const double* M, const double* b
   return WCT_OK;
 }
 
-int wct_stylize(wct_ctx* ctx, const float* content, int H, int W, const float* style, int Hs, int Ws, float alpha,
-                int num_run, float* out, int* Ho, int* Wo) {
-  if (!ctx) return WCT_ERR_INVALID;
-  if (!content || !style || !out || num_run < 1) return fail(ctx, WCT_ERR_INVALID, "stylize: bad arguments");
-  // style side of all five levels first, on the side lane: it only depends on the style image (the SAME image at
-  // every level and every run, WCT.py:121-125), so it is computed once and overlaps the content cascade
-  if (int rc = fork_side(ctx)) return rc;
-  for (int level = 5; level >= 1; --level)
-    if (int rc = style_side(ctx, level, style, Hs, Ws)) return rc;
+namespace {
+// the content cascade of WCT.py:120-125 against the style statistics already in the context
+int cascade(wct_ctx* ctx, const float* content, int H, int W, float alpha, int num_run, float* out, int* Ho, int* Wo) {
   // `out` doubles as the running image: level L reads one buffer and writes the other (ping-pong with tmpT)
   const size_t img_bytes = (size_t)3 * H * W * sizeof(float);
   if (int rc = ensure(ctx, ctx->tmpT, img_bytes)) return rc;
@@ -958,6 +994,64 @@ int wct_stylize(wct_ctx* ctx, const float* content, int H, int W, const float* s
   if (cur != out) HIPCHK(ctx, hipMemcpyAsync(out, cur, (size_t)3 * h * w * sizeof(float), hipMemcpyDeviceToDevice, ctx->main.stream));
   if (Ho) *Ho = h;
   if (Wo) *Wo = w;
+  return WCT_OK;
+}
+}  // namespace
+
+int wct_stylize(wct_ctx* ctx, const float* content, int H, int W, const float* style, int Hs, int Ws, float alpha,
+                int num_run, float* out, int* Ho, int* Wo) {
+  if (!ctx) return WCT_ERR_INVALID;
+  if (!content || !style || !out || num_run < 1) return fail(ctx, WCT_ERR_INVALID, "stylize: bad arguments");
+  // style side of all five levels first, on the side lane: it only depends on the style image (the SAME image at
+  // every level and every run, WCT.py:121-125), so it is computed once and overlaps the content cascade
+  if (int rc = fork_side(ctx)) return rc;
+  for (int level = 5; level >= 1; --level)
+    if (int rc = style_side(ctx, level, style, Hs, Ws)) return rc;
+  return cascade(ctx, content, H, W, alpha, num_run, out, Ho, Wo);
+}
+
+int wct_stylize_prepared(wct_ctx* ctx, const float* content, int H, int W, float alpha, int num_run, float* out, int* Ho,
+                         int* Wo) {
+  if (!ctx) return WCT_ERR_INVALID;
+  if (!content || !out || num_run < 1) return fail(ctx, WCT_ERR_INVALID, "stylize_prepared: bad arguments");
+  for (int level = 5; level >= 1; --level)
+    if (!ctx->eigS[level].p) return fail(ctx, WCT_ERR_STATE, "stylize_prepared: no style statistics for level %d (wct_style_prepare / wct_style_import)", level);
+  return cascade(ctx, content, H, W, alpha, num_run, out, Ho, Wo);
+}
+
+int wct_u8_to_planar(wct_ctx* ctx, const uint8_t* hwc, int H, int W, float* planar) {
+  if (!ctx) return WCT_ERR_INVALID;
+  if (!hwc || !planar || H < 1 || W < 1) return fail(ctx, WCT_ERR_INVALID, "u8_to_planar: bad arguments");
+  ProfScope ps(ctx, ctx->main.stream, "u8_to_planar", 0, 15.0 * H * W);
+  HIPCHK(ctx, launch_u8_to_planar(hwc, (long)H * W, planar, ctx->main.stream));
+  return WCT_OK;
+}
+
+int wct_planar_to_u8(wct_ctx* ctx, const float* planar, int H, int W, uint8_t* hwc, int round_mode) {
+  if (!ctx) return WCT_ERR_INVALID;
+  if (!hwc || !planar || H < 1 || W < 1 || (round_mode != 0 && round_mode != 1)) return fail(ctx, WCT_ERR_INVALID, "planar_to_u8: bad arguments");
+  ProfScope ps(ctx, ctx->main.stream, "planar_to_u8", 0, 15.0 * H * W);
+  HIPCHK(ctx, launch_planar_to_u8(planar, (long)H * W, hwc, round_mode, ctx->main.stream));
+  return WCT_OK;
+}
+
+int wct_stylize_u8(wct_ctx* ctx, const uint8_t* content_hwc, int H, int W, const uint8_t* style_hwc, int Hs, int Ws,
+                   float alpha, int num_run, uint8_t* out_hwc, int* Ho, int* Wo, int round_mode) {
+  if (!ctx) return WCT_ERR_INVALID;
+  if (!content_hwc || !style_hwc || !out_hwc) return fail(ctx, WCT_ERR_INVALID, "stylize_u8: bad arguments");
+  if (int rc = ensure(ctx, ctx->u8c, (size_t)3 * H * W * sizeof(float))) return rc;
+  if (int rc = ensure(ctx, ctx->u8s, (size_t)3 * Hs * Ws * sizeof(float))) return rc;
+  if (int rc = ensure(ctx, ctx->u8o, (size_t)3 * H * W * sizeof(float))) return rc;
+  float* c = reinterpret_cast<float*>(ctx->u8c.p);
+  float* s = reinterpret_cast<float*>(ctx->u8s.p);
+  float* o = reinterpret_cast<float*>(ctx->u8o.p);
+  if (int rc = wct_u8_to_planar(ctx, style_hwc, Hs, Ws, s)) return rc;
+  if (int rc = wct_u8_to_planar(ctx, content_hwc, H, W, c)) return rc;
+  int ho = 0, wo = 0;
+  if (int rc = wct_stylize(ctx, c, H, W, s, Hs, Ws, alpha, num_run, o, &ho, &wo)) return rc;
+  if (int rc = wct_planar_to_u8(ctx, o, ho, wo, out_hwc, round_mode)) return rc;
+  if (Ho) *Ho = ho;
+  if (Wo) *Wo = wo;
   return WCT_OK;
 }
 

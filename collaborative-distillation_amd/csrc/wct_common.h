@@ -62,6 +62,10 @@ hipError_t launch_l1_moments(const ConvDesc& enc0, const float* img, int H, int 
 hipError_t launch_split_pack(const float* wpk32, int cin, int cout_pad, int taps, unsigned* maxbits_dev, void* out,
                              float* inv_scale_out, hipStream_t s, bool have_max = false);
 
+// ---- image edge: uint8 HWC <-> planar fp32 (ToTensor / save_image of the reference's harness)
+hipError_t launch_u8_to_planar(const uint8_t* hwc, long npix, float* planar, hipStream_t s);
+hipError_t launch_planar_to_u8(const float* planar, long npix, uint8_t* hwc, int round_mode, hipStream_t s);
+
 // ---- layout
 hipError_t launch_nhwc_to_nchw(const float* in, float* out, int C, int npix, hipStream_t s);
 hipError_t launch_nchw_to_nhwc(const float* in, float* out, int C, int npix, hipStream_t s);
@@ -75,6 +79,7 @@ hipError_t launch_moments(const float* feat_nhwc, int C, int h, int wfull, int x
 // ---- solve, in two steps (solve.hip): moments of one map -> EigResult; two EigResults -> M (C x C), b (C)
 //      csF = M cF + b   (util_wct.py:62-131, 219).  EigResult = doubles G[C*C] | lam[C] | mu[C] | floor | pad
 size_t eig_result_bytes(int C);
+size_t eig_result_F_offset(size_t C);   // doubles: where F = cov^(+-1/2) starts inside an EigResult (mu is at C*C + C)
 size_t eig_workspace_bytes(int C);
 size_t assemble_workspace_bytes(int C);
 hipError_t launch_eig(int C, double n, const double* sum, const double* sumsq, int inverse, double* res, int* info_dev,

@@ -1,0 +1,155 @@
+"""Command line of the stylisation path: the flags, pairing, naming and log lines of PytorchWCT/WCT.py, on libwct_hip.
+
+    python -m wct_hip.cli --mode 16x --contentPath content --stylePath style --outf stylized_results [--alpha 0.6] ...
+
+What the reference script does around the hot path and where it lives here:
+  WCT.py:15-35      argparse flags                     -> build_parser()   (same names, defaults and choices)
+  WCT.py:37-75      checkpoint paths per --mode        -> checkpoint_args()
+  data_loader.py:22-36   content x style pairs filtered by --picked_*_mark, listdir order   -> list_pairs()
+  data_loader.py:50-59   PIL decode (.convert('RGB')), optional Resize, ToTensor            -> load_rgb_u8() + wct_u8_to_planar (GPU)
+  WCT.py:120-125    the 5-level cascade, --num_run times -> wct_stylize (one C call)
+  WCT.py:127-128    output name and save_image          -> out_name() + wct_planar_to_u8 (GPU) + PIL save
+A frame crosses PCIe as uint8 (3 B/px each way).  --numpy and --synthesis are rejected like in wct_hip.WCT (the first is
+a different operator, the second is broken in the reference: data_loader.py:74 calls torch.rand_like on a PIL image).
+Decoding/encoding files needs Pillow on the host (the reference's own dependency); the GPU library is mandatory: there
+is no CPU fallback.
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+import time
+from typing import List, Optional, Tuple
+
+IMG_EXT = (".png", ".jpg", ".jpeg")   # data_loader.py:15
+
+
+def build_parser() -> argparse.ArgumentParser:
+    p = argparse.ArgumentParser(description="WCT on MI355X (libwct_hip)")
+    p.add_argument("--UHD_contentPath", type=str, default="content/UHD_content")
+    p.add_argument("--UHD_stylePath", type=str, default="style/UHD_style")
+    p.add_argument("--contentPath", type=str, default="content")
+    p.add_argument("--stylePath", type=str, default="style")
+    p.add_argument("--texturePath", type=str, default="style/texture")
+    p.add_argument("--outf", type=str, default="stylized_results", help="folder to output images")
+    p.add_argument("--picked_content_mark", type=str, default=".")
+    p.add_argument("--picked_style_mark", type=str, default=".")
+    p.add_argument("--mode", type=str, default=None, choices=["original", "16x", "16x_kd2sd"], help="to choose different trained models")
+    p.add_argument("--UHD", action="store_true", help="if use the UHD images")
+    p.add_argument("--synthesis", action="store_true", help="for style synthesis")
+    p.add_argument("--content_size", type=int, default=0, help="resize content, leave it to 0 if not resize")
+    p.add_argument("--style_size", type=int, default=0, help="resize style, leave it to 0 if not resize")
+    p.add_argument("--alpha", type=float, default=1, help="hyperparameter to blend wct feature and content feature")
+    p.add_argument("--log_mark", type=str, default=time.strftime("%Y%m%d-%H%M"))
+    p.add_argument("--num_run", type=int, default=1, help="you can run WCT for multiple times")
+    p.add_argument("--debug", action="store_true")
+    p.add_argument("--numpy", action="store_true", help="if use numpy for stylization rather than torch")
+    # not in the reference: where its trained_models/ directory is (default: the paths of WCT.py:37-75 relative to the cwd)
+    p.add_argument("--models_root", type=str, default="..", help="directory that holds trained_models/ (reference layout)")
+    p.add_argument("--round", dest="round_mode", type=int, default=0, choices=[0, 1],
+                   help="uint8 conversion of the result: 0 = truncation (torchvision 0.2.1, the reference's pin), 1 = +0.5")
+    return p
+
+
+def checkpoint_args(args) -> None:
+    """e1..e5 / d1..d5 exactly as WCT.py:37-75 assigns them (relative to --models_root)."""
+    root = os.path.join(args.models_root, "trained_models")
+    if args.mode == "original" or args.mode is None:
+        enc = [os.path.join(root, "original_wct_models", "vgg_normalised_conv%d_1.t7" % k) for k in range(1, 6)]
+        dec = [os.path.join(root, "original_wct_models", "feature_invertor_conv%d_1.t7" % k) for k in range(1, 6)]
+    else:
+        sd = "wct_se_16x_new_sd" if args.mode == "16x" else "wct_se_16x_new_sd_kd2sd"
+        enc = [os.path.join(root, "wct_se_16x_new", "%dSE.pth" % k) for k in range(1, 6)]
+        dec = [os.path.join(root, sd, "%dSD.pth" % k) for k in range(1, 6)]
+    for k in range(1, 6):
+        setattr(args, "e%d" % k, enc[k - 1])
+        setattr(args, "d%d" % k, dec[k - 1])
+
+
+def is_image_file(name: str) -> bool:
+    return any(name.endswith(e) for e in IMG_EXT)
+
+
+def list_pairs(content_dir: str, style_dir: str, content_mark: str = ".", style_mark: str = ".") -> List[Tuple[str, str]]:
+    """The Cartesian product of data_loader.py:32-36: contents outer, styles inner, os.listdir order, substring filters."""
+    cs = [x for x in os.listdir(content_dir) if is_image_file(x) and content_mark in x]
+    ss = [x for x in os.listdir(style_dir) if is_image_file(x) and style_mark in x]
+    return [(c, s) for c in cs for s in ss]
+
+
+def pair_name(content_file: str, style_file: str) -> str:
+    """data_loader.py:60: '<content stem>+<style stem>.jpg' (stem = text before the FIRST dot)."""
+    return content_file.split(".")[0] + "+" + style_file.split(".")[0] + ".jpg"
+
+
+def out_name(args, imname: str) -> str:
+    """WCT.py:127 (str(1) for the integer default of --alpha, like '%s' % args.alpha there)."""
+    return os.path.join(args.outf, "%s_mode=%s_alpha=%s_%s" % (args.log_mark, args.mode, args.alpha, imname))
+
+
+def load_rgb_u8(path: str, size: int = 0):
+    """default_loader + transforms.Resize(size) of data_loader.py:18-19,52-56: RGB uint8 HWC; Resize matches the SMALLER
+    edge to `size` with bilinear interpolation (torchvision 0.2.1 semantics, done by Pillow on the host)."""
+    import numpy as np
+    from PIL import Image
+    img = Image.open(path).convert("RGB")
+    if size:
+        w, h = img.size
+        if not ((w <= h and w == size) or (h <= w and h == size)):
+            if w < h:
+                ow, oh = size, int(size * h / w)
+            else:
+                oh, ow = size, int(size * w / h)
+            img = img.resize((ow, oh), Image.BILINEAR)
+    return np.array(img, dtype=np.uint8)   # a writable, contiguous copy
+
+
+class LogPrinter:     # WCT.py:78-82
+    def __init__(self, debug: bool, path: str):
+        self.log = sys.stdout if debug else open(path, "a+")
+
+    def __call__(self, sth):
+        print(str(sth), file=self.log, flush=True)
+
+
+def main(argv: Optional[List[str]] = None) -> int:
+    args = build_parser().parse_args(argv)
+    checkpoint_args(args)
+    if args.synthesis:
+        raise NotImplementedError("--synthesis is broken in the reference (data_loader.py:74) and not part of this path")
+    os.makedirs(args.outf, exist_ok=True)
+    logprinter = LogPrinter(args.debug, os.path.join(args.outf, "log_%s_%s.txt" % (args.log_mark, args.mode)))
+    logprinter(sorted(vars(args).items()))
+    content_dir = args.UHD_contentPath if args.UHD else args.contentPath
+    style_dir = args.UHD_stylePath if args.UHD else args.stylePath
+    pairs = list_pairs(content_dir, style_dir, args.picked_content_mark, args.picked_style_mark)
+
+    import torch
+    from PIL import Image
+    from .wct import WCT      # raises ImportError if libwct_hip.so is missing: no CPU fallback
+    wct = WCT(args)
+    logprinter("Number of content-style pairs: %s" % len(pairs))
+    avg = 0.0
+    last_style, s_dev = None, None
+    for i, (cfile, sfile) in enumerate(pairs):
+        imname = pair_name(cfile, sfile)
+        logprinter("\n" + "*" * 30 + ' #%s: Transferring "%s"' % (i, imname))
+        c_u8 = torch.from_numpy(load_rgb_u8(os.path.join(content_dir, cfile), args.content_size)).cuda()
+        if sfile != last_style:
+            s_dev = torch.from_numpy(load_rgb_u8(os.path.join(style_dir, sfile), args.style_size)).cuda()
+            last_style = sfile
+        t0 = time.time()
+        out = wct.stylize_u8(c_u8, s_dev, args.alpha, args.num_run, args.round_mode).cpu().numpy()   # .cpu() syncs
+        path = out_name(args, imname)
+        Image.fromarray(out).save(path)
+        dt = time.time() - t0
+        avg += dt
+        logprinter("Elapsed time is: %.4f seconds" % dt)
+    if pairs:
+        logprinter("Processed %d images. Average processing time per pair is: %.4f seconds" % (len(pairs), avg / len(pairs)))
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

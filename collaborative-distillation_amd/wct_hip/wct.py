@@ -16,7 +16,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import byref, c_int, c_void_p
+from ctypes import c_size_t, byref, c_int, c_void_p
 from typing import Dict, Optional
 
 import numpy as np
@@ -260,12 +260,91 @@ class WCT:
 
     # ------------------------------------------------------------------ split level (content-sharded runs)
     @torch.no_grad()
-    def style_prepare(self, styleImg: torch.Tensor):
-        """Style side of all five levels on the context's side stream (overlaps whatever follows)."""
+    def style_prepare(self, styleImg: torch.Tensor, levels=(5, 4, 3, 2, 1)):
+        """Style side of the given levels on the context's side stream (overlaps whatever follows)."""
         s = self._img(styleImg)
         self._style_keep = s   # the side stream reads it asynchronously
+        mask = 0
+        for L in levels:
+            mask |= 1 << int(L)
         self._stream()
-        self._chk(self._lib.wct_style_prepare(self._ctx, s.data_ptr(), int(s.shape[1]), int(s.shape[2])))
+        self._chk(self._lib.wct_style_prepare_levels(self._ctx, s.data_ptr(), int(s.shape[1]), int(s.shape[2]), mask))
+
+    def style_export(self, level: int) -> torch.Tensor:
+        """Style statistics of a prepared level as one fp64 vector: cov_s^(1/2) [C*C] then mu_s [C]."""
+        n = c_size_t()
+        self._chk(self._lib.wct_style_stats_count(self._ctx, level, byref(n)))
+        buf = torch.empty(n.value, device="cuda", dtype=torch.float64)
+        self._stream()
+        self._chk(self._lib.wct_style_export(self._ctx, level, buf.data_ptr()))
+        return buf
+
+    def style_import(self, level: int, stats: torch.Tensor):
+        n = c_size_t()
+        self._chk(self._lib.wct_style_stats_count(self._ctx, level, byref(n)))
+        if stats.dtype != torch.float64 or not stats.is_cuda or stats.numel() != n.value:
+            raise ValueError("style_import: expected %d fp64 values on the GPU" % n.value)
+        stats = stats.contiguous()
+        self._stream()
+        self._chk(self._lib.wct_style_import(self._ctx, level, stats.data_ptr()))
+
+    @torch.no_grad()
+    def stylize_prepared(self, contentImg: torch.Tensor, alpha: Optional[float] = None, num_run: int = 1,
+                         out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """The cascade against the style statistics already in the context (style_prepare / style_import): content x style
+        batches pay the style side once per style (data_loader.py:32-36 builds the Cartesian product)."""
+        alpha = self.alpha if alpha is None else float(alpha)
+        c = self._img(contentImg)
+        H, W = int(c.shape[1]), int(c.shape[2])
+        if out is None:
+            out = torch.empty((3, H, W), device=c.device, dtype=torch.float32)
+        ho, wo = c_int(), c_int()
+        self._stream()
+        self._chk(self._lib.wct_stylize_prepared(self._ctx, c.data_ptr(), H, W, alpha, int(num_run), out.data_ptr(), byref(ho), byref(wo)))
+        return out.view(-1)[: 3 * ho.value * wo.value].view(1, 3, ho.value, wo.value)
+
+    # ------------------------------------------------------------------ image edge (ToTensor / save_image on the device)
+    @staticmethod
+    def _u8(img: torch.Tensor) -> torch.Tensor:
+        if img.dtype != torch.uint8 or img.dim() != 3 or img.shape[2] != 3:
+            raise ValueError("expected a uint8 H x W x 3 image, got %s %s" % (img.dtype, tuple(img.shape)))
+        if not img.is_cuda:
+            img = img.cuda()
+        return img.contiguous()
+
+    @torch.no_grad()
+    def to_tensor_u8(self, img_u8: torch.Tensor) -> torch.Tensor:
+        """transforms.ToTensor() of data_loader.py:57-58 on the GPU: uint8 HWC -> fp32 1x3xHxW in [0,1]."""
+        x = self._u8(img_u8)
+        H, W = int(x.shape[0]), int(x.shape[1])
+        out = torch.empty((1, 3, H, W), device=x.device, dtype=torch.float32)
+        self._stream()
+        self._chk(self._lib.wct_u8_to_planar(self._ctx, x.data_ptr(), H, W, out.data_ptr()))
+        return out
+
+    @torch.no_grad()
+    def to_u8(self, img: torch.Tensor, round_mode: int = 0) -> torch.Tensor:
+        """save_image's conversion (WCT.py:128; torchvision 0.2.1: mul(255).clamp(0,255).byte()) on the GPU: fp32 CHW -> uint8 HWC."""
+        x = self._img(img)
+        H, W = int(x.shape[1]), int(x.shape[2])
+        out = torch.empty((H, W, 3), device=x.device, dtype=torch.uint8)
+        self._stream()
+        self._chk(self._lib.wct_planar_to_u8(self._ctx, x.data_ptr(), H, W, out.data_ptr(), int(round_mode)))
+        return out
+
+    @torch.no_grad()
+    def stylize_u8(self, content_u8: torch.Tensor, style_u8: torch.Tensor, alpha: Optional[float] = None, num_run: int = 1,
+                   round_mode: int = 0) -> torch.Tensor:
+        """uint8 HWC content + style -> uint8 HWC result (ToTensor -> cascade -> save_image conversion), one call."""
+        alpha = self.alpha if alpha is None else float(alpha)
+        c, s = self._u8(content_u8), self._u8(style_u8)
+        H, W, Hs, Ws = int(c.shape[0]), int(c.shape[1]), int(s.shape[0]), int(s.shape[1])
+        out = torch.empty((H, W, 3), device=c.device, dtype=torch.uint8)
+        ho, wo = c_int(), c_int()
+        self._stream()
+        self._chk(self._lib.wct_stylize_u8(self._ctx, c.data_ptr(), H, W, s.data_ptr(), Hs, Ws, alpha, int(num_run), out.data_ptr(),
+                                           byref(ho), byref(wo), int(round_mode)))
+        return out.view(-1)[: 3 * ho.value * wo.value].view(ho.value, wo.value, 3)
 
     @torch.no_grad()
     def content_encode(self, level: int, img: torch.Tensor, x0: int = 0, x1: int = -1):

@@ -129,6 +129,31 @@ int wct_content_decode(wct_ctx* ctx, int level, const double* M, const double* b
 int wct_stylize(wct_ctx* ctx, const float* content, int H, int W, const float* style, int Hs, int Ws, float alpha,
                 int num_run, float* out, int* Ho, int* Wo);
 
+/* Style statistics cache.  wct_style_prepare leaves, per level, the style mean and cov^(1/2) inside the
+ * context; they depend only on the style image, so
+ *   wct_stylize_prepared  runs the content cascade against them (no style-side work): content x style batches pay
+ *                         the style side once per style, not once per pair (data_loader.py:32-36 builds the product)
+ *   wct_style_export / wct_style_import  move them (device f64: C*C matrix, then C means; wct_style_stats_count
+ *                         doubles) so that the GPUs of a node compute each level ONCE and broadcast it
+ *                         (wct_hip/sharded.py) instead of every rank repeating all five.
+ * wct_style_prepare_levels: like wct_style_prepare for the levels in `level_mask` (bit L set = level L). */
+int wct_style_prepare_levels(wct_ctx* ctx, const float* style, int Hs, int Ws, unsigned level_mask);
+int wct_style_stats_count(const wct_ctx* ctx, int level, size_t* n_doubles);
+int wct_style_export(wct_ctx* ctx, int level, double* stats);
+int wct_style_import(wct_ctx* ctx, int level, const double* stats);
+int wct_stylize_prepared(wct_ctx* ctx, const float* content, int H, int W, float alpha, int num_run, float* out, int* Ho,
+                         int* Wo);
+
+/* Image edge: the reference harness's ToTensor (PytorchWCT/data_loader.py:57-58: uint8 HWC -> fp32 CHW
+ * / 255) and save_image (WCT.py:128; torchvision 0.2.1: mul(255).clamp(0,255).byte()) on the device.  Pointers are
+ * device pointers, uint8 images are H x W x 3 interleaved and 4-byte aligned.  round_mode 0 = truncation (the
+ * reference's pinned torchvision), 1 = +0.5 before truncation (torchvision >= 0.4). */
+int wct_u8_to_planar(wct_ctx* ctx, const uint8_t* hwc, int H, int W, float* planar);
+int wct_planar_to_u8(wct_ctx* ctx, const float* planar, int H, int W, uint8_t* hwc, int round_mode);
+/* ToTensor -> wct_stylize -> save_image conversion in one call; out_hwc must hold H*W*3 bytes */
+int wct_stylize_u8(wct_ctx* ctx, const uint8_t* content_hwc, int H, int W, const uint8_t* style_hwc, int Hs, int Ws,
+                   float alpha, int num_run, uint8_t* out_hwc, int* Ho, int* Wo, int round_mode);
+
 /* bytes of internal workspace a wct_stylize of this size will hold; wct_reserve allocates it up front */
 size_t wct_workspace_bytes(const wct_ctx* ctx, int H, int W, int Hs, int Ws);
 int wct_reserve(wct_ctx* ctx, int H, int W, int Hs, int Ws);

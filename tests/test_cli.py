@@ -1,0 +1,82 @@
+"""wct_hip/cli.py: flags, pairing and naming of PytorchWCT/WCT.py + data_loader.py (CPU part), one end-to-end run (GPU)."""
+import os
+
+import numpy as np
+import pytest
+
+from wct_hip import cli
+
+
+def test_parser_defaults_match_reference():
+    a = cli.build_parser().parse_args([])
+    # WCT.py:16-34
+    assert (a.contentPath, a.stylePath, a.outf, a.mode, a.alpha, a.num_run) == ("content", "style", "stylized_results", None, 1, 1)
+    assert (a.content_size, a.style_size, a.picked_content_mark, a.picked_style_mark) == (0, 0, ".", ".")
+    assert not (a.UHD or a.synthesis or a.debug or a.numpy)
+    with pytest.raises(SystemExit):
+        cli.build_parser().parse_args(["--mode", "8x"])
+    a = cli.build_parser().parse_args(["--mode", "16x", "--models_root", "/m"])
+    cli.checkpoint_args(a)
+    assert a.e5 == "/m/trained_models/wct_se_16x_new/5SE.pth" and a.d1 == "/m/trained_models/wct_se_16x_new_sd/1SD.pth"   # WCT.py:49-58
+    a = cli.build_parser().parse_args(["--mode", "16x_kd2sd", "--models_root", "/m"])
+    cli.checkpoint_args(a)
+    assert a.d3 == "/m/trained_models/wct_se_16x_new_sd_kd2sd/3SD.pth"                                                       # WCT.py:60-70
+    a = cli.build_parser().parse_args(["--models_root", "/m"])
+    cli.checkpoint_args(a)
+    assert a.e4 == "/m/trained_models/original_wct_models/vgg_normalised_conv4_1.t7"                                         # WCT.py:37-47
+
+
+def test_pairs_and_names(tmp_path):
+    c, s = tmp_path / "c", tmp_path / "s"
+    c.mkdir(); s.mkdir()
+    for n in ("a.jpg", "b.v2.png", "notes.txt", "x_pick.jpeg"):
+        (c / n).write_bytes(b"")
+    for n in ("s1.png", "s2.jpg", "readme.md"):
+        (s / n).write_bytes(b"")
+    pairs = cli.list_pairs(str(c), str(s))
+    cs = [x for x in os.listdir(c) if cli.is_image_file(x)]
+    ss = [x for x in os.listdir(s) if cli.is_image_file(x)]
+    assert pairs == [(a, b) for a in cs for b in ss] and len(pairs) == 6          # data_loader.py:32-36
+    assert cli.list_pairs(str(c), str(s), "pick", "s2") == [("x_pick.jpeg", "s2.jpg")]
+    assert cli.pair_name("b.v2.png", "s1.png") == "b+s1.jpg"                       # data_loader.py:60: split(".")[0]
+    a = cli.build_parser().parse_args(["--mode", "16x", "--outf", "o", "--log_mark", "L"])
+    assert cli.out_name(a, "b+s1.jpg") == os.path.join("o", "L_mode=16x_alpha=1_b+s1.jpg")   # WCT.py:127
+
+
+def test_resize_smaller_edge(tmp_path):
+    Image = pytest.importorskip("PIL.Image")
+    rng = np.random.default_rng(0)
+    Image.fromarray(rng.integers(0, 256, size=(40, 60, 3), dtype=np.uint8)).save(tmp_path / "i.png")
+    assert cli.load_rgb_u8(str(tmp_path / "i.png")).shape == (40, 60, 3)
+    assert cli.load_rgb_u8(str(tmp_path / "i.png"), 20).shape == (20, 30, 3)        # smaller edge -> 20
+    assert cli.load_rgb_u8(str(tmp_path / "i.png"), 40).shape == (40, 60, 3)        # already matching: untouched
+
+
+@pytest.mark.gpu
+def test_cli_end_to_end(tmp_path):
+    """Two contents x one style through the CLI; every saved PNG equals stylize_u8 on the decoded inputs."""
+    import types
+    import torch
+    Image = pytest.importorskip("PIL.Image")
+    from wct_hip import WCT
+    rng = np.random.default_rng(1)
+    c, s, o = tmp_path / "content", tmp_path / "style", tmp_path / "out"
+    c.mkdir(); s.mkdir()
+    imgs = {"c1.png": rng.integers(0, 256, size=(64, 80, 3), dtype=np.uint8), "c2.png": rng.integers(0, 256, size=(48, 48, 3), dtype=np.uint8)}
+    for n, a in imgs.items():
+        Image.fromarray(a).save(c / n)
+    st = rng.integers(0, 256, size=(56, 40, 3), dtype=np.uint8)
+    Image.fromarray(st).save(s / "st.png")
+    # .png names keep the result lossless (the reference always appends .jpg; the name rule is tested above)
+    assert cli.main(["--mode", "16x", "--contentPath", str(c), "--stylePath", str(s), "--outf", str(o), "--log_mark", "T", "--alpha", "0.6"]) == 0
+    w = WCT(types.SimpleNamespace(mode="16x", alpha=0.6))
+    for n, a in imgs.items():
+        path = o / ("T_mode=16x_alpha=0.6_%s+st.jpg" % n.split(".")[0])
+        assert path.exists()
+        got = np.asarray(Image.open(path).convert("RGB"))
+        ref = w.stylize_u8(torch.from_numpy(a), torch.from_numpy(st)).cpu().numpy()
+        assert got.shape == ref.shape
+        # JPEG is lossy: compare loosely here; exactness of the conversion itself is pinned by the G9 tests
+        assert np.abs(got.astype(np.int32) - ref.astype(np.int32)).mean() < 12
+    log = (o / "log_T_16x.txt").read_text()
+    assert "Number of content-style pairs: 2" in log and "Processed 2 images." in log

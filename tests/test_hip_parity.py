@@ -191,6 +191,46 @@ def test_level1_fused_matches_layerwise(torch_cuda, weights16x, monkeypatch):
         assert float((a[k] - b[k]).abs().max() / b[k].abs().max()) < 2e-5, k  # through the whitening (cond ~1e3)
 
 
+# --------------------------------------------------------------------------- image edge, style cache
+def test_g9_image_edge_bit_exact(torch_cuda, wct16, oracle, golden):
+    """ToTensor / save_image conversions on the device: bit-exact against the golden and, on odd sizes that exercise
+    the 4-pixel tails and unaligned plane starts, against the oracle."""
+    torch = torch_cuda
+    g = golden("g9_image_edge.npz")
+    assert np.array_equal(wct16.to_tensor_u8(torch.from_numpy(g["u8"])).cpu().numpy()[0], g["to_tensor"])
+    assert np.array_equal(wct16.to_u8(torch.from_numpy(g["f32"]).cuda(), 0).cpu().numpy(), g["save_trunc"])
+    assert np.array_equal(wct16.to_u8(torch.from_numpy(g["f32"]).cuda(), 1).cpu().numpy(), g["save_round"])
+    rng = np.random.default_rng(3)
+    for (h, w) in ((1, 1), (3, 5), (7, 13), (64, 67), (251, 509)):
+        u8 = rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8)
+        assert np.array_equal(wct16.to_tensor_u8(torch.from_numpy(u8)).cpu().numpy()[0], oracle.to_tensor_u8(u8))
+        f = (rng.random((3, h, w), dtype=np.float32) * 1.4 - 0.2).astype(np.float32)
+        for mode in (0, 1):
+            assert np.array_equal(wct16.to_u8(torch.from_numpy(f).cuda(), mode).cpu().numpy(), oracle.to_u8(f, mode))
+
+
+def test_stylize_u8_and_prepared_style(torch_cuda, wct16, oracle):
+    """stylize_u8 == to_u8(stylize(to_tensor(.))) bitwise; the prepared-style cascade and export -> import of the style
+    statistics reproduce stylize() bitwise (same kernels, same statistics)."""
+    torch = torch_cuda
+    rng = np.random.default_rng(11)
+    cu8 = torch.from_numpy(rng.integers(0, 256, size=(96, 112, 3), dtype=np.uint8)).cuda()
+    su8 = torch.from_numpy(rng.integers(0, 256, size=(80, 72, 3), dtype=np.uint8)).cuda()
+    c, s = wct16.to_tensor_u8(cu8), wct16.to_tensor_u8(su8)
+    ref = wct16.stylize(c, s).clone()
+    assert torch.equal(wct16.stylize_u8(cu8, su8), wct16.to_u8(ref))
+    wct16.style_prepare(s)
+    assert torch.equal(wct16.stylize_prepared(c), ref)
+    stats = {L: wct16.style_export(L).clone() for L in (5, 4, 3, 2, 1)}
+    wct16.style_prepare(torch.rand_like(s))          # overwrite the statistics with another style's ...
+    assert not torch.equal(wct16.stylize_prepared(c), ref)
+    for L, v in stats.items():                       # ... and bring the first style back through import
+        wct16.style_import(L, v)
+    assert torch.equal(wct16.stylize_prepared(c), ref)
+    wct16.style_prepare(s, levels=(5, 3))            # partial prepare (what a rank of a sharded run does)
+    assert torch.equal(wct16.stylize_prepared(c), ref)
+
+
 # --------------------------------------------------------------------------- G6 original arch, G7 config 1
 def test_g6_original_arch(torch_cuda, golden):
     """--mode original graph (C = 512/512/256/128/64: multi-group conv launches, global-memory Jacobi)."""

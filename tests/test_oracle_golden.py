@@ -158,3 +158,11 @@ def test_g7_config1(oracle, weights16x, golden):
 def test_bad_mode(oracle, weights16x):
     with pytest.raises(ValueError):
         oracle.Modules("32x", weights16x)
+
+
+def test_g9_image_edge(oracle, golden):
+    """ToTensor / save_image conversions of the harness (torchvision 0.2.1 bodies restated with torch ops): bit-exact."""
+    g = golden("g9_image_edge.npz")
+    assert np.array_equal(oracle.to_tensor_u8(g["u8"]), g["to_tensor"])
+    assert np.array_equal(oracle.to_u8(g["f32"], 0), g["save_trunc"])
+    assert np.array_equal(oracle.to_u8(g["f32"], 1), g["save_round"])

@@ -313,5 +313,32 @@ def main():
         print("%-24s %8d bytes" % (f, os.path.getsize(os.path.join(GOLD, f))))
 
 
+def gen_g9():
+    """G9 image edge.  ToTensor / save_image live in torchvision (requirements.txt pins torchvision==0.2.1, absent from
+    the snapshot and from this image); their published 0.2.1 bodies, at the reference's call sites
+    (PytorchWCT/data_loader.py:57-58, PytorchWCT/WCT.py:128), are restated here with the torch ops they execute:
+      ToTensor (PIL RGB uint8):  torch.ByteTensor(HWC).permute(2,0,1).float().div(255)
+      save_image (single image): tensor.mul(255).clamp(0, 255).byte().permute(1, 2, 0)     [>= 0.4: .add_(0.5) first]"""
+    r = np.random.default_rng(9)
+    u8 = r.integers(0, 256, size=(37, 53, 3), dtype=np.uint8)
+    u8[0, :8, 0] = [0, 1, 2, 127, 128, 254, 255, 3]
+    tt = torch.from_numpy(u8).permute(2, 0, 1).float().div(255).contiguous().numpy()
+    f = (r.random((3, 29, 41), dtype=np.float32) * 1.5 - 0.2).astype(np.float32)     # below 0 and above 1 (unclamped ReLU output)
+    k = np.arange(0, 29 * 41 * 3, dtype=np.int64) % 256
+    edge = (k.astype(np.float32) / np.float32(255)).reshape(3, 29, 41)               # exactly representable k/255 boundaries
+    f[:, ::3, ::2] = edge[:, ::3, ::2]
+    f[0, 1, 1], f[1, 1, 1], f[2, 1, 1] = np.float32(1.0), np.float32(0.99999994), np.float32(254.5 / 255)
+    ft = torch.from_numpy(f)
+    sv0 = ft.mul(255).clamp(0, 255).byte().permute(1, 2, 0).contiguous().numpy()
+    sv1 = ft.mul(255).add(0.5).clamp(0, 255).byte().permute(1, 2, 0).contiguous().numpy()
+    np.savez_compressed(os.path.join(GOLD, "g9_image_edge.npz"), u8=u8, to_tensor=tt, f32=f, save_trunc=sv0, save_round=sv1)
+    print("G9: ToTensor %s -> %s, save_image %s -> %s" % (u8.shape, tt.shape, f.shape, sv0.shape))
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 2 and sys.argv[1] == "--only" and sys.argv[2] == "g9":
+        os.makedirs(GOLD, exist_ok=True)
+        gen_g9()
+    else:
+        main()
+        gen_g9()
