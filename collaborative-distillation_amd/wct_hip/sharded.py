@@ -16,7 +16,10 @@ coupling is (n, SUM x, SUM x x^T) of the content feature map (util_wct.py:68-70)
     132 KB at C = 128, latency-bound on xGMI) per level;
   * rank 0 turns the global moments into the colouring map (M, b) and broadcasts it (<= 2.1 MB at C = 512),
     so every rank folds the SAME matrices into its decoder;
-  * the style image is small and replicated: every rank computes the style moments itself (no exchange).
+  * the style side (five encodes + moments + matrix square roots, a third of a single-GPU step) depends only on the
+    style image, and only the rank that solves needs its result: level L's style statistics are computed by rank
+    (5 - L) mod world on its side stream, overlapping that rank's content work, and reach rank 0 by one broadcast of
+    C*C + C fp64 values per level (132 KB at C = 128) instead of every rank repeating all five levels.
 
 The orchestration is backend-agnostic: `engine` is a wct_hip.WCT on the GPU (RCCL = torch.distributed "nccl"),
 and tests run the same code under gloo with a CPU checker as the engine.
@@ -68,7 +71,8 @@ class ShardedStylizer:
         Returns this rank's owned columns of the stylised image, [1, 3, H', own_w'] (H' = 16*floor(H/16)).
 
         Engine interface (wct_hip.WCT on the GPU; tests supply a CPU checker with the same four methods):
-          style_prepare(style)                       style side of all levels (GPU: side stream, overlaps the content)
+          style_prepare(style, levels)               style side of the given levels (GPU: side stream, overlaps the content)
+          style_stats_count(L) / style_export(L) / style_import(L, stats)     the level's style statistics as one fp64 vector
           content_encode(L, img, f0, f1) -> h, w, sum, sumsq    encoder + raw moments over owned feature columns
           content_solve(L, n, sum, sumsq, alpha) -> M, b
           content_decode(L, M, b, H, W) -> image     decoder with (M, b) folded into its first conv
@@ -79,7 +83,9 @@ class ShardedStylizer:
         own = self.own
         lo, hi = ext_bounds(own, W_cur, CUM_HALO[5])
         assert img.shape[-1] == hi - lo, "expected columns [%d,%d) of the content" % (lo, hi)
-        e.style_prepare(style)               # replicated: the style image is small
+        world, rank = self.world, self.rank
+        owner = lambda lvl: (5 - lvl) % world           # rank 0 (the solver) owns level 5, the first one it needs
+        e.style_prepare(style, levels=[lvl for lvl in (5, 4, 3, 2, 1) if owner(lvl) == rank])
         for L in (5, 4, 3, 2, 1):
             sh = L - 1
             # crop the running image to this level's extended strip
@@ -94,6 +100,14 @@ class ShardedStylizer:
             packed = torch.cat([sum_c.reshape(-1), sumsq_c.reshape(-1)])
             if self.world > 1:
                 dist.all_reduce(packed)                                # SUM, fp64, C*C + C values
+            if self.world > 1 and owner(L) != 0:                       # the level's style statistics -> the solving rank
+                if rank == owner(L):
+                    stats = e.style_export(L)
+                else:
+                    stats = torch.empty(e.style_stats_count(L), dtype=torch.float64, device=packed.device)
+                dist.broadcast(stats, src=owner(L))
+                if rank == 0:
+                    e.style_import(L, stats)
             n_c = float(h * (W_cur >> sh))                             # feature pixels of the whole image
             Mb = torch.empty(C * C + C, dtype=torch.float64, device=packed.device)
             if self.rank == 0:

@@ -270,6 +270,11 @@ class WCT:
         self._stream()
         self._chk(self._lib.wct_style_prepare_levels(self._ctx, s.data_ptr(), int(s.shape[1]), int(s.shape[2]), mask))
 
+    def style_stats_count(self, level: int) -> int:
+        n = c_size_t()
+        self._chk(self._lib.wct_style_stats_count(self._ctx, level, byref(n)))
+        return int(n.value)
+
     def style_export(self, level: int) -> torch.Tensor:
         """Style statistics of a prepared level as one fp64 vector: cov_s^(1/2) [C*C] then mu_s [C]."""
         n = c_size_t()

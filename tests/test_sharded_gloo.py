@@ -35,10 +35,25 @@ class OracleEngine:
         X = f[:, :, x0:x1].reshape(f.shape[0], -1)
         return float(X.shape[1]), X.sum(1), X @ X.T
 
-    def style_prepare(self, style):
+    def style_prepare(self, style, levels=(5, 4, 3, 2, 1)):
         s = (style[0] if style.dim() == 4 else style).numpy()
-        for L in range(1, 6):
+        for L in levels:
             self.style_moments[L] = self._raw(self.m.encode(L, s))
+
+    # the level's style statistics as one fp64 vector (this checker ships raw moments: n | sum[C] | sumsq[C*C])
+    def style_stats_count(self, level):
+        from wct_hip import model_zoo
+        C = model_zoo.feature_channels("16x", level)
+        return 1 + C + C * C
+
+    def style_export(self, level):
+        n, s, ss = self.style_moments[level]
+        return torch.from_numpy(np.concatenate([[n], s, ss.reshape(-1)]).astype(np.float64))
+
+    def style_import(self, level, stats):
+        v = stats.numpy()
+        C = int(round((-1 + (1 + 4 * (v.size - 1)) ** 0.5) / 2))
+        self.style_moments[level] = (float(v[0]), v[1:1 + C].copy(), v[1 + C:].reshape(C, C).copy())
 
     def content_encode(self, level, img, x0=0, x1=-1):
         x = (img[0] if img.dim() == 4 else img).numpy()
