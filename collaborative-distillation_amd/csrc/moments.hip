@@ -10,7 +10,7 @@
 //
 // Decomposition: the C x C output is cut into 16x16 tiles, upper triangle only (NP pairs I <= J).
 // grid = (pixel chunks, pair groups); a workgroup (4 waves) walks its pixel chunk in LDS tiles of 64 pixels;
-// wave w owns up to 9 tile pairs (interleaved over the group's 36) for the WHOLE chunk, so accumulators stay
+// wave w owns up to 6 tile pairs (interleaved over the group's 24) for the WHOLE chunk, so accumulators stay
 // in registers and there is no cross-wave reduction.  LDS row stride Cs == 16 (mod 32) dwords makes the
 // operand reads (lane = channel l&15 of pixel l>>4) bank-conflict free.  Partial tiles go to a workspace and a
 // second kernel adds them in a fixed order -> bitwise reproducible, no atomics.
@@ -21,12 +21,11 @@
 
 namespace {
 
-constexpr int PPW = 9;   // tile pairs per wave
-constexpr int PPG = 4 * PPW;
 
 struct MomArgs {
   const float* x;
   int C, T, NP, NPG, NPC, Cs, MP, pixsplit;  // MP: pixels per LDS tile
+  int pw;                // tile pairs a wave owns at most (3 or 6); a pair group is 4 * pw pairs
   long npix, chunk;      // pixels per chunk (multiple of MP)
   int wfull, x0, wwin;   // window: pixel p -> (row p / wwin, col x0 + p % wwin) of a map of width wfull
   double* part_sq;       // [NPC][NP][256]
@@ -62,7 +61,9 @@ __device__ __forceinline__ void tile_steps3(const float* lds, int Cs, int st0, i
   }
 }
 
-template <int NLD>  // float4 load slots per thread per tile: ceil(MP * C / 4 / 256)
+// NLD: float4 load slots per thread per tile = ceil(MP * C / 4 / 256); PW: tile pairs a wave can own (3 / 6 / 9 -- sized to
+// the problem so that small-C launches do not carry 9 accumulators); DEPTH: tiles in flight towards HBM (1 or 2)
+template <int NLD, int PW, int DEPTH>
 __global__ __launch_bounds__(256, 2) void moments_kernel(MomArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* lds = reinterpret_cast<float*>(smem);  // [MP][Cs]
@@ -74,14 +75,14 @@ __global__ __launch_bounds__(256, 2) void moments_kernel(MomArgs a) {
   // work split inside the workgroup:
   //   pixel split (NP <= 6, i.e. C <= 48): every wave owns ALL pairs for a quarter of each tile's pixels (3..6
   //     independent accumulator chains per wave, all four waves busy); the four partial sets are added in LDS;
-  //   pair split: wave w owns pairs pg*PPG + w + 4j for the whole tile.
+  //   pair split: wave w owns pairs pg * 4 PW + w + 4j for the whole tile.
   const bool pixsplit = a.pixsplit != 0;
-  int offA[PPW], offB[PPW], pidx[PPW];
-  bool diag[PPW];
+  int offA[PW], offB[PW], pidx[PW];
+  bool diag[PW];
   int cnt = 0;
 #pragma unroll
-  for (int j = 0; j < PPW; ++j) {
-    const int idx = pixsplit ? j : pg * PPG + wave + 4 * j;
+  for (int j = 0; j < PW; ++j) {
+    const int idx = pixsplit ? j : pg * (4 * PW) + wave + 4 * j;
     offA[j] = offB[j] = 0; pidx[j] = 0; diag[j] = false;
     if (idx < a.NP) {
       int I = 0, rem = idx;
@@ -93,10 +94,10 @@ __global__ __launch_bounds__(256, 2) void moments_kernel(MomArgs a) {
   cnt = __builtin_amdgcn_readfirstlane(cnt);
   const int steps = MP / 4;
   const int st0 = pixsplit ? wave * (steps / 4) : 0, st1 = pixsplit ? st0 + steps / 4 : steps;
-  f64x4 acc[PPW];
-  double s[PPW];
+  f64x4 acc[PW];
+  double s[PW];
 #pragma unroll
-  for (int j = 0; j < PPW; ++j) { acc[j] = f64x4{0., 0., 0., 0.}; s[j] = 0.; }
+  for (int j = 0; j < PW; ++j) { acc[j] = f64x4{0., 0., 0., 0.}; s[j] = 0.; }
   // zero the whole tile once: columns >= C (C = 24 -> T*16 = 32) and the row padding are never loaded
   for (int e = tid; e < MP * a.Cs; e += 256) lds[e] = 0.f;
 
@@ -123,23 +124,34 @@ __global__ __launch_bounds__(256, 2) void moments_kernel(MomArgs a) {
       v[k] = *reinterpret_cast<const f32x4*>(a.x + g * a.C + (lpix[k] < 0 ? 0 : lc4[k]) * 4);
     }
   };
-  // software pipeline: the loads of tile t+1 are in flight while tile t is multiplied (one LDS buffer, the next
-  // tile waits in registers) -- keeps ~one tile per workgroup outstanding towards HBM at all times
-  f32x4 nxt[NLD];
-  fetch(p0, nxt);
-  for (long pt = p0; pt < p1; pt += MP) {
+  // software pipeline, TWO tiles deep: while tile t is multiplied, the loads of tiles t+1 and t+2 are in flight (one LDS
+  // buffer, the next two tiles wait in registers).  One tile ahead is not enough: the workgroups of a launch run in
+  // lockstep, so with a single tile in flight the whole chip alternates between "everybody loads" (HBM queues drain in
+  // ~4 us) and "everybody multiplies" (HBM idle) -- measured 1.5 TB/s at C = 32 with depth 1.
+  f32x4 nxa[NLD], nxb[DEPTH == 2 ? NLD : 1];
+  fetch(p0, nxa);
+  if constexpr (DEPTH == 2) fetch(p0 + MP < p1 ? p0 + MP : p0, nxb);
+  auto step = [&](long pt, f32x4 (&cur)[NLD]) {
     __syncthreads();   // previous tile fully consumed
 #pragma unroll
     for (int k = 0; k < NLD; ++k)
       if (lpix[k] >= 0) {
         const bool ok = pt + lpix[k] < p1;
-        *reinterpret_cast<f32x4*>(lds + lpix[k] * a.Cs + lc4[k] * 4) = ok ? nxt[k] : f32x4{0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<f32x4*>(lds + lpix[k] * a.Cs + lc4[k] * 4) = ok ? cur[k] : f32x4{0.f, 0.f, 0.f, 0.f};
       }
     __syncthreads();
-    if (pt + MP < p1) fetch(pt + MP, nxt);
+    if (pt + DEPTH * MP < p1) fetch(pt + DEPTH * MP, cur);   // refill the register set that was just written out
     if (cnt > 0) tile_steps3(lds, a.Cs, st0, st1, pk, offA, offB, acc[0], acc[1], acc[2], s[0], s[1], s[2]);
-    if (cnt > 3) tile_steps3(lds, a.Cs, st0, st1, pk, offA + 3, offB + 3, acc[3], acc[4], acc[5], s[3], s[4], s[5]);
-    if (cnt > 6) tile_steps3(lds, a.Cs, st0, st1, pk, offA + 6, offB + 6, acc[6], acc[7], acc[8], s[6], s[7], s[8]);
+    if constexpr (PW > 3) { if (cnt > 3) tile_steps3(lds, a.Cs, st0, st1, pk, offA + 3, offB + 3, acc[3], acc[4], acc[5], s[3], s[4], s[5]); }
+    if constexpr (PW > 6) { if (cnt > 6) tile_steps3(lds, a.Cs, st0, st1, pk, offA + 6, offB + 6, acc[6], acc[7], acc[8], s[6], s[7], s[8]); }
+  };
+  if constexpr (DEPTH == 2) {
+    for (long pt = p0; pt < p1; pt += 2 * MP) {
+      step(pt, nxa);
+      if (pt + MP < p1) step(pt + MP, nxb);
+    }
+  } else {
+    for (long pt = p0; pt < p1; pt += MP) step(pt, nxa);
   }
   // D layout (f64): col = lane & 15, row = (lane >> 4) + 4 * reg
   if (pixsplit) {
@@ -148,7 +160,7 @@ __global__ __launch_bounds__(256, 2) void moments_kernel(MomArgs a) {
     double* red = reinterpret_cast<double*>(smem);  // [4][NP][256] + [4][T*16]
     double* reds = red + (size_t)4 * a.NP * 256;
 #pragma unroll
-    for (int j = 0; j < PPW; ++j) {
+    for (int j = 0; j < PW; ++j) {
       if (j < cnt) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) red[((size_t)wave * a.NP + j) * 256 + (pk + 4 * r) * 16 + c] = acc[j][r];
@@ -170,7 +182,7 @@ __global__ __launch_bounds__(256, 2) void moments_kernel(MomArgs a) {
     return;
   }
 #pragma unroll
-  for (int j = 0; j < PPW; ++j) {
+  for (int j = 0; j < PW; ++j) {
     if (j < cnt) {
       double* dst = a.part_sq + ((size_t)pc * a.NP + pidx[j]) * 256;
 #pragma unroll
@@ -318,7 +330,10 @@ MomArgs plan(int C, long npix) {
   MomArgs a{};
   a.C = C; a.T = (C + 15) / 16; a.NP = a.T * (a.T + 1) / 2;
   a.pixsplit = a.NP <= 6;
-  a.NPG = a.pixsplit ? 1 : (a.NP + PPG - 1) / PPG;
+  // pairs per wave: 3 or 6 -- never more, so that two tiles of prefetch fit the register file beside the accumulators;
+  // larger C splits the pairs over NPG workgroup groups (each re-reads the features, mostly from L2)
+  a.pw = a.pixsplit ? (a.NP <= 3 ? 3 : 6) : (a.NP <= 12 ? 3 : 6);
+  a.NPG = a.pixsplit ? 1 : (a.NP + 4 * a.pw - 1) / (4 * a.pw);
   a.Cs = (a.T & 1) ? a.T * 16 : a.T * 16 + 16;  // == 16 (mod 32) dwords
   a.MP = std::min(256, (MAXLD * 256 * 4 / C) / 16 * 16);  // MP * C / 4 <= 8 * 256 float4 slots; multiple of 16
   const int MP = a.MP;
@@ -367,16 +382,13 @@ hipError_t launch_moments(const float* feat, int C, int h, int wfull, int x0, in
     return hipSuccess;
   };
   hipError_t le;
+#define WCT_MOM_CASE(N) \
+  case N: le = a.pw == 3 ? go(moments_kernel<N, 3, 2>) : go(moments_kernel<N, 6, 2>); break;
   switch (nld) {
-    case 1: le = go(moments_kernel<1>); break;
-    case 2: le = go(moments_kernel<2>); break;
-    case 3: le = go(moments_kernel<3>); break;
-    case 4: le = go(moments_kernel<4>); break;
-    case 5: le = go(moments_kernel<5>); break;
-    case 6: le = go(moments_kernel<6>); break;
-    case 7: le = go(moments_kernel<7>); break;
-    default: le = go(moments_kernel<8>); break;
+    WCT_MOM_CASE(1) WCT_MOM_CASE(2) WCT_MOM_CASE(3) WCT_MOM_CASE(4) WCT_MOM_CASE(5) WCT_MOM_CASE(6) WCT_MOM_CASE(7)
+    default: le = a.pw == 3 ? go(moments_kernel<8, 3, 2>) : go(moments_kernel<8, 6, 2>); break;
   }
+#undef WCT_MOM_CASE
   if (le != hipSuccess) return le;
   const long ne = (long)a.NP * 256 + a.T * 16;
   hipLaunchKernelGGL(moments_reduce_kernel, dim3((unsigned)((ne + 15) / 16)), dim3(256), 0, s, a, sum, sumsq);
