@@ -116,12 +116,15 @@ __global__ __launch_bounds__(512) void conv3x3_sp_kernel(SpArgs a) {
   // ---- one piece (cout tile c, 8-channel group q, tile row p) of a finished tile's epilogue.
   // D: col = lane & 31 (pixel), row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) (cout)
   constexpr int NPIECE = CPW * 4 * (POOL ? 1 : 2);
-  constexpr int PPT = (NPIECE + 8) / 9;              // pieces per tap: 16 -> 2, 8 / 4 -> 1
+  // The four pieces q = 0..3 of one (cout tile, row) complete the same 128-byte lines of the output, so they are issued
+  // in the SAME tap (4 pieces per tap on the first NPIECE / 4 taps): spread over four taps the lines were written back
+  // half-filled in between (PMC: +18 % HBM write traffic).
+  constexpr int PPT = 4;
   auto epilogue_piece = [&](const f32x16 (&r)[CPW][2], int piece, int ptile, int pgrp) {
     const int ty0 = (ptile / a.tiles_x) * SPH, tx0 = (ptile % a.tiles_x) * FTW;
     const int gx = tx0 + li;
     const int oH = POOL ? a.H >> 1 : a.H, oW = POOL ? a.W >> 1 : a.W;
-    const int p = POOL ? 0 : piece & 1, cq = POOL ? piece : piece >> 1, c = cq >> 2, q = cq & 3;
+    const int q = piece & 3, cp = piece >> 2, p = POOL ? 0 : cp & 1, c = POOL ? cp : cp >> 1;
     const int co = pgrp * COW + (c0 + c) * 32 + 8 * q + 4 * kh;
     const f32x4 bias = *reinterpret_cast<const f32x4*>(biasL + co);
     f32x4 x;
