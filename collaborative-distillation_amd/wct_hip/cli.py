@@ -131,16 +131,24 @@ def main(argv: Optional[List[str]] = None) -> int:
     wct = WCT(args)
     logprinter("Number of content-style pairs: %s" % len(pairs))
     avg = 0.0
-    last_style, s_dev = None, None
+    # style statistics are computed once per style image and reused for every content it is paired with
+    # (data_loader.py:32-36 builds the content x style product; the reference re-encodes the style for every pair)
+    style_cache = {}
     for i, (cfile, sfile) in enumerate(pairs):
         imname = pair_name(cfile, sfile)
         logprinter("\n" + "*" * 30 + ' #%s: Transferring "%s"' % (i, imname))
-        c_u8 = torch.from_numpy(load_rgb_u8(os.path.join(content_dir, cfile), args.content_size)).cuda()
-        if sfile != last_style:
-            s_dev = torch.from_numpy(load_rgb_u8(os.path.join(style_dir, sfile), args.style_size)).cuda()
-            last_style = sfile
+        c_u8 = torch.from_numpy(load_rgb_u8(os.path.join(content_dir, cfile), args.content_size)).pin_memory().cuda(non_blocking=True)
+        s_u8 = None
+        if sfile not in style_cache:
+            s_u8 = torch.from_numpy(load_rgb_u8(os.path.join(style_dir, sfile), args.style_size)).pin_memory().cuda(non_blocking=True)
         t0 = time.time()
-        out = wct.stylize_u8(c_u8, s_dev, args.alpha, args.num_run, args.round_mode).cpu().numpy()   # .cpu() syncs
+        if s_u8 is not None:
+            wct.style_prepare(wct.to_tensor_u8(s_u8))
+            style_cache[sfile] = {L: wct.style_export(L) for L in (5, 4, 3, 2, 1)}
+        else:
+            for L, stats in style_cache[sfile].items():
+                wct.style_import(L, stats)
+        out = wct.to_u8(wct.stylize_prepared(wct.to_tensor_u8(c_u8), args.alpha, args.num_run), args.round_mode).cpu().numpy()   # .cpu() syncs
         path = out_name(args, imname)
         Image.fromarray(out).save(path)
         dt = time.time() - t0
