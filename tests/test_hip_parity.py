@@ -166,6 +166,30 @@ def test_fused_ends_match_unfused(torch_cuda, weights16x, monkeypatch):
         assert torch.equal(a, b)
 
 
+def test_sp16_dma_path_bitwise_equals_fp32_activations(torch_cuda, weights16x, monkeypatch):
+    """SP16 intermediates + DMA-staged kernels (default) vs fp32 NHWC intermediates + register-staged kernels
+    (WCT_SP=0): the split hi/lo values and every accumulation order are the same, so whole encoders / decoders agree bit
+    for bit -- on odd sizes (partial tiles, odd pooling, image-border reflection) and in original mode (cout groups)."""
+    from wct_hip import WCT
+    torch = torch_cuda
+    g = torch.Generator(device="cuda").manual_seed(33)
+    c = torch.rand((1, 3, 211, 173), device="cuda", generator=g)
+    f5 = torch.rand((1, 128, 13, 11), device="cuda", generator=g)
+    f3 = torch.rand((1, 64, 37, 45), device="cuda", generator=g)
+    co = torch.rand((1, 3, 70, 90), device="cuda", generator=g)
+    wo = model_zoo.synth_weights("original", 7)
+    res = {}
+    for sp in ("1", "0"):
+        monkeypatch.setenv("WCT_SP", sp)
+        w = WCT(types.SimpleNamespace(mode="16x", alpha=1.0), weights=weights16x)
+        r = [w.e5(c).clone(), w.e4(c).clone(), w.e3(c).clone(), w.e2(c).clone(), w.d5(f5).clone(), w.d3(f3).clone()]
+        w2 = WCT(types.SimpleNamespace(mode="original", alpha=1.0), weights=wo)
+        r += [w2.e4(co).clone(), w2.d4(w2.e4(co)).clone()]
+        res[sp] = r
+    for a, b in zip(res["1"], res["0"]):
+        assert a.shape == b.shape and torch.equal(a, b)
+
+
 def test_level1_fused_matches_layerwise(torch_cuda, weights16x, monkeypatch):
     """Level 1 without relu1_1 in HBM (level1.hip: image -> conv11 -> moments, image -> conv11 -> folded conv -> image)
     vs the layer-by-layer path (fp32-MFMA conv11, moments kernel, c16 decoder conv).  conv11 is f16x3 in the fused
