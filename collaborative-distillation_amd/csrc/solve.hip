@@ -73,14 +73,14 @@ __device__ __forceinline__ double rotation(double al, double be, double ga, doub
 __host__ __device__ inline size_t eig_doubles(int C) { return 2 * (size_t)C * C + 2 * (size_t)C + 4; }
 __host__ __device__ inline size_t eig_F_offset(int C) { return (size_t)C * C + 2 * (size_t)C + 4; }
 
-__global__ void cov_kernel(int C, double n, const double* sum, const double* sumsq, double* res) {
+__global__ void cov_kernel(int C, double n, const double* sum, const double* sumsq, double* res, double diag_add) {
   const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= (long)C * C) return;
   const int r = (int)(e / C), c = (int)(e % C);
   const double mr = sum[r] / n, mc = sum[c] / n;
   // symmetric by construction: use the (min,max) entry for both halves
   const int lo = r < c ? r : c, hi = r < c ? c : r;
-  res[e] = (sumsq[(size_t)lo * C + hi] - n * mr * mc) / (n - 1.0);
+  res[e] = (sumsq[(size_t)lo * C + hi] - n * mr * mc) / (n - 1.0) + (r == c ? diag_add : 0.0);   // diag_add: `--numpy` (+ I)
   if (c == 0) res[(size_t)C * C + C + r] = mr;  // mu
   if (e == 0) {
     double ex2 = 0.;
@@ -563,13 +563,13 @@ size_t eig_workspace_bytes(int C) {
 size_t assemble_workspace_bytes(int C) { return (size_t)C * C * sizeof(double); }
 
 hipError_t launch_eig(int C, double n, const double* sum, const double* sumsq, int inverse, double* res, int* info_dev,
-                      void* ws, size_t ws_bytes, hipStream_t s) {
+                      void* ws, size_t ws_bytes, hipStream_t s, double diag_add) {
   if (C < 2 || (C & 1) || C > 512 || n < 2) return hipErrorInvalidValue;  // unbiased covariance needs n >= 2
   if (ws_bytes < eig_workspace_bytes(C)) return hipErrorOutOfMemory;
   const size_t cc = (size_t)C * C;
   const int Cp = ns_pad(C);
   const size_t cp2 = (size_t)Cp * Cp;
-  hipLaunchKernelGGL(cov_kernel, dim3((unsigned)((cc + 255) / 256)), dim3(256), 0, s, C, n, sum, sumsq, res);
+  hipLaunchKernelGGL(cov_kernel, dim3((unsigned)((cc + 255) / 256)), dim3(256), 0, s, C, n, sum, sumsq, res, diag_add);
   NsWs w;
   double* p = reinterpret_cast<double*>(ws);
   w.Y[0] = p; w.Y[1] = p + cp2; w.Z[0] = p + 2 * cp2; w.Z[1] = p + 3 * cp2; w.T = p + 4 * cp2;

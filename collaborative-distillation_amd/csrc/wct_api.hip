@@ -65,6 +65,7 @@ struct wct_ctx {
   DevBuf u8c, u8s, u8o;   // fp32 planar staging of wct_stylize_u8 (content, style, result)
   DevBuf l1img;       // level 1 fused: copy of the content image between wct_content_encode and wct_content_decode
   int cur_H = 0, cur_W = 0;
+  int numpy_variant = 0;  // 1: `--numpy` semantics (util_wct.py:143): + I on the CONTENT covariance
   int l1fuse = 1;     // 1: level 1 of the 16x cascade without materialising relu1_1 (level1.hip)
   int sp = 1;         // 1: intermediate activations of the f16x3 path in SP16 (split at the producer, DMA-staged consumers)
   int fuse = 1;       // 1: fused conv11+conv12+pool / conv12+conv11 kernels at the full-resolution ends of the 16x networks
@@ -446,7 +447,8 @@ int eig_impl(wct_ctx* ctx, Lane& ln, int C, double n, const double* sum, const d
   if (int rc = ensure(ctx, res, eig_result_bytes(C))) return rc;
   if (int rc = ensure(ctx, ln.wsEig, eig_workspace_bytes(C))) return rc;
   ProfScope ps(ctx, ln.stream, inverse ? "matfun_invsqrt" : "matfun_sqrt", 0, 0);
-  HIPCHK(ctx, launch_eig(C, n, sum, sumsq, inverse, reinterpret_cast<double*>(res.p), info_dev, ln.wsEig.p, ln.wsEig.cap, ln.stream));
+  HIPCHK(ctx, launch_eig(C, n, sum, sumsq, inverse, reinterpret_cast<double*>(res.p), info_dev, ln.wsEig.p, ln.wsEig.cap, ln.stream,
+                         (inverse && ctx->numpy_variant) ? 1.0 : 0.0));
   return WCT_OK;
 }
 
@@ -1118,6 +1120,12 @@ int wct_reserve(wct_ctx* ctx, int H, int W, int Hs, int Ws) {
   }
   double *M, *b;
   return mb_view(ctx, &M, &b);
+}
+
+int wct_set_numpy_variant(wct_ctx* ctx, int on) {
+  if (!ctx) return WCT_ERR_INVALID;
+  ctx->numpy_variant = on ? 1 : 0;
+  return WCT_OK;
 }
 
 int wct_set_overlap(wct_ctx* ctx, int on) {

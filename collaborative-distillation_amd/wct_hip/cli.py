@@ -9,8 +9,8 @@ What the reference script does around the hot path and where it lives here:
   data_loader.py:50-59   PIL decode (.convert('RGB')), optional Resize, ToTensor            -> load_rgb_u8() + wct_u8_to_planar (GPU)
   WCT.py:120-125    the 5-level cascade, --num_run times -> wct_stylize (one C call)
   WCT.py:127-128    output name and save_image          -> out_name() + wct_planar_to_u8 (GPU) + PIL save
-A frame crosses PCIe as uint8 (3 B/px each way).  --numpy and --synthesis are rejected like in wct_hip.WCT (the first is
-a different operator, the second is broken in the reference: data_loader.py:74 calls torch.rand_like on a PIL image).
+A frame crosses PCIe as uint8 (3 B/px each way).  --numpy selects the reference's whiten_and_color_np semantics (+ I on the
+content covariance); --synthesis is rejected (broken in the reference: data_loader.py:74 calls torch.rand_like on a PIL image).
 Decoding/encoding files needs Pillow on the host (the reference's own dependency); the GPU library is mandatory: there
 is no CPU fallback.
 """

@@ -24,7 +24,7 @@ SYMBOLS = [
     "wct_style_prepare", "wct_content_encode", "wct_content_solve", "wct_content_decode",
     "wct_style_prepare_levels", "wct_style_stats_count", "wct_style_export", "wct_style_import", "wct_stylize_prepared",
     "wct_u8_to_planar", "wct_planar_to_u8", "wct_stylize_u8",
-    "wct_workspace_bytes", "wct_reserve", "wct_set_conv_mode", "wct_set_overlap", "wct_profile_enable", "wct_profile_reset", "wct_profile_read",
+    "wct_workspace_bytes", "wct_reserve", "wct_set_conv_mode", "wct_set_numpy_variant", "wct_set_overlap", "wct_profile_enable", "wct_profile_reset", "wct_profile_read",
 ]
 
 
@@ -94,6 +94,7 @@ def load() -> ctypes.CDLL:
     lib.wct_workspace_bytes.restype = c_size_t
     lib.wct_reserve.argtypes = [c_void_p, c_int, c_int, c_int, c_int]
     lib.wct_set_conv_mode.argtypes = [c_void_p, c_int]
+    lib.wct_set_numpy_variant.argtypes = [c_void_p, c_int]
     lib.wct_set_overlap.argtypes = [c_void_p, c_int]
     lib.wct_profile_enable.argtypes = [c_void_p, c_int]
     lib.wct_profile_reset.argtypes = [c_void_p]

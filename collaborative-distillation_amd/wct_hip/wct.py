@@ -72,9 +72,6 @@ class WCT:
         if mode not in model_zoo.MODES:
             # the reference prints "Wrong mode. Please check." and exit(1)s (util_wct.py:57-59)
             raise ValueError("Wrong mode. Please check.")
-        if getattr(args, "numpy", False):
-            # --numpy adds +I to the content covariance (util_wct.py:143): a different operator, not the parity target
-            raise NotImplementedError("--numpy (whiten_and_color_np) is not provided by the HIP path")
         if not torch.cuda.is_available():
             raise RuntimeError("wct_hip needs a ROCm GPU (torch.cuda.is_available() is False); there is no CPU path")
         self.args = args
@@ -87,6 +84,10 @@ class WCT:
         if weights is None:
             weights = self._weights_from_args(args, mode)
         self._load_modules(weights)
+        # --numpy (util_wct.py:204-208): whiten_and_color_np = the same steps with + I on the content covariance (:143)
+        self.numpy_variant = bool(getattr(args, "numpy", False))
+        if self.numpy_variant:
+            self._chk(self._lib.wct_set_numpy_variant(self._ctx, 1))
         for k in range(1, 6):
             setattr(self, "e%d" % k, _Module(self, "enc", k))
             setattr(self, "d%d" % k, _Module(self, "dec", k))

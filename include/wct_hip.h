@@ -165,6 +165,11 @@ int wct_reserve(wct_ctx* ctx, int H, int W, int Hs, int Ws);
  * env WCT_CONV_MODE=0|fp32 selects 0 at wct_create. */
 int wct_set_conv_mode(wct_ctx* ctx, int mode);
 
+/* `--numpy` of the reference (WCT.py:34, util_wct.py:204-208): whiten_and_color_np adds the identity to the CONTENT
+ * covariance before its SVD (util_wct.py:143) -- a different operator from the default path (max-abs 0.49 on a toy case),
+ * otherwise the same steps.  0 (default): off. */
+int wct_set_numpy_variant(wct_ctx* ctx, int on);
+
 /* 1 (default): the style side of a level (encode, moments, eigen-decomposition -- independent of the content) runs on
  * a context-owned side stream and overlaps the content side; 0: everything runs in order on the caller's stream
  * (used when timing individual kernels). */

@@ -50,8 +50,6 @@ def test_host_mirror_error_behaviour():
     from wct_hip import WCT
     with pytest.raises(ValueError, match="Wrong mode"):          # util_wct.py:57-59 prints this and exits
         WCT(types.SimpleNamespace(mode="32x"))
-    with pytest.raises(NotImplementedError):
-        WCT(types.SimpleNamespace(mode="16x", numpy=True))
     if not torch.cuda.is_available():
         with pytest.raises(RuntimeError, match="no CPU path"):   # the product never falls back to the CPU
             WCT(types.SimpleNamespace(mode="16x"))

@@ -255,6 +255,17 @@ def test_stylize_u8_and_prepared_style(torch_cuda, wct16, oracle):
     assert torch.equal(wct16.stylize_prepared(c), ref)
 
 
+def test_g10_numpy_variant(torch_cuda, weights16x, golden):
+    """`--numpy` semantics on the device (+ I on the content covariance, util_wct.py:143) against the reference's output."""
+    from wct_hip import WCT
+    g = golden("g10_numpy_variant.npz")
+    w = WCT(types.SimpleNamespace(mode="16x", alpha=1.0, numpy=True), weights=weights16x)
+    for tag in ("c64", "c24"):
+        cF, sF = cu(torch_cuda, g[tag + ".cF"]), cu(torch_cuda, g[tag + ".sF"])
+        y = w.transform(cF, sF, None, float(g[tag + ".alpha"])).cpu().numpy()
+        assert rel_err(y, g[tag + ".csF"]) < 2e-6, tag
+
+
 # --------------------------------------------------------------------------- G6 original arch, G7 config 1
 def test_g6_original_arch(torch_cuda, golden):
     """--mode original graph (C = 512/512/256/128/64: multi-group conv launches, global-memory Jacobi)."""

@@ -166,3 +166,12 @@ def test_g9_image_edge(oracle, golden):
     assert np.array_equal(oracle.to_tensor_u8(g["u8"]), g["to_tensor"])
     assert np.array_equal(oracle.to_u8(g["f32"], 0), g["save_trunc"])
     assert np.array_equal(oracle.to_u8(g["f32"], 1), g["save_round"])
+
+
+def test_g10_numpy_variant(oracle, golden):
+    """`--numpy` (whiten_and_color_np: + I on the content covariance) against the reference's own output."""
+    g = golden("g10_numpy_variant.npz")
+    for tag in ("c64", "c24"):
+        y = oracle.transform(g[tag + ".cF"], g[tag + ".sF"], float(g[tag + ".alpha"]), numpy_variant=True)
+        assert rel_err(y, g[tag + ".csF"]) < 1e-6
+        assert rel_err(oracle.transform(g[tag + ".cF"], g[tag + ".sF"], float(g[tag + ".alpha"])), g[tag + ".csF"]) > 1e-3   # a different operator

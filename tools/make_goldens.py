@@ -335,10 +335,35 @@ def gen_g9():
     print("G9: ToTensor %s -> %s, save_image %s -> %s" % (u8.shape, tt.shape, f.shape, sv0.shape))
 
 
+def gen_g10():
+    """G10 `--numpy`: the reference's whiten_and_color_np path (util_wct.py:134-208, `+ I` on the content covariance)
+    through wct.transform, on relu3_1-like (C = 64, with exactly-dead channels) and relu1_1-like (C = 24) features."""
+    util_wct = import_reference()
+    a = ref_args()
+    a.numpy = True
+    wct = util_wct.WCT(a)
+    wct.eval()
+    r = np.random.default_rng(10)
+    g = {}
+    for tag, C, hw, hws, alpha in (("c64", 64, (23, 31), (19, 17), 1.0), ("c24", 24, (40, 36), (28, 44), 0.6)):
+        cF = np.maximum(r.normal(0.3, 1.0, size=(C,) + hw), 0).astype(np.float32)
+        sF = np.maximum(r.normal(0.1, 1.5, size=(C,) + hws), 0).astype(np.float32)
+        if C == 64:
+            cF[5] = 0; cF[40] = 0; sF[7] = 0     # exactly dead channels: harmless with + I on the content side
+        out = ref_transform(wct, t(cF), t(sF), alpha).numpy()
+        g[tag + ".cF"], g[tag + ".sF"], g[tag + ".alpha"], g[tag + ".csF"] = cF, sF, np.float64(alpha), out
+        print("G10 %s: out mean %.5f" % (tag, out.mean()))
+    np.savez_compressed(os.path.join(GOLD, "g10_numpy_variant.npz"), **g)
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 2 and sys.argv[1] == "--only" and sys.argv[2] == "g9":
+    if len(sys.argv) > 2 and sys.argv[1] == "--only" and sys.argv[2] == "g10":
+        os.makedirs(GOLD, exist_ok=True)
+        gen_g10()
+    elif len(sys.argv) > 2 and sys.argv[1] == "--only" and sys.argv[2] == "g9":
         os.makedirs(GOLD, exist_ok=True)
         gen_g9()
     else:
         main()
         gen_g9()
+        gen_g10()
