@@ -19,7 +19,13 @@ from typing import Dict, List, Tuple
 
 import numpy as np
 
-MODES = ("original", "16x")
+MODES = ("original", "16x", "16x_kd2sd")
+
+
+def arch(mode: str) -> str:
+    """Layer graph of a mode: 16x_kd2sd (model/model_kd2sd.py) has the 16x graphs -- its aux 1x1 heads are training-only
+    (never called in forward) and only the decoder checkpoints differ (WCT.py:60-70)."""
+    return "16x" if mode == "16x_kd2sd" else mode
 
 # channel width of VGG block k (conv{k}_x) per mode
 _WIDTHS = {
@@ -54,6 +60,7 @@ def _block(name: str) -> int:
 
 def feature_channels(mode: str, level: int) -> int:
     """C of relu{level}_1 for the given mode (128,128,64,32,24 / 512,512,256,128,64)."""
+    mode = arch(mode)
     if level == 1:
         return _L1_WIDTH[mode]
     return _WIDTHS[mode][level]
@@ -61,6 +68,7 @@ def feature_channels(mode: str, level: int) -> int:
 
 def encoder_layers(mode: str, level: int) -> List[Layer]:
     assert mode in MODES and 1 <= level <= 5
+    mode = arch(mode)
     out: List[Layer] = []
     cin = 3
     last = _LAST_OF_LEVEL[level]

@@ -107,6 +107,9 @@ class WCT:
             return w
         if mode == "16x":
             return model_zoo.load_npz_weights(DEFAULT_16X_WEIGHTS)
+        if mode == "16x_kd2sd":
+            raise FileNotFoundError("mode '16x_kd2sd' needs trained_models/wct_se_16x_new_sd_kd2sd/{1..5}SD.pth (WCT.py:60-70; "
+                                    "not in the reference snapshot) -- pass the .pth paths in args.d1..d5 or weights=...")
         raise FileNotFoundError("mode 'original' needs the torch7 checkpoints of README.md:26 (not in the reference "
                                 "snapshot; load_lua is gone from torch>=1.0) -- pass weights=... instead")
 

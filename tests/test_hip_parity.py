@@ -266,6 +266,19 @@ def test_g10_numpy_variant(torch_cuda, weights16x, golden):
         assert rel_err(y, g[tag + ".csF"]) < 2e-6, tag
 
 
+def test_mode_16x_kd2sd_uses_16x_graphs(torch_cuda, wct16, weights16x):
+    """--mode 16x_kd2sd (WCT.py:60-70, model/model_kd2sd.py): the 16x encoders with decoders of the same conv graph (their aux
+    1x1 heads are never called in forward); its checkpoints are absent, so the plumbing is checked with the 16x tensors."""
+    from wct_hip import WCT
+    torch = torch_cuda
+    w = WCT(types.SimpleNamespace(mode="16x_kd2sd", alpha=1.0), weights=weights16x)
+    g = torch.Generator(device="cuda").manual_seed(2)
+    c, s = torch.rand((1, 3, 64, 80), device="cuda", generator=g), torch.rand((1, 3, 48, 48), device="cuda", generator=g)
+    assert torch.equal(w.stylize(c, s), wct16.stylize(c, s))
+    with pytest.raises(FileNotFoundError):
+        WCT(types.SimpleNamespace(mode="16x_kd2sd", alpha=1.0))
+
+
 # --------------------------------------------------------------------------- G6 original arch, G7 config 1
 def test_g6_original_arch(torch_cuda, golden):
     """--mode original graph (C = 512/512/256/128/64: multi-group conv launches, global-memory Jacobi)."""
