@@ -18,10 +18,9 @@
 //   tile boundary makes all 256 CUs store at once (measured: 20-45 k cycles per tile with the matrix cores idle, HBM
 //   write-bound) and then all compute with HBM idle.  Spread over the next tile's MFMAs the stores are free.
 //
-// LDS (16-B units): stage = act[hl][kh][640] (612 halo pixels of the 34 x 18 tile, padded to 10 DMA blocks of 64)
+// LDS (16-B units): stage = act[640 pixel slots][4 pieces, XOR-swizzled] (612 halo pixels of the 34 x 18 tile)
 //                          + wgt[tap][hl][kh][COW];  2 stages + bias = 154 KB at COW = 64.
-// Plane / segment strides are multiples of 256 B and consecutive lanes read consecutive 16-B slots: every MFMA
-// operand is one conflict-free ds_read_b128, as in conv3x3_f16.hip.
+// Every MFMA operand is one conflict-free ds_read_b128 (see sp_slot below for the activation layout).
 // 128 and more couts run as cout groups of 64 (the activation tile is re-read from L2 per group; a 128-wide weight
 // slab would not leave room for the second stage).
 #include "wct_common.h"
@@ -34,7 +33,15 @@ constexpr int SPH = 16;
 constexpr int SP_NPH = FHW * (SPH + 2);      // 612
 constexpr int SP_NBLK = (SP_NPH + 63) / 64;  // 10
 constexpr int SP_NPP = SP_NBLK * 64;         // 640 (10240 B == 0 mod 256)
-constexpr int SP_ACT_DMA = 4 * SP_NBLK;      // 40 wave-instructions per chunk for the activations
+constexpr int SP_ACT_DMA = (SP_NPH * 4 + 63) / 64;   // 39 wave-instructions per chunk for the activations
+// Activation stage in LDS: pixel-major, 64 B per halo pixel = the four 16-byte pieces q = 2 kh + hl of the chunk, stored at
+// slot 4 pix + (q ^ ((pix >> 2) & 3)).  Why: a DMA wave-instruction writes 64 CONSECUTIVE 16-byte LDS slots, so with this
+// layout its lanes read 16 pixels x 64 contiguous bytes (16 half-used 128-B lines per instruction); the plane layout
+// act[q][pix] made every lane fetch 16 B of a different line (64 lines per instruction, 8x L2->L1 read amplification,
+// measured as the difference between this kernel and its skeleton in tools/experiments/mfma_loop.hip).  The XOR keeps
+// the MFMA operand reads conflict-free: the 16 lanes of a ds_read_b128 group read 16 pixels whose indices are distinct
+// mod 16, i.e. distinct (pix & 3, (pix >> 2) & 3) pairs -> 16 distinct 16-byte slots of the 256-byte bank row.
+__device__ __forceinline__ int sp_slot(int pix, int q) { return pix * 4 + (q ^ ((pix >> 2) & 3)); }
 
 struct SpArgs {
   const char* in;        // SP16 [inH * inW][cin / 8][hi 8 | lo 8] halfs
@@ -81,14 +88,14 @@ __global__ __launch_bounds__(512) void conv3x3_sp_kernel(SpArgs a) {
 #pragma unroll
     for (int i = 0; i < SP_ACT_PER_WAVE; ++i) {
       int idx = wave + NWV * i;
-      idx = idx < SP_ACT_DMA ? idx : SP_ACT_DMA - 1;
-      const int blk = idx % SP_NBLK;
-      int pix = blk * 64 + lane;
-      pix = pix < SP_NPH ? pix : SP_NPH - 1;
+      idx = idx < SP_ACT_DMA ? idx : SP_ACT_DMA - 1;   // surplus waves re-send the last block (same bytes, same place)
+      const int slot_pix = idx * 16 + (lane >> 2);      // LDS slot idx * 64 + lane = 4 slot_pix + (lane & 3)
+      const int q = (lane & 3) ^ ((slot_pix >> 2) & 3);  // the piece that belongs there
+      const int pix = slot_pix < SP_NPH ? slot_pix : SP_NPH - 1;
       const int py = pix / FHW, px = pix - py * FHW;
       int gy = reflect_clamp(ty0 - 1 + py, a.H), gx = reflect_clamp(tx0 - 1 + px, a.W);
       if (a.up_in) { gy >>= 1; gx >>= 1; }
-      poff[i] = ((size_t)gy * a.inW + gx) * rec_in;
+      poff[i] = ((size_t)gy * a.inW + gx) * rec_in + q * 16;
     }
   };
   // slice i (0 .. SP_ACT_PER_WAVE - 1) of a job's DMA: one activation and (if any is left) one weight wave-instruction
@@ -97,10 +104,8 @@ __global__ __launch_bounds__(512) void conv3x3_sp_kernel(SpArgs a) {
     u32x4* wgt = act + 4 * SP_NPP;
     {
       int idx = wave + NWV * i;
-      idx = idx < SP_ACT_DMA ? idx : SP_ACT_DMA - 1;   // surplus waves re-send the last block (same bytes, same place)
-      const int blk = idx % SP_NBLK, q = idx / SP_NBLK;   // q = hl * 2 + kh
-      const char* g = a.in + poff[i] + ch * 64 + (q & 1) * 32 + (q >> 1) * 16;
-      __builtin_amdgcn_global_load_lds(g, (lds_ptr)(act + q * SP_NPP + blk * 64), 16, 0, 0);
+      idx = idx < SP_ACT_DMA ? idx : SP_ACT_DMA - 1;
+      __builtin_amdgcn_global_load_lds(a.in + poff[i] + ch * 64, (lds_ptr)(act + idx * 64), 16, 0, 0);
     }
     if (i < W_PER_WAVE) {
       int idx = wave + NWV * i;
@@ -197,8 +202,8 @@ __global__ __launch_bounds__(512) void conv3x3_sp_kernel(SpArgs a) {
 #pragma unroll
       for (int p = 0; p < 2; ++p) {
         const int pix = (rw * 2 + p + dy) * FHW + li + dx;
-        bh[p] = __builtin_bit_cast(f16x8, act[(0 * 2 + kh) * SP_NPP + pix]);
-        bl[p] = __builtin_bit_cast(f16x8, act[(1 * 2 + kh) * SP_NPP + pix]);
+        bh[p] = __builtin_bit_cast(f16x8, act[sp_slot(pix, 2 * kh)]);
+        bl[p] = __builtin_bit_cast(f16x8, act[sp_slot(pix, 2 * kh + 1)]);
       }
       f16x8 ah[CPW], al[CPW];
 #pragma unroll

@@ -1,0 +1,190 @@
+// How busy can the matrix cores get in the conv kernels' inner loop shape (per tap: 8 ds_read_b128 -> 12 MFMA 32x32x16 f16),
+// with no global traffic at all?  Variants: V0 program order per tap (reads, then MFMAs), V1 operands of tap t+1 read
+// before the MFMAs of tap t (two register sets), V2 = V1 with weights of the whole chunk kept in registers (CT=2: 36 reads
+// hoisted out -> only B reads in the loop).  8 waves per workgroup, one workgroup per CU, barrier per 9 taps.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+constexpr int NPP = 640, COW = 64, FHW = 34;
+
+template <int V>
+__global__ __launch_bounds__(512) void k(float* out, int chunks) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  u32x4* act = reinterpret_cast<u32x4*>(smem);
+  u32x4* wgt = act + 4 * NPP;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, kh = lane >> 5;
+  for (int e = tid; e < 4 * NPP + 36 * COW; e += 512) act[e] = u32x4{0x3c003c00u + e, 0x3c003c00u, 0x38003800u, 0x3c003c00u};
+  __syncthreads();
+  f32x16 acc[2][2];
+  for (int c = 0; c < 2; ++c) for (int p = 0; p < 2; ++p) for (int r = 0; r < 16; ++r) acc[c][p][r] = 0.f;
+  auto load = [&](int tap, f16x8 (&bh)[2], f16x8 (&bl)[2], f16x8 (&ah)[2], f16x8 (&al)[2]) {
+    const int dy = tap / 3, dx = tap - dy * 3;
+    for (int p = 0; p < 2; ++p) {
+      const int pix = (wave * 2 + p + dy) * FHW + li + dx;
+      bh[p] = __builtin_bit_cast(f16x8, act[(0 * 2 + kh) * NPP + pix]);
+      bl[p] = __builtin_bit_cast(f16x8, act[(1 * 2 + kh) * NPP + pix]);
+    }
+    for (int c = 0; c < 2; ++c) {
+      ah[c] = __builtin_bit_cast(f16x8, wgt[((tap * 2 + 0) * 2 + kh) * COW + c * 32 + li]);
+      al[c] = __builtin_bit_cast(f16x8, wgt[((tap * 2 + 1) * 2 + kh) * COW + c * 32 + li]);
+    }
+  };
+  auto mm = [&](f16x8 (&bh)[2], f16x8 (&bl)[2], f16x8 (&ah)[2], f16x8 (&al)[2]) {
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        acc[c][p] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[c], bh[p], acc[c][p], 0, 0, 0);
+        acc[c][p] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[c], bl[p], acc[c][p], 0, 0, 0);
+        acc[c][p] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[c], bh[p], acc[c][p], 0, 0, 0);
+      }
+  };
+  for (int ch = 0; ch < chunks; ++ch) {
+    if (V == 0) {
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        f16x8 bh[2], bl[2], ah[2], al[2];
+        load(tap, bh, bl, ah, al);
+        mm(bh, bl, ah, al);
+      }
+    } else {
+      f16x8 bh[2][2], bl[2][2], ah[2][2], al[2][2];
+      load(0, bh[0], bl[0], ah[0], al[0]);
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        if (tap < 8) load(tap + 1, bh[(tap + 1) & 1], bl[(tap + 1) & 1], ah[(tap + 1) & 1], al[(tap + 1) & 1]);
+        mm(bh[tap & 1], bl[tap & 1], ah[tap & 1], al[tap & 1]);
+      }
+    }
+    if (V != 2) __syncthreads();
+  }
+  float s = 0.f;
+  for (int c = 0; c < 2; ++c) for (int p = 0; p < 2; ++p) for (int r = 0; r < 16; ++r) s += acc[c][p][r];
+  out[blockIdx.x * 512 + tid] = s;
+}
+
+typedef __attribute__((address_space(3))) void* lds_ptr;
+// V3/V4/V5: the V1 loop + per chunk the DMA of the NEXT chunk's activations (40 wave-instructions) and weights (36) into the
+// other LDS stage (global_load_lds_dwordx4), one wait + barrier per chunk -- the real kernel's skeleton.
+//   gsrc: activation source, `stride` bytes between workgroups/chunks (0: everything from one L2-resident 41 KB block);
+//   STORES: every 4th chunk each wave also stores its 64 accumulator registers (16 x 16-byte stores per lane).
+template <bool STORES>
+__global__ __launch_bounds__(512) void kd(float* out, int chunks, const u32x4* gact, size_t stride16, const u32x4* gwgt, u32x4* gout) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int STAGE = 4 * NPP + 36 * COW;
+  u32x4* lds = reinterpret_cast<u32x4*>(smem);
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, kh = lane >> 5;
+  for (int e = tid; e < 2 * STAGE; e += 512) lds[e] = u32x4{0x3c003c00u + e, 0x3c003c00u, 0x38003800u, 0x3c003c00u};
+  __syncthreads();
+  f32x16 acc[2][2];
+  for (int c = 0; c < 2; ++c) for (int p = 0; p < 2; ++p) for (int r = 0; r < 16; ++r) acc[c][p][r] = 0.f;
+  auto issue = [&](int ch, int stage) {
+    u32x4* act = lds + stage * STAGE;
+    u32x4* wgt = act + 4 * NPP;
+    const u32x4* ga = gact + ((size_t)blockIdx.x * chunks + ch) * stride16;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const int idx = wave + 8 * i;
+      __builtin_amdgcn_global_load_lds(ga + idx * 64 + lane, (lds_ptr)(act + idx * 64), 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      int idx = wave + 8 * i; idx = idx < 36 ? idx : 35;
+      __builtin_amdgcn_global_load_lds(gwgt + (size_t)((ch & 3) * 36 + idx) * 64 + lane, (lds_ptr)(wgt + idx * 64), 16, 0, 0);
+    }
+  };
+  issue(0, 0);
+  for (int ch = 0; ch < chunks; ++ch) {
+    const int stage = ch & 1;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (ch + 1 < chunks) issue(ch + 1, stage ^ 1);
+    const u32x4* act = lds + stage * STAGE;
+    const u32x4* wgt = act + 4 * NPP;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int dy = tap / 3, dx = tap - dy * 3;
+      f16x8 bh[2], bl[2], ah[2], al[2];
+      for (int p = 0; p < 2; ++p) {
+        const int pix = (wave * 2 + p + dy) * FHW + li + dx;
+        bh[p] = __builtin_bit_cast(f16x8, act[(0 * 2 + kh) * NPP + pix]);
+        bl[p] = __builtin_bit_cast(f16x8, act[(1 * 2 + kh) * NPP + pix]);
+      }
+      for (int c = 0; c < 2; ++c) {
+        ah[c] = __builtin_bit_cast(f16x8, wgt[((tap * 2 + 0) * 2 + kh) * COW + c * 32 + li]);
+        al[c] = __builtin_bit_cast(f16x8, wgt[((tap * 2 + 1) * 2 + kh) * COW + c * 32 + li]);
+      }
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+          acc[c][p] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[c], bh[p], acc[c][p], 0, 0, 0);
+          acc[c][p] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[c], bl[p], acc[c][p], 0, 0, 0);
+          acc[c][p] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[c], bh[p], acc[c][p], 0, 0, 0);
+        }
+    }
+    if (STORES && (ch & 3) == 3) {
+      u32x4* go = gout + ((size_t)blockIdx.x * (chunks / 4) + (ch >> 2)) * 8192 + wave * 1024 + lane;
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            go[((c * 2 + p) * 4 + q) * 64] = u32x4{__float_as_uint(acc[c][p][4 * q]), __float_as_uint(acc[c][p][4 * q + 1]), __float_as_uint(acc[c][p][4 * q + 2]), __float_as_uint(acc[c][p][4 * q + 3])};
+            acc[c][p][4 * q] = 0.f;
+          }
+    }
+  }
+  float s = 0.f;
+  for (int c = 0; c < 2; ++c) for (int p = 0; p < 2; ++p) for (int r = 0; r < 16; ++r) s += acc[c][p][r];
+  out[blockIdx.x * 512 + tid] = s;
+}
+
+int main() {
+  float* out; hipMalloc(&out, 256 * 512 * 4);
+  const int chunks = 4000; const size_t lds = (4 * NPP + 36 * COW) * 16;
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  auto run = [&](auto kern, const char* name, int wgs) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kern, dim3(wgs), dim3(512), lds, 0, out, 10);
+    hipDeviceSynchronize();
+    hipEventRecord(e0); hipLaunchKernelGGL(kern, dim3(wgs), dim3(512), lds, 0, out, chunks); hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    const double flop = (double)wgs * 8 * chunks * 9 * 12 * 32768.0;
+    printf("%-40s %d WGs: %.2f ms  %.0f TF f16 = %.1f%% of 2516\n", name, wgs, ms, flop / ms / 1e9, flop / ms / 1e9 / 2516 * 100);
+  };
+  run(k<0>, "V0 reads then MFMAs per tap", 256);
+  run(k<1>, "V1 next tap's operands prefetched", 256);
+  run(k<2>, "V1 without the per-chunk barrier", 256);
+  run(k<0>, "V0, 2 WGs per CU", 512);
+  run(k<1>, "V1, 2 WGs per CU", 512);
+  {
+    const int ch2 = 400, wgs = 256;
+    const size_t lds2 = 2 * lds;
+    u32x4 *ga, *gw, *go;
+    const size_t big = (size_t)wgs * ch2 * 2560;     // 16-byte units: 41 KB per (workgroup, chunk) = 4.2 GB
+    hipMalloc(&ga, big * 16); hipMalloc(&gw, 4 * 36 * 64 * 16); hipMalloc(&go, (size_t)wgs * (ch2 / 4) * 8192 * 16);
+    hipMemset(ga, 0x3c, big * 16); hipMemset(gw, 0x3c, 4 * 36 * 64 * 16);
+    auto rund = [&](auto kern, const char* name, size_t stride16) {
+      hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+      hipLaunchKernelGGL(kern, dim3(wgs), dim3(512), lds2, 0, out, 8, ga, stride16, gw, go);
+      hipDeviceSynchronize();
+      hipEventRecord(e0); hipLaunchKernelGGL(kern, dim3(wgs), dim3(512), lds2, 0, out, ch2, ga, stride16, gw, go); hipEventRecord(e1); hipEventSynchronize(e1);
+      float ms; hipEventElapsedTime(&ms, e0, e1);
+      const double flop = (double)wgs * 8 * ch2 * 9 * 12 * 32768.0;
+      printf("%-52s %.2f ms  %.0f TF f16 = %.1f%% of 2516  (act read %.2f TB/s)\n", name, ms, flop / ms / 1e9, flop / ms / 1e9 / 2516 * 100,
+             stride16 ? (double)wgs * ch2 * 40960 / ms / 1e9 : 0.0);
+    };
+    rund(kd<false>, "V3 + DMA, everything L2-resident", 0);
+    rund(kd<false>, "V4 + DMA, activations streamed from HBM", 2560);
+    rund(kd<true>, "V5 = V4 + accumulator stores every 4th chunk", 2560);
+  }
+  return 0;
+}
