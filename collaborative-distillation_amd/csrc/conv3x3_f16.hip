@@ -61,7 +61,9 @@ __device__ __forceinline__ void fetch_act(const F16Args& a, ActRegs& r, int ch, 
     if (a.up_in) { gy >>= 1; gx >>= 1; }
     int c = cbase + kh * 8;
     c = c + 8 <= a.cin ? c : 0;   // cin is a multiple of 8 on this path (16, 24, 32, 64, 128, ...)
-    const float* src = a.in + ((size_t)gy * a.inW + gx) * a.cin + c;
+    // SP16 input (conv_f16_dev.h): chunk plane `ch`, 64-byte pixel record, group kh -> the same 32 bytes as [8 hi | 8 lo]
+    const float* src = a.in_sp ? a.in + (size_t)ch * ((size_t)a.inH * a.inW * 16) + ((size_t)gy * a.inW + gx) * 16 + kh * 8
+                               : a.in + ((size_t)gy * a.inW + gx) * a.cin + c;
     r.v0[k] = *reinterpret_cast<const f32x4*>(src);
     r.v1[k] = *reinterpret_cast<const f32x4*>(src + 4);
   }
@@ -212,7 +214,7 @@ __global__ __launch_bounds__(32 * TH) void conv3x3_f16_kernel(F16Args a) {
         const bool ok = !(li & 1) && oy < Hp && ox < Wp && co < a.cout;
         if (a.out_sp) {
           const u32x4 w = sp16_pair_exchange(m);
-          if (ok) *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(a.out) + ((size_t)oy * Wp + ox) * a.cout * 4 + (co >> 3) * 32 + kh * 16) = w;
+          if (ok) *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(a.out) + sp16_piece(sp16_plane_bytes(Hp, Wp), (size_t)oy * Wp + ox, co >> 3, kh)) = w;
         } else if (ok) {
           *reinterpret_cast<f32x4*>(a.out + ((size_t)oy * Wp + ox) * a.cout + co) = m;
         }
@@ -229,7 +231,7 @@ __global__ __launch_bounds__(32 * TH) void conv3x3_f16_kernel(F16Args a) {
           const bool ok = gy < a.H && gx < a.W && co < a.cout;
           if (a.out_sp) {
             const u32x4 w = sp16_pair_exchange(v);
-            if (ok) *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(a.out) + ((size_t)gy * a.W + gx) * a.cout * 4 + (co >> 3) * 32 + kh * 16) = w;
+            if (ok) *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(a.out) + sp16_piece(sp16_plane_bytes(a.H, a.W), (size_t)gy * a.W + gx, co >> 3, kh)) = w;
           } else if (ok) {
             *reinterpret_cast<f32x4*>(a.out + ((size_t)gy * a.W + gx) * a.cout + co) = v;
           }

@@ -44,13 +44,13 @@ constexpr int SP_ACT_DMA = (SP_NPH * 4 + 63) / 64;   // 39 wave-instructions per
 __device__ __forceinline__ int sp_slot(int pix, int q) { return pix * 4 + (q ^ ((pix >> 2) & 3)); }
 
 struct SpArgs {
-  const char* in;        // SP16 [inH * inW][cin / 8][hi 8 | lo 8] halfs
+  const char* in;        // SP16 (conv_f16_dev.h): [cin / 16] planes of 64-byte pixel records
   char* out;             // SP16 or fp32 NHWC
   const u32x4* wpk;      // [chunk][9][hl][kh][cout_pad] x 16 B
   const float* bias;     // [cout_pad]
   const float* inv_scale_ptr;
   float inv_scale;
-  int H, W, inW;
+  int H, W, inW, inH;
   int cin, cout, cin_chunks, cout_pad, groups;
   int tiles_x, tiles_y, up_in, relu;
 };
@@ -78,7 +78,7 @@ __global__ __launch_bounds__(512) void conv3x3_sp_kernel(SpArgs a) {
   const int ntiles = a.tiles_x * a.tiles_y;
   for (int e = tid; e < a.cout_pad; e += NWV * 64) biasL[e] = a.bias[e];
   const float inv = a.inv_scale_ptr ? *a.inv_scale_ptr : a.inv_scale;
-  const size_t rec_in = (size_t)a.cin * 4;
+  const size_t in_plane = sp16_plane_bytes(a.inH, a.inW);
 
   // ---- DMA of one job into a stage.  Activations: wave-instruction idx = wave + 8 i covers pixel block idx % 10 of
   // plane idx / 10; each lane's pixel offset for the wave's five blocks is recomputed when the tile changes.
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(512) void conv3x3_sp_kernel(SpArgs a) {
       const int py = pix / FHW, px = pix - py * FHW;
       int gy = reflect_clamp(ty0 - 1 + py, a.H), gx = reflect_clamp(tx0 - 1 + px, a.W);
       if (a.up_in) { gy >>= 1; gx >>= 1; }
-      poff[i] = ((size_t)gy * a.inW + gx) * rec_in + q * 16;
+      poff[i] = ((size_t)gy * a.inW + gx) * 64 + q * 16;   // within a chunk plane
     }
   };
   // slice i (0 .. SP_ACT_PER_WAVE - 1) of a job's DMA: one activation and (if any is left) one weight wave-instruction
@@ -105,7 +105,7 @@ __global__ __launch_bounds__(512) void conv3x3_sp_kernel(SpArgs a) {
     {
       int idx = wave + NWV * i;
       idx = idx < SP_ACT_DMA ? idx : SP_ACT_DMA - 1;
-      __builtin_amdgcn_global_load_lds(a.in + poff[i] + ch * 64, (lds_ptr)(act + idx * 64), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(a.in + (size_t)ch * in_plane + poff[i], (lds_ptr)(act + idx * 64), 16, 0, 0);
     }
     if (i < W_PER_WAVE) {
       int idx = wave + NWV * i;
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(512) void conv3x3_sp_kernel(SpArgs a) {
       if (ok) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.out) + ((size_t)oy * oW + ox) * a.cout + co) = x;
     } else {
       const u32x4 w = sp16_pair_exchange(x);
-      if (ok) *reinterpret_cast<u32x4*>(a.out + ((size_t)oy * oW + ox) * a.cout * 4 + (co >> 3) * 32 + kh * 16) = w;
+      if (ok) *reinterpret_cast<u32x4*>(a.out + sp16_piece(sp16_plane_bytes(oH, oW), (size_t)oy * oW + ox, co >> 3, kh)) = w;
     }
   };
 
@@ -277,7 +277,7 @@ hipError_t launch_conv3x3_sp(const ConvDesc& d, const void* in, void* out, int H
   a.inv_scale_ptr = d.inv_scale_ptr; a.inv_scale = d.inv_scale;
   a.H = H; a.W = W;
   a.up_in = (d.flags & CONV_UP_IN) ? 1 : 0;
-  a.inW = a.up_in ? W / 2 : W;
+  a.inW = a.up_in ? W / 2 : W; a.inH = a.up_in ? H / 2 : H;
   a.cin = d.cin; a.cout = d.cout; a.cin_chunks = d.cin_chunks; a.cout_pad = d.cout_pad;
   a.tiles_x = (W + FTW - 1) / FTW; a.tiles_y = (H + SPH - 1) / SPH;
   a.relu = (d.flags & CONV_NO_RELU) ? 0 : 1;

@@ -42,10 +42,19 @@ __device__ __forceinline__ void split8(const f32x4& a, const f32x4& b, f16x8& hi
 }
 
 // ---- "SP16" activation format (intermediate activations of the f16x3 path):
-// per pixel, per group of 8 channels: [8 hi halfs][8 lo halfs] (32 B), x = hi + lo; C * 4 bytes per pixel like fp32.
+// the tensor is cut into 16-channel chunks; each chunk is a plane of 64-byte pixel records
+//     [chunk k = c >> 4][pixel][group (c >> 3) & 1][hi 8 halfs | lo 8 halfs],      x = hi + lo
+// i.e. C * 4 bytes per pixel like fp32, but one chunk's records are CONTIGUOUS over pixels: a convolution walks its K
+// dimension chunk by chunk, so the 64 bytes it needs of a pixel are a full half cache line next to its neighbours'
+// (pixel-major NHWC records made every 16-channel slice a strided gather).  A 16-channel tensor is its own single plane.
 // The split (with its +-65504 clamp) is done ONCE by the producing kernel's epilogue instead of by every consumer on
 // every halo re-read, and consumers move the 16-byte groups global -> LDS without touching them
 // (global_load_lds_dwordx4: no VGPR staging, no VALU).  hi / lo are exactly what split8() computes from the fp32 value.
+__device__ __forceinline__ size_t sp16_plane_bytes(int H, int W) { return (size_t)H * W * 64; }
+// byte offset of the 16-byte piece (hi: hl = 0, lo: hl = 1) of channels 8 g .. 8 g + 7 of a pixel
+__device__ __forceinline__ size_t sp16_piece(size_t plane_bytes, size_t pixel, int g, int hl) {
+  return (size_t)(g >> 1) * plane_bytes + pixel * 64 + (g & 1) * 32 + hl * 16;
+}
 
 // 4 consecutive channels -> (hi, lo) as 2 + 2 dwords
 __device__ __forceinline__ void split4(const f32x4& v, u32x2& hi, u32x2& lo) {
