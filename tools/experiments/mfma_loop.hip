@@ -147,6 +147,15 @@ __global__ __launch_bounds__(512) void kd(float* out, int chunks, const u32x4* g
   out[blockIdx.x * 512 + tid] = s;
 }
 
+__global__ void fill_rand(unsigned* p, size_t n, unsigned seed) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    unsigned x = (unsigned)i * 2654435761u + seed; x ^= x >> 15; x *= 2246822519u; x ^= x >> 13;
+    // two f16 values in [-2, 2): keep the exponent small so that nothing overflows in 4000 accumulations
+    const unsigned lo = (x & 0x83ffu) | 0x3800u, hi = ((x >> 16) & 0x83ffu) | 0x3800u;
+    p[i] = lo | (hi << 16);
+  }
+}
+
 int main() {
   float* out; hipMalloc(&out, 256 * 512 * 4);
   const int chunks = 4000; const size_t lds = (4 * NPP + 36 * COW) * 16;
@@ -172,6 +181,8 @@ int main() {
     const size_t big = (size_t)wgs * ch2 * 2560;     // 16-byte units: 41 KB per (workgroup, chunk) = 4.2 GB
     hipMalloc(&ga, big * 16); hipMalloc(&gw, 4 * 36 * 64 * 16); hipMalloc(&go, (size_t)wgs * (ch2 / 4) * 8192 * 16);
     hipMemset(ga, 0x3c, big * 16); hipMemset(gw, 0x3c, 4 * 36 * 64 * 16);
+    const bool rnd = getenv("RANDOM_FILL") != nullptr;
+    if (rnd) { hipLaunchKernelGGL(fill_rand, dim3(4096), dim3(256), 0, 0, (unsigned*)ga, big * 4, 1u); hipLaunchKernelGGL(fill_rand, dim3(64), dim3(256), 0, 0, (unsigned*)gw, (size_t)4 * 36 * 64 * 4, 7u); hipDeviceSynchronize(); printf("random operands in [-2,2):\n"); }
     auto rund = [&](auto kern, const char* name, size_t stride16) {
       hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
       hipLaunchKernelGGL(kern, dim3(wgs), dim3(512), lds2, 0, out, 8, ga, stride16, gw, go);
