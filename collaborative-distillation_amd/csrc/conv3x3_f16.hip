@@ -10,7 +10,10 @@
 // epilogue multiplies by the exact inverse.  Activations beyond +-65504 saturate (never inf).
 //
 // Same fusions and the same NHWC/planar layouts as conv3x3.hip (reflect pad, 2x2 max-pool epilogue, nearest-x2
-// in the tile load, folded conv0 / WCT affine); the 3-channel FIRST conv stays on the fp32 kernel (HBM-bound).
+// in the tile load, folded conv0 / WCT affine).  These are the REGISTER-STAGED kernels: fp32 NHWC or SP16 input
+// (conv_f16_dev.h), fp32 or SP16 output.  They serve the fp32-input layers (first decoder conv with the folded WCT map, API
+// entry points), the 16-cout layers and the pooled 32-cout layers; SP16-input layers with >= 32 couts otherwise take the
+// DMA-staged kernel of conv3x3_sp.hip.  A stand-alone 3-channel first conv (original mode) stays on the fp32 kernel.
 //
 // Tiling: workgroup = 4 waves = 32 x 8 output pixels x all couts (<= 128); wave w owns rows 2w, 2w+1.
 // K is walked in 16-channel chunks; per chunk LDS holds, as 16-byte groups of 8 halfs,
@@ -355,8 +358,8 @@ __global__ __launch_bounds__(256) void conv3x3_f16_c16_kernel(F16Args a) {
 // + pool: model_cd.py:726-728) and the last two decoder layers (conv12 16->16 after the upsample, conv11 16->3:
 // model_cd.py:291-293) run at full image resolution with only 16 channels: unfused they move 156 B per pixel
 // (the 64 B/px intermediate written and read back), fused 28 B per pixel.  The intermediate lives only in LDS,
-// already split into f16 hi/lo planes.  Arithmetic and summation order are those of the unfused kernels, so
-// results are bitwise identical to running the two layers separately.
+// already split into f16 hi/lo planes.  The tail keeps the arithmetic and summation order of the unfused kernels (bitwise
+// identical to running the two layers separately); the head's conv11 is f16x3 here and exact-fp32 MFMA unfused (3e-6).
 // The intermediate's own reflect padding: a halo pixel OUTSIDE the image must hold the intermediate value of its
 // mirror pixel (not the first conv evaluated outside the image), so every halo pixel is evaluated at its reflected
 // image coordinate -- whose 3x3 input window is inside the staged tile -- and stored at the halo position.
