@@ -114,7 +114,7 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("world,H,W", [(2, 64, 1280), (3, 48, 1925)])
+@pytest.mark.parametrize("world,H,W", [(2, 64, 1280), (3, 48, 1925), (6, 32, 1152)])   # 6 ranks: every level's style side on another rank, rank 5 none
 def test_sharded_equals_untiled(tmp_path, oracle, weights16x, world, H, W):
     out = str(tmp_path / "sharded.npy")
     mp.spawn(_worker, args=(world, _free_port(), H, W, out), nprocs=world, join=True)
