@@ -75,6 +75,12 @@ __host__ __device__ inline size_t eig_F_offset(int C) { return (size_t)C * C + 2
 
 __global__ void cov_kernel(int C, double n, const double* sum, const double* sumsq, double* res, double diag_add) {
   const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (blockIdx.x == 0 && threadIdx.x < 64) {   // eigenvalue floor from max E[x^2]: one wave, strided + shuffle max
+    double ex2 = 0.;                            // (a single thread walking the diagonal cost 19 us of dependent loads)
+    for (int j = threadIdx.x; j < C; j += 64) ex2 = fmax(ex2, sumsq[(size_t)j * C + j]);
+    for (int o = 32; o > 0; o >>= 1) ex2 = fmax(ex2, __shfl_xor(ex2, o));
+    if (threadIdx.x == 0) res[(size_t)C * C + 2 * C] = ABS_FLOOR * ex2 / n;
+  }
   if (e >= (long)C * C) return;
   const int r = (int)(e / C), c = (int)(e % C);
   const double mr = sum[r] / n, mc = sum[c] / n;
@@ -82,11 +88,6 @@ __global__ void cov_kernel(int C, double n, const double* sum, const double* sum
   const int lo = r < c ? r : c, hi = r < c ? c : r;
   res[e] = (sumsq[(size_t)lo * C + hi] - n * mr * mc) / (n - 1.0) + (r == c ? diag_add : 0.0);   // diag_add: `--numpy` (+ I)
   if (c == 0) res[(size_t)C * C + C + r] = mr;  // mu
-  if (e == 0) {
-    double ex2 = 0.;
-    for (int j = 0; j < C; ++j) ex2 = fmax(ex2, sumsq[(size_t)j * C + j]);
-    res[(size_t)C * C + 2 * C] = ABS_FLOOR * ex2 / n;
-  }
 }
 
 // =====================================================================================================
