@@ -56,6 +56,9 @@ def load() -> ctypes.CDLL:
     if not os.path.exists(LIB_PATH):
         raise ImportError("libwct_hip.so not found at %s -- build it with collaborative-distillation_amd/build.sh; "
                           "there is no CPU fallback" % LIB_PATH)
+    # torch first: it brings its own HIP runtime, and both must resolve to ONE libamdhip64 in the process -- with this
+    # library loaded before torch, wct_create later fails with a HIP error (seen when build() and smoke() share a process)
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     fp, dp, ip = POINTER(c_float), POINTER(c_double), POINTER(c_int)
     vp = c_void_p  # device pointers travel as integers
