@@ -78,6 +78,7 @@ class WCT:
         self.mode = mode
         self.alpha = float(getattr(args, "alpha", 1.0))
         self.device = torch.cuda.current_device() if device is None else int(device)
+        self.stats_device = "cuda:%d" % self.device   # where style_export() tensors live (wct_hip/replicas.py, sharded.py)
         self._lib = _lib.load()
         self._ctx = c_void_p()
         _lib.check(self._lib, None, self._lib.wct_create(self.device, byref(self._ctx)))

@@ -279,6 +279,16 @@ def test_mode_16x_kd2sd_uses_16x_graphs(torch_cuda, wct16, weights16x):
         WCT(types.SimpleNamespace(mode="16x_kd2sd", alpha=1.0))
 
 
+def test_replica_stylizer_single_rank(torch_cuda, wct16):
+    """wct_hip/replicas.py with one rank is stylize(); the multi-rank exchange is covered on CPU (gloo, test_sharded_gloo.py)."""
+    from wct_hip.replicas import ReplicaStylizer
+    torch = torch_cuda
+    g = torch.Generator(device="cuda").manual_seed(4)
+    c, s = torch.rand((1, 3, 80, 96), device="cuda", generator=g), torch.rand((1, 3, 64, 64), device="cuda", generator=g)
+    ref = wct16.stylize(c, s).clone()
+    assert torch.equal(ReplicaStylizer(wct16, None).stylize(c, s), ref)
+
+
 # --------------------------------------------------------------------------- G6 original arch, G7 config 1
 def test_g6_original_arch(torch_cuda, golden):
     """--mode original graph (C = 512/512/256/128/64: multi-group conv launches, global-memory Jacobi)."""

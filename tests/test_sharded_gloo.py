@@ -71,6 +71,16 @@ class OracleEngine:
         M, b = self.o.affine_from_moments(mu_c, cov_c, mu_s, cov_s, alpha)
         return torch.from_numpy(M), torch.from_numpy(b)
 
+    def stylize_prepared(self, content, alpha=1.0, num_run=1):
+        """The cascade against the style moments held by the engine (what wct_hip.WCT.stylize_prepared does on the GPU)."""
+        img = (content[0] if content.dim() == 4 else content)
+        for _ in range(num_run):
+            for L in (5, 4, 3, 2, 1):
+                h, w, s, ss = self.content_encode(L, img)
+                M, b = self.content_solve(L, float(h * w), s, ss, alpha)
+                img = self.content_decode(L, M, b, 0, 0)[0]
+        return img[None]
+
     def content_decode(self, level, M, b, H, W):
         f = self.cF.astype(np.float64)
         y = (np.einsum("ab,bhw->ahw", M.numpy(), f) + b.numpy()[:, None, None]).astype(np.float32)
@@ -149,3 +159,40 @@ def test_strip_bounds():
     assert ext_bounds((0, 1280), 10240, 272) == (0, 1552) and ext_bounds((8960, 10240), 10240, 272) == (8688, 10240)
     with pytest.raises(ValueError):
         strip_bounds(40, 4)
+
+
+def _replica_worker(rank, world, port, out_dir):
+    for p in (REPO, PKG):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from wct_hip import model_zoo
+        from wct_hip.replicas import ReplicaStylizer
+        eng = OracleEngine(model_zoo.load_npz_weights(os.path.join(PKG, "weights", "16x.npz")))
+        eng.o.set_num_threads(2)
+        style = np.random.default_rng(2).random((3, 48, 64), dtype=np.float32)
+        content = np.random.default_rng(10 + rank).random((3, 32 + 16 * rank, 48), dtype=np.float32)   # a different image per rank
+        out = ReplicaStylizer(eng, dist).stylize(torch.from_numpy(content), torch.from_numpy(style))
+        assert sorted(eng.style_moments) == [1, 2, 3, 4, 5]
+        np.save(os.path.join(out_dir, "r%d.npy" % rank), out.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_replicas_share_the_style_side(tmp_path, weights16x):
+    """BASELINE config 5: independent contents, one style.  Each rank computes some levels of the style statistics, all
+    ranks end up with all of them, and every rank's result equals a single-process run on its own content."""
+    world = 3
+    mp.spawn(_replica_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    style = np.random.default_rng(2).random((3, 48, 64), dtype=np.float32)
+    for rank in range(world):
+        content = np.random.default_rng(10 + rank).random((3, 32 + 16 * rank, 48), dtype=np.float32)
+        eng = OracleEngine(weights16x)
+        eng.style_prepare(torch.from_numpy(style))
+        ref = eng.stylize_prepared(torch.from_numpy(content)).numpy()
+        got = np.load(str(tmp_path / ("r%d.npy" % rank)))
+        assert got.shape == ref.shape and np.array_equal(got, ref)    # same engine, same statistics: identical
