@@ -22,9 +22,10 @@
 // Rank policy: the reference keeps every singular value >= 1e-100 (util_wct.py:25,82-86), i.e. all of
 // them -- null directions get lambda ~ 1e-15 from LAPACK and are multiplied into exactly-zero centred
 // features.  Jacobi returns the same directions with tiny norms; directions with
-// lambda <= max(rel_thresh * lambda_max, ABS_FLOOR * max E[x^2]) are dropped (rel_thresh 1e-10; live spectra
-// sit >= 13 decades above the noise), which reproduces the reference to <= 2e-6 in every regime of
-// tests/golden/g3.  The absolute floor is the round-off level of the covariance itself (formed from raw fp64
+// lambda <= max(REL_THRESH * lambda_max, ABS_FLOOR * max E[x^2]) are dropped (REL_THRESH 1e-12: round-off puts null
+// directions at <= 1e-16 lambda_max, while GENUINE directions 1e-10..1e-11 below the top one exist -- --mode original on
+// generated weights has them -- and the reference whitens those like any other), which reproduces the reference to
+// <= 2e-6 in every regime of tests/golden/g3.  The absolute floor is the round-off level of the covariance itself (formed from raw fp64
 // sums of magnitude E[x^2]); it makes a constant feature map (cov = 0 up to round-off) whiten to exactly 0 like
 // the reference's exact-zero centred features do (k_c = 0 -> target = s_mean, util_wct.py:82-86,117-126).
 #include "wct_common.h"
@@ -37,6 +38,7 @@ typedef double f64x2 __attribute__((ext_vector_type(2)));
 constexpr int MAX_SWEEPS = 40;
 constexpr double ROT_TOL = 1e-12;  // relative off-diagonal; quadratic convergence overshoots this by far
 constexpr double ABS_FLOOR = 1e-13;
+static const double REL_THRESH = [] { const char* e = getenv("WCT_REL_THRESH"); return e ? atof(e) : 1e-12; }();
 
 __device__ __forceinline__ void tournament_pair(int n, int round, int k, int& p, int& q) {
   // circle method: player n-1 stays, the others rotate
@@ -102,14 +104,22 @@ __global__ void cov_kernel(int C, double n, const double* sum, const double* sum
 // residual of iteration k-1 is already below NS_TOL.  If the budget runs out (singular or very ill-conditioned
 // matrix, e.g. fewer pixels than channels) ok stays 0 and the Jacobi path below takes over (C <= 128: one gated
 // launch; C > 128: decided on the host after reading the flag back, see launch_eig).
-constexpr int NS_MAXIT = 26, NS_MAXIT_REG = 26;
+constexpr int NS_MAXIT = 26, NS_MAXIT_REG = 96;   // default budget; size of the residual array (WCT_NS_MAXIT may raise the budget)
 constexpr double NS_TOL = 1e-7;   // on max|ZY - I| BEFORE an update; the update squares it (quadratic convergence)
+// Condition gate of the inverse square root: Z -> (A/s)^(-1/2), so ||Z||_F >= (lambda_min/s)^(-1/2) (and <= sqrt(C) times it).
+// Above 1e6 (lambda_min <~ 1e-12 s; the eps-regularised null space of a rank-deficient covariance lands at 3e7) the
+// converged iterate is the inverse of round-off, not the pseudo-inverse the reference's exactly-zero centred components
+// make of it (util_wct.py:117-120): ok stays 0 and the Jacobi path drops those directions (REL_THRESH, above).  Below it
+// every direction is genuine and kept, as the reference does; the iteration's error there is ~10 cond eps (8e-5 of max|M|
+// at lambda_min = 1e-11 lambda_max, tools/experiments/solve_cond.py).
+static const double NS_ZMAX = [] { const char* e = getenv("WCT_NS_ZMAX"); return e ? atof(e) : 1e6; }();
 
 struct NsWs {           // carved from the eig workspace
   double* Y[2]; double* Z[2]; double* T;
   int* dead;            // [C]
   double* scal;         // [0] = s (Frobenius norm)
   unsigned long long* resid;  // [maxit + 1] max |ZY - I| per iteration, as double bits (non-negative -> integer order)
+  double* zfro;         // [maxit + 1] ||Z_k||_F^2 of the iterate entering iteration k (live block), for the condition gate
   int* iters;           // iterations actually executed
   int* ok;              // 1: F holds the Newton-Schulz result
 };
@@ -119,7 +129,7 @@ __global__ __launch_bounds__(1024) void ns_init_kernel(const double* res, int C,
   const int tid = threadIdx.x;
   const double floor_ = res[(size_t)C * C + 2 * C];
   for (int j = tid; j < C; j += 1024) w.dead[j] = !(res[(size_t)j * C + j] > floor_);
-  for (int k = tid; k <= maxit; k += 1024) w.resid[k] = 0ull;  // atomicMax target; a skipped iteration leaves 0 = "converged"
+  for (int k = tid; k <= maxit; k += 1024) { w.resid[k] = 0ull; w.zfro[k] = 0.; }  // atomic targets; a skipped iteration leaves resid 0 = "converged"
   if (tid == 0) { *w.iters = 0; *w.ok = 0; }
   __syncthreads();
   double s = 0.;
@@ -151,12 +161,13 @@ __global__ void ns_fill_kernel(const double* res, int C, int Cp, NsWs w) {
 // one 16x16 output tile per wave, 2x2 tiles per workgroup: D = P Q with the TRUE row-major operands.  (Reading P
 // transposed because "every iterate is symmetric" is tempting -- both operands would be coalesced -- but it makes the
 // iteration unstable: the antisymmetric part of the round-off is amplified and it diverges for cond >~ 3e3.)
-__device__ __forceinline__ f64x4 tile_gemm(const double* P, const double* Q, int Cp, int i0, int j0, int lane) {
+__device__ __forceinline__ f64x4 tile_gemm(const double* P, const double* Q, int Cp, int i0, int j0, int lane, int kbeg = 0, int kend = -1) {
   const int li = lane & 15, kk = lane >> 4;
   f64x4 acc = f64x4{0., 0., 0., 0.};
   const double* pp = P + (size_t)(i0 + li) * Cp + kk;
   const double* qq = Q + (size_t)kk * Cp + j0 + li;
-  for (int k0 = 0; k0 < Cp; k0 += 16) {
+  if (kend < 0) kend = Cp;
+  for (int k0 = kbeg; k0 < kend; k0 += 16) {
     double a[4], b[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) { a[u] = pp[k0 + 4 * u]; b[u] = qq[(size_t)(k0 + 4 * u) * Cp]; }
@@ -166,17 +177,38 @@ __device__ __forceinline__ f64x4 tile_gemm(const double* P, const double* Q, int
   return acc;  // row = kk + 4 * reg, col = li
 }
 
+// Cp >= 256: one 16x16 tile per WORKGROUP, the k range split over its 4 waves and summed through LDS in a fixed order --
+// the k loop of a whole-tile wave is a chain of Cp/16 dependent load batches (~30 us per launch at Cp = 512, against 3.4 us
+// of fp64 MFMA work), a quarter of it with 4x the workgroups hides that latency.  Returns the tile in wave 0 only.
+__device__ __forceinline__ f64x4 tile_gemm_splitk(const double* P, const double* Q, int Cp, int i0, int j0, int lane, int wave, double (*red)[256]) {
+  const int kq = Cp >> 2;
+  f64x4 acc = tile_gemm(P, Q, Cp, i0, j0, lane, wave * kq, (wave + 1) * kq);
+  if (wave) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[wave - 1][r * 64 + lane] = acc[r];
+  }
+  __syncthreads();
+  if (!wave) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = ((acc[r] + red[0][r * 64 + lane]) + red[1][r * 64 + lane]) + red[2][r * 64 + lane];
+  }
+  return acc;
+}
+
 __device__ __forceinline__ bool ns_converged(const NsWs& w, int it) {
   return it > 0 && __longlong_as_double((long long)w.resid[it - 1]) < NS_TOL;
 }
 
 // stage 1 of iteration `it`: T = 1.5 I - 0.5 Z Y ; resid[it] = max |Z Y - I|
+template <bool SPLITK>
 __global__ __launch_bounds__(256) void ns_stage1_kernel(NsWs w, int Cp, int it) {
   if (ns_converged(w, it)) return;
+  __shared__ double red[SPLITK ? 3 : 1][256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int i0 = blockIdx.y * 32 + (wave >> 1) * 16, j0 = blockIdx.x * 32 + (wave & 1) * 16;
+  const int i0 = SPLITK ? blockIdx.y * 16 : blockIdx.y * 32 + (wave >> 1) * 16, j0 = SPLITK ? blockIdx.x * 16 : blockIdx.x * 32 + (wave & 1) * 16;
   const int cur = it & 1;
-  const f64x4 acc = tile_gemm(w.Z[cur], w.Y[cur], Cp, i0, j0, lane);
+  const f64x4 acc = SPLITK ? tile_gemm_splitk(w.Z[cur], w.Y[cur], Cp, i0, j0, lane, wave, red) : tile_gemm(w.Z[cur], w.Y[cur], Cp, i0, j0, lane);
+  if (SPLITK && wave) return;
   const int li = lane & 15, kk = lane >> 4;
   double m = 0.;
 #pragma unroll
@@ -191,34 +223,95 @@ __global__ __launch_bounds__(256) void ns_stage1_kernel(NsWs w, int Cp, int it) 
 }
 
 // stage 2: Y' = Y T (blockIdx.z = 0), Z' = T Z (blockIdx.z = 1), into the other ping-pong buffer
+template <bool SPLITK>
 __global__ __launch_bounds__(256) void ns_stage2_kernel(NsWs w, int Cp, int it) {
   if (ns_converged(w, it)) return;
+  __shared__ double red[SPLITK ? 3 : 1][256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int i0 = blockIdx.y * 32 + (wave >> 1) * 16, j0 = blockIdx.x * 32 + (wave & 1) * 16;
+  const int i0 = SPLITK ? blockIdx.y * 16 : blockIdx.y * 32 + (wave >> 1) * 16, j0 = SPLITK ? blockIdx.x * 16 : blockIdx.x * 32 + (wave & 1) * 16;
   const int cur = it & 1, nxt = cur ^ 1;
   const bool zside = blockIdx.z == 1;
-  const f64x4 acc = zside ? tile_gemm(w.T, w.Z[cur], Cp, i0, j0, lane) : tile_gemm(w.Y[cur], w.T, Cp, i0, j0, lane);
+  const double* Pm = zside ? w.T : w.Y[cur];
+  const double* Qm = zside ? w.Z[cur] : w.T;
+  const f64x4 acc = SPLITK ? tile_gemm_splitk(Pm, Qm, Cp, i0, j0, lane, wave, red) : tile_gemm(Pm, Qm, Cp, i0, j0, lane);
+  if (SPLITK && wave) return;
   double* out = zside ? w.Z[nxt] : w.Y[nxt];
   const int li = lane & 15, kk = lane >> 4;
 #pragma unroll
   for (int r = 0; r < 4; ++r) out[(size_t)(i0 + kk + 4 * r) * Cp + j0 + li] = acc[r];
-  if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) *w.iters = it + 1;
+  if (zside) {   // ||Z'||_F^2 (the identity block of dead / padding channels adds at most Cp: irrelevant against the gate)
+    double q = acc[0] * acc[0] + acc[1] * acc[1] + acc[2] * acc[2] + acc[3] * acc[3];
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    if (lane == 0) atomicAdd(&w.zfro[it + 1], q);
+  }
+  if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) *w.iters = it + 1;   // wave 0 in either flavour
 }
 
 // F = Z / sqrt(s) (inverse) or Y * sqrt(s), dead rows/cols zeroed; ok = converged
-__global__ void ns_final_kernel(double* res, int C, int Cp, int inverse, NsWs w, int maxit, int* info) {
+__global__ void ns_final_kernel(double* res, int C, int Cp, int inverse, NsWs w, int maxit, double zmax, int* info, const double* deflated) {
   const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
   // n = executed iterations; the iterate lives in buffer n & 1.  resid[n-1] was measured on the iterate BEFORE the
   // last executed update, which squares it.
   const int n = *w.iters;
-  const bool ok = n >= 1 && n <= maxit && __longlong_as_double((long long)w.resid[n - 1]) < NS_TOL;
+  bool ok = n >= 1 && n <= maxit && __longlong_as_double((long long)w.resid[n - 1]) < NS_TOL;
+  if (ok && inverse && !deflated) ok = w.zfro[n] <= zmax * zmax;   // condition gate (NS_ZMAX)
   if (e == 0) { *w.ok = ok ? 1 : 0; if (info && ok) *info = n; }
   if (e >= (long)C * C || !ok) return;
   const int r = (int)(e / C), c = (int)(e % C);
   const double s = w.scal[0];
   double v = 0.;
-  if (!w.dead[r] && !w.dead[c]) v = inverse ? w.Z[n & 1][(size_t)r * Cp + c] * rsqrt(s) : w.Y[n & 1][(size_t)r * Cp + c] * sqrt(s);
+  if (!w.dead[r] && !w.dead[c]) {
+    const size_t at = (size_t)r * Cp + c;
+    v = (deflated ? deflated[at] : inverse ? w.Z[n & 1][at] : w.Y[n & 1][at]) * (inverse ? rsqrt(s) : sqrt(s));
+  }
   res[eig_F_offset(C) + e] = v;
+}
+
+// ---- C > 128: deflated iteration.  The wide layers of --mode original meet singular covariances (fewer pixels than
+//      channels) and spectra graded over 10+ decades, and a Jacobi sweep there is C - 1 dependent launches (27..68 ms per
+//      matrix).  So the iteration runs on B = A + delta I with delta = NS_DEFLATE ||A||_F (cond(B) <= 1e12: <= 41 iterations),
+//      and the pseudo-inverse square root of A itself is recovered from Z = B^(-1/2), Y = B^(1/2) with a few more GEMMs:
+//          E = delta Z^2 = delta (A + delta)^-1                eigenvalue delta/(lambda+delta): ~0 live, ~1 null
+//          P = h^5(I - E),  h(x) = 3x^2 - 2x^3                  0 and 1 are super-attracting: a hard projector onto lambda > delta
+//          A^(-1/2) = P Z (I - E)^(-1/2),  A^(1/2) = P Y (I - E)^(1/2)     (Taylor series in E, 5 terms: |E| <= 1e-4 on directions
+//                                                                with lambda >= 1e-8 ||A||, exact to round-off there)
+//      numpy prototype against eigh + threshold: <= 2e-8 for rank-deficient covariances (n = 16 .. C-1 pixels) and for graded
+//      spectra down to 1e-11; directions within a decade of delta get a soft weight instead of the hard cut (no
+//      implementation agrees with another there: the reference amplifies its own fp32 conv round-off by 1e6 in them).
+constexpr double NS_DEFLATE = 1e-12;
+
+// D = alpha P Q + beta R + gamma I ; optionally D2 = I - D
+__global__ __launch_bounds__(256) void ns_gemm_kernel(const double* P, const double* Q, double* D, double* D2, int Cp, double alpha,
+                                                       const double* R, double beta, double gamma) {
+  __shared__ double red[3][256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i0 = blockIdx.y * 16, j0 = blockIdx.x * 16;
+  const f64x4 acc = tile_gemm_splitk(P, Q, Cp, i0, j0, lane, wave, red);
+  if (wave) return;
+  const int li = lane & 15, kk = lane >> 4;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = i0 + kk + 4 * r, col = j0 + li;
+    const size_t at = (size_t)row * Cp + col;
+    double v = alpha * acc[r] + (row == col ? gamma : 0.0);
+    if (R) v += beta * R[at];
+    D[at] = v;
+    if (D2) D2[at] = (row == col ? 1.0 : 0.0) - v;
+  }
+}
+
+// the converged iterate into buffer 0 (the post-processing addresses fixed buffers); S1 = a E + g I
+__global__ void ns_settle_kernel(NsWs w, int Cp) {
+  if (!(*w.iters & 1)) return;
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (long)Cp * Cp) return;
+  w.Y[0][e] = w.Y[1][e];
+  w.Z[0][e] = w.Z[1][e];
+}
+__global__ void ns_axpi_kernel(const double* E, double* D, int Cp, double a, double g) {
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (long)Cp * Cp) return;
+  D[e] = a * E[e] + ((e / Cp) == (e % Cp) ? g : 0.0);
 }
 
 // ---- C <= 64: the whole coupled iteration in ONE workgroup, Y / Z / T resident in LDS (3 x 34 KB at Cp = 64).
@@ -246,7 +339,7 @@ __device__ __forceinline__ f64x4 tile_gemm_lds(const double* P, const double* Q,
 
 template <int CP>
 __global__ __launch_bounds__((CP / 16) * (CP / 16) * 64) void ns_lds_kernel(double* res, int C, int inverse, double eps_rel,
-                                                                               int maxit, int* ok_out, int* info) {
+                                                                               int maxit, double zmax, int* ok_out, int* info) {
   constexpr int LD = CP + 2, TPR = CP / 16, NW = TPR * TPR, NT = NW * 64;
   extern __shared__ __attribute__((aligned(16))) char smem_ns[];
   double* Y = reinterpret_cast<double*>(smem_ns);
@@ -314,7 +407,18 @@ __global__ __launch_bounds__((CP / 16) * (CP / 16) * 64) void ns_lds_kernel(doub
     __syncthreads();
     n = it + 1;
   }
-  const bool ok = n >= 1 && prev < NS_TOL;
+  bool ok = n >= 1 && prev < NS_TOL;
+  if (ok && inverse) {   // condition gate (NS_ZMAX)
+    double q = 0.;
+    for (int e = tid; e < CP * CP; e += NT) { const double z = Z[(e / CP) * LD + (e % CP)]; q += z * z; }
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    __syncthreads();
+    if (lane == 0) red[wave] = q;
+    __syncthreads();
+    q = 0.;
+    for (int w = 0; w < NW; ++w) q += red[w];
+    ok = q <= zmax * zmax;
+  }
   if (tid == 0) { *ok_out = ok ? 1 : 0; if (info && ok) *info = n; }
   if (!ok) return;
   const double sc = inverse ? rsqrt(s) : sqrt(s);
@@ -524,7 +628,7 @@ __global__ void colnorm_kernel(double* res, int n, const int* fl, int* info) {
   if (j == 0 && info) {
     int sw = 0;
     while (sw < MAX_SWEEPS && fl[sw]) ++sw;
-    *info = sw;
+    *info = 100 + sw;   // 100 + sweeps, like the LDS kernel
   }
 }
 
@@ -556,10 +660,10 @@ __global__ __launch_bounds__(256) void sym_power_kernel(double* res, int n, doub
 
 size_t eig_result_bytes(int C) { return eig_doubles(C) * sizeof(double); }
 size_t eig_result_F_offset(size_t C) { return eig_F_offset((int)C); }
-static inline int ns_pad(int C) { return (C + 31) / 32 * 32; }
+static inline int ns_pad(int C) { return C > 128 ? (C + 63) / 64 * 64 : (C + 31) / 32 * 32; }   // split-k: k quarters in steps of 16
 size_t eig_workspace_bytes(int C) {
   const size_t cp2 = (size_t)ns_pad(C) * ns_pad(C);
-  return 5 * cp2 * sizeof(double) + (size_t)C * sizeof(int) + 4 * sizeof(double) + (NS_MAXIT_REG + 2) * sizeof(unsigned long long) + 64;
+  return 5 * cp2 * sizeof(double) + (size_t)C * sizeof(int) + 4 * sizeof(double) + 2 * (NS_MAXIT_REG + 2) * sizeof(unsigned long long) + 64;
 }
 size_t assemble_workspace_bytes(int C) { return (size_t)C * C * sizeof(double); }
 
@@ -576,11 +680,14 @@ hipError_t launch_eig(int C, double n, const double* sum, const double* sumsq, i
   w.Y[0] = p; w.Y[1] = p + cp2; w.Z[0] = p + 2 * cp2; w.Z[1] = p + 3 * cp2; w.T = p + 4 * cp2;
   w.scal = p + 5 * cp2;
   w.resid = reinterpret_cast<unsigned long long*>(w.scal + 4);
-  w.iters = reinterpret_cast<int*>(w.resid + NS_MAXIT_REG + 2);
+  w.zfro = reinterpret_cast<double*>(w.resid + NS_MAXIT_REG + 2);
+  w.iters = reinterpret_cast<int*>(w.zfro + NS_MAXIT_REG + 2);
   w.ok = w.iters + 1;
   w.dead = w.iters + 2;
   const bool big = C > 128;
-  const int maxit = NS_MAXIT;
+  static const int maxit_env = [] { const char* e = getenv("WCT_NS_MAXIT"); const int v = e ? atoi(e) : 0; return v < 1 ? 0 : (v > NS_MAXIT_REG ? NS_MAXIT_REG : v); }();
+  // C > 128 (original mode): the deflated problem has cond <= 1e12, i.e. <= 41 iterations; a stage there is ~30 us
+  const int maxit = maxit_env ? maxit_env : (C > 128 ? 48 : NS_MAXIT);
   if (Cp <= 64) {
     // one workgroup, iterates in LDS (see ns_lds_kernel)
     auto go = [&](auto kern, int cp) -> hipError_t {
@@ -588,26 +695,64 @@ hipError_t launch_eig(int C, double n, const double* sum, const double* sumsq, i
       const size_t lds = (size_t)3 * cp * (cp + 2) * sizeof(double) + (size_t)(nw + 2) * sizeof(double) + (size_t)cp * sizeof(int);
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return e;
-      hipLaunchKernelGGL(kern, dim3(1), dim3((unsigned)nw * 64), lds, s, res, C, inverse, 1e-15, maxit, w.ok, info_dev);
+      hipLaunchKernelGGL(kern, dim3(1), dim3((unsigned)nw * 64), lds, s, res, C, inverse, 1e-15, maxit, NS_ZMAX, w.ok, info_dev);
       return hipSuccess;
     };
     hipError_t e = Cp == 32 ? go(ns_lds_kernel<32>, 32) : go(ns_lds_kernel<64>, 64);
     if (e != hipSuccess) return e;
   } else {
-    hipLaunchKernelGGL(ns_init_kernel, dim3(1), dim3(1024), 0, s, res, C, 1e-15, w, maxit);
+    hipLaunchKernelGGL(ns_init_kernel, dim3(1), dim3(1024), 0, s, res, C, big ? NS_DEFLATE : 1e-15, w, maxit);
     hipLaunchKernelGGL(ns_fill_kernel, dim3((unsigned)((cp2 + 255) / 256)), dim3(256), 0, s, res, C, Cp, w);
-    const dim3 g1(Cp / 32, Cp / 32, 1), g2(Cp / 32, Cp / 32, 2);
+    const int tw = big ? 16 : 32;   // C > 128: split-k kernels, one tile per workgroup
+    const dim3 g1(Cp / tw, Cp / tw, 1), g2(Cp / tw, Cp / tw, 2);
     for (int it = 0; it < maxit; ++it) {
-      hipLaunchKernelGGL(ns_stage1_kernel, g1, dim3(256), 0, s, w, Cp, it);
-      hipLaunchKernelGGL(ns_stage2_kernel, g2, dim3(256), 0, s, w, Cp, it);
+      if (big) {
+        hipLaunchKernelGGL(ns_stage1_kernel<true>, g1, dim3(256), 0, s, w, Cp, it);
+        hipLaunchKernelGGL(ns_stage2_kernel<true>, g2, dim3(256), 0, s, w, Cp, it);
+      } else {
+        hipLaunchKernelGGL(ns_stage1_kernel<false>, g1, dim3(256), 0, s, w, Cp, it);
+        hipLaunchKernelGGL(ns_stage2_kernel<false>, g2, dim3(256), 0, s, w, Cp, it);
+      }
     }
-    hipLaunchKernelGGL(ns_final_kernel, dim3((unsigned)((cc + 255) / 256)), dim3(256), 0, s, res, C, Cp, inverse, w, maxit, info_dev);
+    const double* deflated = nullptr;
+    if (big) {
+      const unsigned eb = (unsigned)((cp2 + 255) / 256);
+      const double de = NS_DEFLATE / (1.0 + NS_DEFLATE);   // delta / s in the iteration's units
+      auto gemm = [&](const double* P, const double* Q, double* D, double* D2, double alpha, const double* R, double beta, double gamma) {
+        hipLaunchKernelGGL(ns_gemm_kernel, g1, dim3(256), 0, s, P, Q, D, D2, Cp, alpha, R, beta, gamma);
+      };
+      hipLaunchKernelGGL(ns_settle_kernel, dim3(eb), dim3(256), 0, s, w, Cp);
+      const double* Rm = inverse ? w.Z[0] : w.Y[0];
+      double* E = w.Y[1];
+      double* wb[3] = {inverse ? w.Y[0] : w.Z[1], inverse ? w.Z[1] : w.T, inverse ? w.T : w.Z[0]};   // Z[0] is free once E exists
+      gemm(w.Z[0], w.Z[0], E, wb[0], de, nullptr, 0., 0.);            // E = delta Z^2, P = I - E
+      int ip = 0;
+      for (int h = 0; h < 5; ++h) {                                    // P <- 3 P^2 - 2 P^3
+        const int i2 = (ip + 1) % 3, in = (ip + 2) % 3;
+        gemm(wb[ip], wb[ip], wb[i2], nullptr, 1., nullptr, 0., 0.);
+        gemm(wb[i2], wb[ip], wb[in], nullptr, -2., wb[i2], 3., 0.);
+        ip = in;
+      }
+      double* Sa = wb[(ip + 1) % 3];
+      double* Sb = wb[(ip + 2) % 3];
+      // (1 - x)^(-1/2) = 1 + x/2 + 3x^2/8 + 5x^3/16 + 35x^4/128 + 63x^5/256 ; (1 - x)^(1/2) = 1 - x/2 - x^2/8 - x^3/16 - 5x^4/128 - 7x^5/256
+      static const double ci[6] = {1., 0.5, 3. / 8, 5. / 16, 35. / 128, 63. / 256}, cs[6] = {1., -0.5, -1. / 8, -1. / 16, -5. / 128, -7. / 256};
+      const double* cf = inverse ? ci : cs;
+      hipLaunchKernelGGL(ns_axpi_kernel, dim3(eb), dim3(256), 0, s, (const double*)E, Sa, Cp, cf[5], cf[4]);
+      for (int k = 3; k >= 0; --k) {                                   // Horner: S <- S E + c_k I
+        gemm(Sa, E, Sb, nullptr, 1., nullptr, 0., cf[k]);
+        double* t = Sa; Sa = Sb; Sb = t;
+      }
+      gemm(Rm, Sa, Sb, nullptr, 1., nullptr, 0., 0.);                 // R S
+      gemm(wb[ip], Sb, Sa, nullptr, 1., nullptr, 0., 0.);             // P R S
+      deflated = Sa;
+    }
+    hipLaunchKernelGGL(ns_final_kernel, dim3((unsigned)((cc + 255) / 256)), dim3(256), 0, s, res, C, Cp, inverse, w, maxit, NS_ZMAX, info_dev, deflated);
   }
   if (big) {
-    // C > 128 has no single-CU Jacobi.  A singular covariance (fewer pixels than channels) needs the true
-    // pseudo-inverse -- a regularised inverse would put gains of 1e6 into the folded decoder weights and lose
-    // everything to cancellation -- so the outcome of the iteration is read back (one 4-byte copy + stream sync per
-    // solve, original mode only) and the slow global-memory Jacobi (one launch per tournament round) runs only then.
+    // C > 128 has no single-CU Jacobi: the deflated iteration above covers singular and ill-conditioned covariances, and the
+    // slow global-memory Jacobi (one launch per tournament round) is the net under it -- the outcome of the iteration is read
+    // back (one 4-byte copy + stream sync per solve, original mode only) and Jacobi runs only if it did not converge.
     int ok_host = 0;
     hipError_t e = hipMemcpyAsync(&ok_host, w.ok, sizeof(int), hipMemcpyDeviceToHost, s);
     if (e != hipSuccess) return e;
@@ -617,13 +762,22 @@ hipError_t launch_eig(int C, double n, const double* sum, const double* sumsq, i
       int* flags = reinterpret_cast<int*>(w.Y[0]);  // the iteration's buffers are free now
       e = hipMemsetAsync(flags, 0, (MAX_SWEEPS + 1) * sizeof(int), s);
       if (e != hipSuccess) return e;
-      const int sweeps = 16;  // fp64 cyclic Jacobi converges quadratically; later sweeps exit at once via flags
+      // a sweep is C - 1 launches (~1.7 ms at C = 512), so the host looks at the sweep's flag before queueing the next one:
+      // well-separated spectra stop after 7-10 sweeps, graded ones spanning > 12 decades need 30+ (16 fixed sweeps used to
+      // leave those unconverged).
       const dim3 grid((unsigned)((C / 2 + 3) / 4));
-      for (int sw = 0; sw < sweeps; ++sw)
+      for (int sw = 0; sw < MAX_SWEEPS; ++sw) {
         for (int r = 0; r < C - 1; ++r)
           hipLaunchKernelGGL(jacobi_round_global_kernel, grid, dim3(256), 0, s, res, C, r, sw, flags);
+        int rotated = 0;
+        e = hipMemcpyAsync(&rotated, flags + sw, sizeof(int), hipMemcpyDeviceToHost, s);
+        if (e != hipSuccess) return e;
+        e = hipStreamSynchronize(s);
+        if (e != hipSuccess) return e;
+        if (!rotated) break;
+      }
       hipLaunchKernelGGL(colnorm_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, s, res, C, flags, info_dev);
-      hipLaunchKernelGGL(sym_power_kernel, dim3((unsigned)((cc + 255) / 256)), dim3(256), 0, s, res, C, inverse ? -0.5 : 0.5, 1e-10,
+      hipLaunchKernelGGL(sym_power_kernel, dim3((unsigned)((cc + 255) / 256)), dim3(256), 0, s, res, C, inverse ? -0.5 : 0.5, REL_THRESH,
                          (const int*)nullptr);
     }
   } else {
@@ -638,7 +792,7 @@ hipError_t launch_eig(int C, double n, const double* sum, const double* sumsq, i
     };
     hipError_t e = lpp == 16 ? go(jacobi_lds_kernel<16>, 16) : lpp == 8 ? go(jacobi_lds_kernel<8>, 8) : go(jacobi_lds_kernel<4>, 4);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(sym_power_kernel, dim3((unsigned)((cc + 255) / 256)), dim3(256), 0, s, res, C, inverse ? -0.5 : 0.5, 1e-10,
+    hipLaunchKernelGGL(sym_power_kernel, dim3((unsigned)((cc + 255) / 256)), dim3(256), 0, s, res, C, inverse ? -0.5 : 0.5, REL_THRESH,
                        (const int*)w.ok);
   }
   return hipGetLastError();

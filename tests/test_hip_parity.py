@@ -112,6 +112,41 @@ def test_moments_and_solve_split_form(torch_cuda, wct16, oracle, C, n):
     assert rel_err(M.cpu().numpy(), Mr) < 1e-8 and rel_err(b.cpu().numpy(), br) < 1e-8
 
 
+@pytest.mark.parametrize("C,lmin,dead,rank", [(128, 1e-8, 9, None), (128, 1e-15, 0, None), (256, 3e-11, 69, None), (512, 1e-9, 0, None),
+                                              (512, 1e-7, 7, 100), (256, 1e-6, 0, 255), (512, 1e-5, 0, 15)])
+def test_solve_ill_conditioned_and_singular(torch_cuda, wct16, oracle, C, lmin, dead, rank):
+    """Covariances with a prescribed spectrum: 1 .. lmin log-uniform over `rank` directions (None: all live ones), exact zeros
+    beyond, plus exactly-dead channels.  The reference keeps every singular value >= 1e-100 (util_wct.py:25,82-86): a GENUINE
+    direction 1e-11 below the top one is whitened like any other (--mode original on generated weights has them;
+    tools/experiments/original_parity.py), while the null space of a singular covariance meets exactly-zero centred
+    components, i.e. is dropped.  C <= 128: Newton-Schulz or the LDS Jacobi; C > 128: the deflated iteration."""
+    rng = np.random.default_rng(C + dead)
+    live = C - dead
+    def spd(lo, scale, k):
+        Q, _ = np.linalg.qr(rng.standard_normal((live, live)))
+        lam = np.zeros(live)
+        lam[:k] = scale * np.exp(np.linspace(0.0, np.log(lo), k))
+        A = np.zeros((C, C))
+        idx = np.sort(rng.permutation(C)[:live])
+        A[np.ix_(idx, idx)] = (Q * lam) @ Q.T
+        return (A + A.T) / 2
+    cov_c, cov_s = spd(lmin, 40.0, rank or live), spd(1e-6, 3.0, live)
+    mu_c, mu_s = rng.random(C) * (cov_c.diagonal() > 0), rng.random(C) * (cov_s.diagonal() > 0)
+    dev = lambda a: torch_cuda.from_numpy(np.ascontiguousarray(a, np.float64)).cuda()
+    raw = lambda n, mu, cov: (n, dev(n * mu), dev((n - 1) * cov + n * np.outer(mu, mu)))
+    M, b, info = wct16.solve(*raw(50000.0, mu_c, cov_c), *raw(20000.0, mu_s, cov_s), alpha=1.0, want_info=True)
+    Mr, br = oracle.affine_from_moments(mu_c, cov_c, mu_s, cov_s, 1.0)
+    if lmin > 1e-12 and rank is None:
+        # nothing is at the round-off level: the policy keeps everything, as the reference does (SVD + 1e-100)
+        Mk, _ = oracle.affine_from_moments(mu_c, cov_c, mu_s, cov_s, 1.0, rel_thresh=1e-14, abs_floor=1e-16)
+        assert rel_err(Mk, Mr) < 1e-9
+    if C > 128:
+        assert 0 < info[0] < 60, info      # GEMMs only: the global-memory Jacobi (100 + sweeps) costs 27..68 ms per matrix
+    # |M| ~ lmin^-1/2; the error is ~10 cond eps relative to the largest entry
+    tol = 3e-4 if lmin < 1e-10 else 1e-6
+    assert rel_err(M.cpu().numpy(), Mr) < tol and rel_err(b.cpu().numpy(), br) < tol, (info, rel_err(M.cpu().numpy(), Mr))
+
+
 # --------------------------------------------------------------------------- G4 cascade
 @pytest.mark.parametrize("tag", ["a", "b"])
 def test_g4_cascade(torch_cuda, wct16, golden, tag):
