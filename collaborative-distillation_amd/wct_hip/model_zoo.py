@@ -121,6 +121,45 @@ def load_npz_weights(path: str) -> Dict[str, np.ndarray]:
         return {k: np.ascontiguousarray(z[k], dtype=np.float32) for k in z.files}
 
 
+def t7_indices(kind: str, level: int) -> List[int]:
+    """`model.get(i)` indices the reference reads a `--mode original` module's convolutions from, in forward order
+    (model_original.py:27-28, 59, 92-95, 135-137, 179-184, 232-236, 288-297, 360-368, 471-484, 561-573).
+    Encoders are conv0, then [pad, conv, relu] triples with a pool entry after conv12/22/34/44; decoders are
+    [pad, conv, relu] triples with an unpool entry after conv51/41/31/21."""
+    idx: List[int] = []
+    if kind == "enc":
+        idx.append(0)
+        at = 1
+        for l in encoder_layers("original", level):
+            idx.append(at + 1)               # pad at `at`, conv at `at + 1`, relu at `at + 2`
+            at += 3 + (1 if l.pool_after else 0)
+    else:
+        at = 0
+        for l in decoder_layers("original", level):
+            idx.append(at + 1)
+            at += 3 + (1 if l.up_after else 0)
+    return idx
+
+
+def load_t7_module(path: str, kind: str, level: int) -> Dict[str, np.ndarray]:
+    """One `--mode original` module from its torch7 file: {"conv0.weight", "conv0.bias", "conv11.weight", ...} like the
+    state_dict of the same module (what `load_param_from_t7`, utils.py:64-67, copies into the nn.Module)."""
+    from . import t7
+    convs = t7.sequential_convs(t7.load(path))
+    layers = encoder_layers("original", level) if kind == "enc" else decoder_layers("original", level)
+    names = (["conv0"] if kind == "enc" else []) + [l.name for l in layers]
+    shapes = ([(3, 3, 1, 1)] if kind == "enc" else []) + [(l.cout, l.cin, 3, 3) for l in layers]
+    want = t7_indices(kind, level)
+    if [c[0] for c in convs] != want:
+        raise ValueError("%s: convolutions at Sequential indices %s, the reference reads %s (%s level %d)" % (path, [c[0] for c in convs], want, kind, level))
+    out: Dict[str, np.ndarray] = {}
+    for (i, w, b), name, shape in zip(convs, names, shapes):
+        if w.shape != shape:
+            raise ValueError("%s: module %d (%s) has weight %s, expected %s" % (path, i, name, w.shape, shape))
+        out[name + ".weight"], out[name + ".bias"] = w, b
+    return out
+
+
 #: fixed conv0 of the un-pruned encoders: RGB[0,1] -> BGR*255 - mean  (model_original.py:428-433)
 ORIGINAL_CONV0_W = np.array([[0, 0, 255], [0, 255, 0], [255, 0, 0]], np.float32).reshape(3, 3, 1, 1)
 ORIGINAL_CONV0_B = np.array([-103.939, -116.779, -123.68], np.float32)

@@ -99,10 +99,15 @@ class WCT:
         paths = {("e%d" % k): getattr(args, "e%d" % k, None) for k in range(1, 6)}
         paths.update({("d%d" % k): getattr(args, "d%d" % k, None) for k in range(1, 6)})
         have = [p for p in paths.values() if p and os.path.exists(p)]
-        if len(have) == 10 and all(p.endswith(".pth") for p in have):
+        # per module: ".t7" (torch7, --mode original: model_original.py:24-30) or ".pth" (state_dict), as the reference asserts
+        if len(have) == 10 and all(p.endswith(".pth") or (p.endswith(".t7") and mode == "original") for p in have):
             w = {}
             for key, p in paths.items():
-                for n, v in _load_state(p).items():
+                if p.endswith(".t7"):
+                    state = model_zoo.load_t7_module(p, "enc" if key[0] == "e" else "dec", int(key[1]))
+                else:
+                    state = _load_state(p)
+                for n, v in state.items():
                     if "aux" not in n:  # conv{k}1_aux heads are training-only (model_cd.py:700-704)
                         w["%s.%s" % (key, n)] = v
             return w
@@ -111,8 +116,9 @@ class WCT:
         if mode == "16x_kd2sd":
             raise FileNotFoundError("mode '16x_kd2sd' needs trained_models/wct_se_16x_new_sd_kd2sd/{1..5}SD.pth (WCT.py:60-70; "
                                     "not in the reference snapshot) -- pass the .pth paths in args.d1..d5 or weights=...")
-        raise FileNotFoundError("mode 'original' needs the torch7 checkpoints of README.md:26 (not in the reference "
-                                "snapshot; load_lua is gone from torch>=1.0) -- pass weights=... instead")
+        raise FileNotFoundError("mode 'original' needs the torch7 checkpoints of README.md:26 in args.e1..e5 / args.d1..d5 "
+                                "(trained_models/original_wct_models/*.t7, not in the reference snapshot; read by wct_hip/t7.py) "
+                                "-- or pass weights=...")
 
     def _load_modules(self, w: Dict[str, np.ndarray]):
         self._keep = []  # host arrays must outlive wct_load_module only, but keep them for clarity

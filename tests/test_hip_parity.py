@@ -527,3 +527,22 @@ def test_strip_halos_exact_per_level(torch_cuda, wct16):
             a, e = max(0, own[0] - v), min(Wn, own[1] + v)
             assert torch.equal(o[..., a - lo:e - lo], full[..., a:e]), (L, own)
         assert tot == nc
+
+
+def test_original_mode_from_t7_checkpoints(torch_cuda, tmp_path):
+    """`--mode original` as the reference starts it: ten torch7 files in args.e1..d5 (WCT.py:36-46) -> the same device state as
+    handing the arrays over directly."""
+    from tests.test_t7 import write_module
+    from wct_hip import WCT
+    w = model_zoo.synth_weights("original", 5)
+    args = types.SimpleNamespace(mode="original", alpha=0.7)
+    for k in range(1, 6):
+        for kind, key in (("enc", "e%d" % k), ("dec", "d%d" % k)):
+            path = str(tmp_path / (key + ".t7"))
+            write_module(path, kind, k, w, key, mm=(k == 2))
+            setattr(args, key, path)
+    a, b = WCT(args), WCT(types.SimpleNamespace(mode="original", alpha=0.7), weights=w)
+    g = torch_cuda.Generator(device="cuda").manual_seed(1)
+    c, s = torch_cuda.rand((1, 3, 96, 80), device="cuda", generator=g), torch_cuda.rand((1, 3, 64, 112), device="cuda", generator=g)
+    ya, yb = a.stylize(c, s), b.stylize(c, s)
+    assert torch_cuda.isfinite(ya).all() and torch_cuda.equal(ya, yb)

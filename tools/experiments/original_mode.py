@@ -17,5 +17,5 @@ torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / 3
 print("original mode 1920x1080: %.1f ms/step  %.1f MP/s  out %s finite=%s range [%.3f, %.3f]" % (dt * 1e3, 1920 * 1080 / 1e6 / dt, tuple(out.shape), bool(torch.isfinite(out).all()), out.min().item(), out.max().item()))
 wct.set_overlap(False); wct.profile_reset(); wct.profile(True); wct.stylize(c, s); torch.cuda.synchronize(); wct.profile(False)
-for e in sorted(wct.profile_read(), key=lambda e: -e["ms"])[:12]:
+for e in sorted(wct.profile_read(), key=lambda e: -e["ms"])[:30]:
     print("  %-34s %8.3f ms  %3d launches  %s" % (e["name"], e["ms"], e["launches"], ("%.0f TF" % (e["flops"] / e["ms"] / 1e9)) if e["flops"] else ""))
