@@ -126,18 +126,37 @@ struct NsWs {           // carved from the eig workspace
 
 __global__ __launch_bounds__(1024) void ns_init_kernel(const double* res, int C, double eps_rel, NsWs w, int maxit) {
   __shared__ double red[1024];
+  __shared__ int sdead[512];
   const int tid = threadIdx.x;
   const double floor_ = res[(size_t)C * C + 2 * C];
-  for (int j = tid; j < C; j += 1024) w.dead[j] = !(res[(size_t)j * C + j] > floor_);
+  for (int j = tid; j < C; j += 1024) { const int d = !(res[(size_t)j * C + j] > floor_); w.dead[j] = d; sdead[j] = d; }
   for (int k = tid; k <= maxit; k += 1024) { w.resid[k] = 0ull; w.zfro[k] = 0.; }  // atomic targets; a skipped iteration leaves resid 0 = "converged"
   if (tid == 0) { *w.iters = 0; *w.ok = 0; }
   __syncthreads();
-  double s = 0.;
-  for (long e = tid; e < (long)C * C; e += 1024) {
-    const int r = (int)(e / C), c = (int)(e % C);
-    if (!w.dead[r] && !w.dead[c]) s += res[e] * res[e];
+  // ||A_live||_F by ONE workgroup (a fixed summation order: the scale must not depend on scheduling); rows in turn, the
+  // row's columns across the threads, 4 independent rows in flight (the first version -- one element per thread per trip,
+  // flags from global memory -- took 214 us at C = 512)
+  double s0 = 0., s1 = 0., s2 = 0., s3 = 0.;
+  {
+    const int nrg = 1024 / C > 0 ? 1024 / C : 1;   // row groups in parallel (C = 512: 2)
+    const int grp = tid / C, c = tid - grp * C;
+    const bool live_c = grp < nrg && !sdead[c];
+#pragma unroll 2
+    for (int r = 4 * grp; r < C; r += 4 * nrg) {
+      double v0 = 0., v1 = 0., v2 = 0., v3 = 0.;
+      if (live_c) {
+        v0 = res[(size_t)r * C + c];
+        if (r + 1 < C) v1 = res[(size_t)(r + 1) * C + c];
+        if (r + 2 < C) v2 = res[(size_t)(r + 2) * C + c];
+        if (r + 3 < C) v3 = res[(size_t)(r + 3) * C + c];
+      }
+      if (!sdead[r]) s0 += v0 * v0;
+      if (r + 1 < C && !sdead[r + 1]) s1 += v1 * v1;
+      if (r + 2 < C && !sdead[r + 2]) s2 += v2 * v2;
+      if (r + 3 < C && !sdead[r + 3]) s3 += v3 * v3;
+    }
   }
-  red[tid] = s;
+  red[tid] = (s0 + s1) + (s2 + s3);
   __syncthreads();
   for (int o = 512; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
   if (tid == 0) {
@@ -161,13 +180,12 @@ __global__ void ns_fill_kernel(const double* res, int C, int Cp, NsWs w) {
 // one 16x16 output tile per wave, 2x2 tiles per workgroup: D = P Q with the TRUE row-major operands.  (Reading P
 // transposed because "every iterate is symmetric" is tempting -- both operands would be coalesced -- but it makes the
 // iteration unstable: the antisymmetric part of the round-off is amplified and it diverges for cond >~ 3e3.)
-__device__ __forceinline__ f64x4 tile_gemm(const double* P, const double* Q, int Cp, int i0, int j0, int lane, int kbeg = 0, int kend = -1) {
+__device__ __forceinline__ f64x4 tile_gemm(const double* P, const double* Q, int Cp, int i0, int j0, int lane) {
   const int li = lane & 15, kk = lane >> 4;
   f64x4 acc = f64x4{0., 0., 0., 0.};
   const double* pp = P + (size_t)(i0 + li) * Cp + kk;
   const double* qq = Q + (size_t)kk * Cp + j0 + li;
-  if (kend < 0) kend = Cp;
-  for (int k0 = kbeg; k0 < kend; k0 += 16) {
+  for (int k0 = 0; k0 < Cp; k0 += 16) {
     double a[4], b[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) { a[u] = pp[k0 + 4 * u]; b[u] = qq[(size_t)(k0 + 4 * u) * Cp]; }
@@ -177,38 +195,17 @@ __device__ __forceinline__ f64x4 tile_gemm(const double* P, const double* Q, int
   return acc;  // row = kk + 4 * reg, col = li
 }
 
-// Cp >= 256: one 16x16 tile per WORKGROUP, the k range split over its 4 waves and summed through LDS in a fixed order --
-// the k loop of a whole-tile wave is a chain of Cp/16 dependent load batches (~30 us per launch at Cp = 512, against 3.4 us
-// of fp64 MFMA work), a quarter of it with 4x the workgroups hides that latency.  Returns the tile in wave 0 only.
-__device__ __forceinline__ f64x4 tile_gemm_splitk(const double* P, const double* Q, int Cp, int i0, int j0, int lane, int wave, double (*red)[256]) {
-  const int kq = Cp >> 2;
-  f64x4 acc = tile_gemm(P, Q, Cp, i0, j0, lane, wave * kq, (wave + 1) * kq);
-  if (wave) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) red[wave - 1][r * 64 + lane] = acc[r];
-  }
-  __syncthreads();
-  if (!wave) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) acc[r] = ((acc[r] + red[0][r * 64 + lane]) + red[1][r * 64 + lane]) + red[2][r * 64 + lane];
-  }
-  return acc;
-}
-
 __device__ __forceinline__ bool ns_converged(const NsWs& w, int it) {
   return it > 0 && __longlong_as_double((long long)w.resid[it - 1]) < NS_TOL;
 }
 
-// stage 1 of iteration `it`: T = 1.5 I - 0.5 Z Y ; resid[it] = max |Z Y - I|
-template <bool SPLITK>
-__global__ __launch_bounds__(256) void ns_stage1_kernel(NsWs w, int Cp, int it) {
+// stage 1 of iteration `it`: T = ca I - cb Z Y (plain iteration: 1.5, 0.5; scaled: 1.5 mu, 0.5 mu^3) ; resid[it] = max |Z Y - I|
+__global__ __launch_bounds__(256) void ns_stage1_kernel(NsWs w, int Cp, int it, double ca, double cb) {
   if (ns_converged(w, it)) return;
-  __shared__ double red[SPLITK ? 3 : 1][256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int i0 = SPLITK ? blockIdx.y * 16 : blockIdx.y * 32 + (wave >> 1) * 16, j0 = SPLITK ? blockIdx.x * 16 : blockIdx.x * 32 + (wave & 1) * 16;
+  const int i0 = blockIdx.y * 32 + (wave >> 1) * 16, j0 = blockIdx.x * 32 + (wave & 1) * 16;
   const int cur = it & 1;
-  const f64x4 acc = SPLITK ? tile_gemm_splitk(w.Z[cur], w.Y[cur], Cp, i0, j0, lane, wave, red) : tile_gemm(w.Z[cur], w.Y[cur], Cp, i0, j0, lane);
-  if (SPLITK && wave) return;
+  const f64x4 acc = tile_gemm(w.Z[cur], w.Y[cur], Cp, i0, j0, lane);
   const int li = lane & 15, kk = lane >> 4;
   double m = 0.;
 #pragma unroll
@@ -216,25 +213,20 @@ __global__ __launch_bounds__(256) void ns_stage1_kernel(NsWs w, int Cp, int it) 
     const int row = i0 + kk + 4 * r, col = j0 + li;
     const double zy = acc[r], d = zy - (row == col ? 1.0 : 0.0);
     m = (d == d) ? fmax(m, fabs(d)) : __longlong_as_double(0x7ff0000000000000ll);  // fmax would swallow a NaN
-    w.T[(size_t)row * Cp + col] = (row == col ? 1.5 : 0.0) - 0.5 * zy;
+    w.T[(size_t)row * Cp + col] = (row == col ? ca : 0.0) - cb * zy;
   }
   for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o));
   if (lane == 0) atomicMax(&w.resid[it], (unsigned long long)__double_as_longlong(m));
 }
 
 // stage 2: Y' = Y T (blockIdx.z = 0), Z' = T Z (blockIdx.z = 1), into the other ping-pong buffer
-template <bool SPLITK>
 __global__ __launch_bounds__(256) void ns_stage2_kernel(NsWs w, int Cp, int it) {
   if (ns_converged(w, it)) return;
-  __shared__ double red[SPLITK ? 3 : 1][256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int i0 = SPLITK ? blockIdx.y * 16 : blockIdx.y * 32 + (wave >> 1) * 16, j0 = SPLITK ? blockIdx.x * 16 : blockIdx.x * 32 + (wave & 1) * 16;
+  const int i0 = blockIdx.y * 32 + (wave >> 1) * 16, j0 = blockIdx.x * 32 + (wave & 1) * 16;
   const int cur = it & 1, nxt = cur ^ 1;
   const bool zside = blockIdx.z == 1;
-  const double* Pm = zside ? w.T : w.Y[cur];
-  const double* Qm = zside ? w.Z[cur] : w.T;
-  const f64x4 acc = SPLITK ? tile_gemm_splitk(Pm, Qm, Cp, i0, j0, lane, wave, red) : tile_gemm(Pm, Qm, Cp, i0, j0, lane);
-  if (SPLITK && wave) return;
+  const f64x4 acc = zside ? tile_gemm(w.T, w.Z[cur], Cp, i0, j0, lane) : tile_gemm(w.Y[cur], w.T, Cp, i0, j0, lane);
   double* out = zside ? w.Z[nxt] : w.Y[nxt];
   const int li = lane & 15, kk = lane >> 4;
 #pragma unroll
@@ -244,7 +236,99 @@ __global__ __launch_bounds__(256) void ns_stage2_kernel(NsWs w, int Cp, int it) 
     for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
     if (lane == 0) atomicAdd(&w.zfro[it + 1], q);
   }
-  if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) *w.iters = it + 1;   // wave 0 in either flavour
+  if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) *w.iters = it + 1;
+}
+
+// ---- C > 128 (Cp = 256, 512): one 32x32 output tile per WORKGROUP, the k range split over its 4 waves and summed through LDS
+//      in a fixed order.  A whole-k wave per 16x16 tile is a chain of Cp/16 dependent load batches with one 8-byte operand
+//      load per lane per MFMA (~30 us per launch at Cp = 512, against 3.4 us of fp64 MFMA work); here a wave holds 2x2 MFMA
+//      tiles (half the operand bytes per MFMA) over a quarter of k, and lane group kk owns k = k0 + 4 kk + u of a 16-block, so
+//      its four P values are 32 contiguous bytes (two 16-byte loads; the wave reads whole 128-byte lines of 16 rows instead
+//      of 32 bytes out of each).  The k order differs from tile_gemm's -- both are "true row-major operands".
+struct Acc32 { f64x4 t[4]; };   // MFMA tile (ri, cj) at t[2 ri + cj]: rows i0 + 16 ri + kk + 4 reg, cols j0 + 16 cj + li
+
+__device__ __forceinline__ void gemm32_splitk(const double* P, const double* Q, int Cp, int i0, int j0, int lane, int wave,
+                                               double (*red)[16 * 64], Acc32& acc) {
+  const int li = lane & 15, kk = lane >> 4;
+  const int kq = Cp >> 2, kbeg = wave * kq, kend = kbeg + kq;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc.t[t] = f64x4{0., 0., 0., 0.};
+  const double* p0 = P + (size_t)(i0 + li) * Cp + 4 * kk;
+  const double* p1 = p0 + (size_t)16 * Cp;
+  const double* q0 = Q + (size_t)(4 * kk) * Cp + j0 + li;
+#pragma unroll 2
+  for (int k0 = kbeg; k0 < kend; k0 += 16) {
+    const f64x2 a0l = *reinterpret_cast<const f64x2*>(p0 + k0), a0h = *reinterpret_cast<const f64x2*>(p0 + k0 + 2);
+    const f64x2 a1l = *reinterpret_cast<const f64x2*>(p1 + k0), a1h = *reinterpret_cast<const f64x2*>(p1 + k0 + 2);
+    double b0[4], b1[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { b0[u] = q0[(size_t)(k0 + u) * Cp]; b1[u] = q0[(size_t)(k0 + u) * Cp + 16]; }
+    const double a0[4] = {a0l[0], a0l[1], a0h[0], a0h[1]}, a1[4] = {a1l[0], a1l[1], a1h[0], a1h[1]};
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      acc.t[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[u], b0[u], acc.t[0], 0, 0, 0);
+      acc.t[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[u], b1[u], acc.t[1], 0, 0, 0);
+      acc.t[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[u], b0[u], acc.t[2], 0, 0, 0);
+      acc.t[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[u], b1[u], acc.t[3], 0, 0, 0);
+    }
+  }
+  if (wave) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[wave - 1][(t * 4 + r) * 64 + lane] = acc.t[t][r];
+  }
+  __syncthreads();
+  if (!wave) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int at = (t * 4 + r) * 64 + lane;
+        acc.t[t][r] = ((acc.t[t][r] + red[0][at]) + red[1][at]) + red[2][at];
+      }
+  }
+}
+
+__global__ __launch_bounds__(256) void ns_stage1_wide_kernel(NsWs w, int Cp, int it, double ca, double cb) {
+  if (ns_converged(w, it)) return;
+  __shared__ double red[3][16 * 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i0 = blockIdx.y * 32, j0 = blockIdx.x * 32, cur = it & 1;
+  Acc32 acc;
+  gemm32_splitk(w.Z[cur], w.Y[cur], Cp, i0, j0, lane, wave, red, acc);
+  if (wave) return;
+  const int li = lane & 15, kk = lane >> 4;
+  double m = 0.;
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = i0 + 16 * (t >> 1) + kk + 4 * r, col = j0 + 16 * (t & 1) + li;
+      const double zy = acc.t[t][r], d = zy - (row == col ? 1.0 : 0.0);
+      m = (d == d) ? fmax(m, fabs(d)) : __longlong_as_double(0x7ff0000000000000ll);
+      w.T[(size_t)row * Cp + col] = (row == col ? ca : 0.0) - cb * zy;
+    }
+  for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o));
+  if (lane == 0) atomicMax(&w.resid[it], (unsigned long long)__double_as_longlong(m));
+}
+
+__global__ __launch_bounds__(256) void ns_stage2_wide_kernel(NsWs w, int Cp, int it) {
+  if (ns_converged(w, it)) return;
+  __shared__ double red[3][16 * 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i0 = blockIdx.y * 32, j0 = blockIdx.x * 32, cur = it & 1, nxt = cur ^ 1;
+  const bool zside = blockIdx.z == 1;
+  Acc32 acc;
+  gemm32_splitk(zside ? w.T : w.Y[cur], zside ? w.Z[cur] : w.T, Cp, i0, j0, lane, wave, red, acc);
+  if (wave) return;
+  double* out = zside ? w.Z[nxt] : w.Y[nxt];
+  const int li = lane & 15, kk = lane >> 4;
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) out[(size_t)(i0 + 16 * (t >> 1) + kk + 4 * r) * Cp + j0 + 16 * (t & 1) + li] = acc.t[t][r];
+  if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) *w.iters = it + 1;
 }
 
 // F = Z / sqrt(s) (inverse) or Y * sqrt(s), dead rows/cols zeroed; ok = converged
@@ -283,21 +367,24 @@ constexpr double NS_DEFLATE = 1e-12;
 // D = alpha P Q + beta R + gamma I ; optionally D2 = I - D
 __global__ __launch_bounds__(256) void ns_gemm_kernel(const double* P, const double* Q, double* D, double* D2, int Cp, double alpha,
                                                        const double* R, double beta, double gamma) {
-  __shared__ double red[3][256];
+  __shared__ double red[3][16 * 64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int i0 = blockIdx.y * 16, j0 = blockIdx.x * 16;
-  const f64x4 acc = tile_gemm_splitk(P, Q, Cp, i0, j0, lane, wave, red);
+  const int i0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
+  Acc32 acc;
+  gemm32_splitk(P, Q, Cp, i0, j0, lane, wave, red, acc);
   if (wave) return;
   const int li = lane & 15, kk = lane >> 4;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int row = i0 + kk + 4 * r, col = j0 + li;
-    const size_t at = (size_t)row * Cp + col;
-    double v = alpha * acc[r] + (row == col ? gamma : 0.0);
-    if (R) v += beta * R[at];
-    D[at] = v;
-    if (D2) D2[at] = (row == col ? 1.0 : 0.0) - v;
-  }
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = i0 + 16 * (t >> 1) + kk + 4 * r, col = j0 + 16 * (t & 1) + li;
+      const size_t at = (size_t)row * Cp + col;
+      double v = alpha * acc.t[t][r] + (row == col ? gamma : 0.0);
+      if (R) v += beta * R[at];
+      D[at] = v;
+      if (D2) D2[at] = (row == col ? 1.0 : 0.0) - v;
+    }
 }
 
 // the converged iterate into buffer 0 (the post-processing addresses fixed buffers); S1 = a E + g I
@@ -668,7 +755,7 @@ size_t eig_workspace_bytes(int C) {
 size_t assemble_workspace_bytes(int C) { return (size_t)C * C * sizeof(double); }
 
 hipError_t launch_eig(int C, double n, const double* sum, const double* sumsq, int inverse, double* res, int* info_dev,
-                      void* ws, size_t ws_bytes, hipStream_t s, double diag_add) {
+                      void* ws, size_t ws_bytes, hipStream_t s, double diag_add, bool wide_model) {
   if (C < 2 || (C & 1) || C > 512 || n < 2) return hipErrorInvalidValue;  // unbiased covariance needs n >= 2
   if (ws_bytes < eig_workspace_bytes(C)) return hipErrorOutOfMemory;
   const size_t cc = (size_t)C * C;
@@ -684,10 +771,10 @@ hipError_t launch_eig(int C, double n, const double* sum, const double* sumsq, i
   w.iters = reinterpret_cast<int*>(w.zfro + NS_MAXIT_REG + 2);
   w.ok = w.iters + 1;
   w.dead = w.iters + 2;
-  const bool big = C > 128;
+  const bool big = C > 128 || (wide_model && C > 64 && ns_pad(C) % 64 == 0);   // deflated, scaled iteration + host check of the outcome
   static const int maxit_env = [] { const char* e = getenv("WCT_NS_MAXIT"); const int v = e ? atoi(e) : 0; return v < 1 ? 0 : (v > NS_MAXIT_REG ? NS_MAXIT_REG : v); }();
-  // C > 128 (original mode): the deflated problem has cond <= 1e12, i.e. <= 41 iterations; a stage there is ~30 us
-  const int maxit = maxit_env ? maxit_env : (C > 128 ? 48 : NS_MAXIT);
+  // C > 128 (original mode): the deflated, optimally scaled iteration takes 19-20 iterations whatever the matrix
+  const int maxit = maxit_env ? maxit_env : (C > 128 ? 24 : NS_MAXIT);
   if (Cp <= 64) {
     // one workgroup, iterates in LDS (see ns_lds_kernel)
     auto go = [&](auto kern, int cp) -> hipError_t {
@@ -703,15 +790,22 @@ hipError_t launch_eig(int C, double n, const double* sum, const double* sumsq, i
   } else {
     hipLaunchKernelGGL(ns_init_kernel, dim3(1), dim3(1024), 0, s, res, C, big ? NS_DEFLATE : 1e-15, w, maxit);
     hipLaunchKernelGGL(ns_fill_kernel, dim3((unsigned)((cp2 + 255) / 256)), dim3(256), 0, s, res, C, Cp, w);
-    const int tw = big ? 16 : 32;   // C > 128: split-k kernels, one tile per workgroup
-    const dim3 g1(Cp / tw, Cp / tw, 1), g2(Cp / tw, Cp / tw, 2);
+    const dim3 g1(Cp / 32, Cp / 32, 1), g2(Cp / 32, Cp / 32, 2);
+    // Deflated problem: every eigenvalue of Z Y = B/s starts in [l0, 1] with l0 = delta/s KNOWN, so the iteration can be
+    // scaled optimally (T = mu (3I - mu^2 Z Y)/2 with mu^2 = 3/(1 + x + x^2), x = sqrt of the current lower bound: the cubic
+    // then maps both ends of [x, 1] to the same value) -- small eigenvalues grow 6.75x per step instead of 2.25x and the
+    // whole spectrum arrives together: 19 iterations for ANY matrix instead of 15 (cond 1e3) .. 39 (singular).  The schedule
+    // depends on l0 alone, so it is computed here; numpy prototype: same accuracy as the plain iteration.
+    double xlow = big ? sqrt(NS_DEFLATE / (1.0 + NS_DEFLATE)) : 1.0;
     for (int it = 0; it < maxit; ++it) {
       if (big) {
-        hipLaunchKernelGGL(ns_stage1_kernel<true>, g1, dim3(256), 0, s, w, Cp, it);
-        hipLaunchKernelGGL(ns_stage2_kernel<true>, g2, dim3(256), 0, s, w, Cp, it);
+        const double mu = xlow <= 0.9 ? sqrt(3.0 / (1.0 + xlow + xlow * xlow)) : 1.0;
+        xlow = mu * xlow * (3.0 - mu * mu * xlow * xlow) / 2.0;
+        hipLaunchKernelGGL(ns_stage1_wide_kernel, g1, dim3(256), 0, s, w, Cp, it, 1.5 * mu, 0.5 * mu * mu * mu);
+        hipLaunchKernelGGL(ns_stage2_wide_kernel, g2, dim3(256), 0, s, w, Cp, it);
       } else {
-        hipLaunchKernelGGL(ns_stage1_kernel<false>, g1, dim3(256), 0, s, w, Cp, it);
-        hipLaunchKernelGGL(ns_stage2_kernel<false>, g2, dim3(256), 0, s, w, Cp, it);
+        hipLaunchKernelGGL(ns_stage1_kernel, g1, dim3(256), 0, s, w, Cp, it, 1.5, 0.5);
+        hipLaunchKernelGGL(ns_stage2_kernel, g2, dim3(256), 0, s, w, Cp, it);
       }
     }
     const double* deflated = nullptr;

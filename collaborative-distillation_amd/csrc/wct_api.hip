@@ -66,6 +66,7 @@ struct wct_ctx {
   DevBuf l1img;       // level 1 fused: copy of the content image between wct_content_encode and wct_content_decode
   int cur_H = 0, cur_W = 0;
   int numpy_variant = 0;  // 1: `--numpy` semantics (util_wct.py:143): + I on the CONTENT covariance
+  bool wide_model = false;  // a loaded encoder ends wider than 128 channels (--mode original): see launch_eig
   int l1fuse = 1;     // 1: level 1 of the 16x cascade without materialising relu1_1 (level1.hip)
   int sp = 1;         // 1: intermediate activations of the f16x3 path in SP16 (split at the producer, DMA-staged consumers)
   int fuse = 1;       // 1: fused conv11+conv12+pool / conv12+conv11 kernels at the full-resolution ends of the 16x networks
@@ -448,7 +449,7 @@ int eig_impl(wct_ctx* ctx, Lane& ln, int C, double n, const double* sum, const d
   if (int rc = ensure(ctx, ln.wsEig, eig_workspace_bytes(C))) return rc;
   ProfScope ps(ctx, ln.stream, inverse ? "matfun_invsqrt" : "matfun_sqrt", 0, 0);
   HIPCHK(ctx, launch_eig(C, n, sum, sumsq, inverse, reinterpret_cast<double*>(res.p), info_dev, ln.wsEig.p, ln.wsEig.cap, ln.stream,
-                         (inverse && ctx->numpy_variant) ? 1.0 : 0.0));
+                         (inverse && ctx->numpy_variant) ? 1.0 : 0.0, ctx->wide_model));
   return WCT_OK;
 }
 
@@ -690,6 +691,7 @@ int wct_load_module(wct_ctx* ctx, int kind, int level, int n_layers, const wct_l
     const bool out3 = kind == WCT_KIND_DEC && i == n_layers - 1;
     ld.pool_after = L.pool_after; ld.up_after = L.up_after;
     ld.d.cin = L.cin; ld.d.cout = L.cout;
+    if (kind == WCT_KIND_ENC && i == n_layers - 1 && L.cout > 128) ctx->wide_model = true;
     ld.d.cin_chunks = in3 ? 1 : (L.cin + 15) / 16;
     ld.d.cout_pad = pad_cout(L.cout);
     ld.d.flags = (in3 ? CONV_IN_NCHW3 : 0) | (out3 ? CONV_OUT_NCHW3 : 0) | (L.pool_after ? CONV_POOL_OUT : 0) |

@@ -83,8 +83,10 @@ size_t eig_result_F_offset(size_t C);   // doubles: where F = cov^(+-1/2) starts
 size_t eig_workspace_bytes(int C);
 size_t assemble_workspace_bytes(int C);
 //   diag_add is added to the covariance's diagonal (1.0 on the content side = the reference's `--numpy` variant)
+//   wide_model: the module set has feature maps wider than 128 channels (--mode original); its 128-channel level then takes the
+//   deflated iteration too (ill-conditioned there: the 26-iteration budget ran out and the 2 ms LDS Jacobi took over)
 hipError_t launch_eig(int C, double n, const double* sum, const double* sumsq, int inverse, double* res, int* info_dev,
-                      void* workspace, size_t workspace_bytes, hipStream_t s, double diag_add = 0.0);
+                      void* workspace, size_t workspace_bytes, hipStream_t s, double diag_add = 0.0, bool wide_model = false);
 hipError_t launch_assemble(int C, const double* eig_c, const double* eig_s, double alpha, double rel_thresh,
                            double* M, double* b, void* workspace, size_t workspace_bytes, hipStream_t s);
 
