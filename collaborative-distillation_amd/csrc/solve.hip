@@ -328,6 +328,13 @@ __global__ __launch_bounds__(256) void ns_stage2_wide_kernel(NsWs w, int Cp, int
   for (int t = 0; t < 4; ++t)
 #pragma unroll
     for (int r = 0; r < 4; ++r) out[(size_t)(i0 + 16 * (t >> 1) + kk + 4 * r) * Cp + j0 + 16 * (t & 1) + li] = acc.t[t][r];
+  if (zside) {   // ||Z'||_F^2 for the condition gate of the plain (C <= 128) iteration
+    double q = 0.;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) q += acc.t[t][0] * acc.t[t][0] + acc.t[t][1] * acc.t[t][1] + acc.t[t][2] * acc.t[t][2] + acc.t[t][3] * acc.t[t][3];
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    if (lane == 0) atomicAdd(&w.zfro[it + 1], q);
+  }
   if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) *w.iters = it + 1;
 }
 
@@ -797,11 +804,16 @@ hipError_t launch_eig(int C, double n, const double* sum, const double* sumsq, i
     // whole spectrum arrives together: 19 iterations for ANY matrix instead of 15 (cond 1e3) .. 39 (singular).  The schedule
     // depends on l0 alone, so it is computed here; numpy prototype: same accuracy as the plain iteration.
     double xlow = big ? sqrt(NS_DEFLATE / (1.0 + NS_DEFLATE)) : 1.0;
+    static const bool sk_env = [] { const char* e = getenv("WCT_NS_SPLITK"); return e ? atoi(e) != 0 : true; }();
+    const bool splitk128 = sk_env && Cp % 64 == 0;
     for (int it = 0; it < maxit; ++it) {
       if (big) {
         const double mu = xlow <= 0.9 ? sqrt(3.0 / (1.0 + xlow + xlow * xlow)) : 1.0;
         xlow = mu * xlow * (3.0 - mu * mu * xlow * xlow) / 2.0;
         hipLaunchKernelGGL(ns_stage1_wide_kernel, g1, dim3(256), 0, s, w, Cp, it, 1.5 * mu, 0.5 * mu * mu * mu);
+        hipLaunchKernelGGL(ns_stage2_wide_kernel, g2, dim3(256), 0, s, w, Cp, it);
+      } else if (splitk128) {   // Cp = 128, plain adaptive iteration on the split-k tiles (2 k-blocks per wave instead of 8)
+        hipLaunchKernelGGL(ns_stage1_wide_kernel, g1, dim3(256), 0, s, w, Cp, it, 1.5, 0.5);
         hipLaunchKernelGGL(ns_stage2_wide_kernel, g2, dim3(256), 0, s, w, Cp, it);
       } else {
         hipLaunchKernelGGL(ns_stage1_kernel, g1, dim3(256), 0, s, w, Cp, it, 1.5, 0.5);
