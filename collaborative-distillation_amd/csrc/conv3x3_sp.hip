@@ -163,26 +163,35 @@ __global__ __launch_bounds__(512) void conv3x3_sp_kernel(SpArgs a) {
   };
 
   f32x16 acc[CPW][2], pend[CPW][2];
-  // job state (uniform): virtual tile index v (this workgroup walks v, v + grid, ...), cout group, chunk
-  int v = blockIdx.x, grp = 0, ch = 0, stage = 0;
-  if (v >= ntiles) return;
-  int tile = xcd_swizzle(v, ntiles);
+  // job state (uniform).  Work units are (tile, cout group) pairs, dealt out per XCD: workgroup b runs on XCD b & 7, which
+  // owns a contiguous range of tiles (as xcd_swizzle does) and all their groups; its workgroups walk that unit list with
+  // stride grid/8, group fastest -- the groups of one tile run side by side on ONE XCD and share the activation tile in
+  // its L2.  (Units used to be whole tiles with the groups in sequence: a 135x240x512 layer -- 72 tiles x 8 groups -- kept
+  // 72 of 256 CUs busy, 135 TF instead of 400+.)
+  const int xq = ntiles >> 3, xr = ntiles & 7, xcd = blockIdx.x & 7;
+  const int tbase = xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq;
+  const int ngroups = GROUPS ? a.groups : 1;
+  const int nunits = (xq + (xcd < xr ? 1 : 0)) * ngroups, ustep = gridDim.x >> 3;
+  int v = blockIdx.x >> 3, ch = 0, stage = 0;
+  if (v >= nunits) return;
+  int grp = GROUPS ? v % ngroups : 0;
+  int tile = tbase + (GROUPS ? v / ngroups : v);
   int dma_tile = tile;          // tile the offsets in poff[] belong to
   int ptile = 0, pgrp = 0;      // tile / group whose finished accumulators wait in pend[]
   bool have_pend = false;
   tile_offsets(tile);
 #pragma unroll
-  for (int i = 0; i < SP_ACT_PER_WAVE; ++i) issue_slice(i, 0, 0, 0);
+  for (int i = 0; i < SP_ACT_PER_WAVE; ++i) issue_slice(i, 0, grp, 0);
   while (true) {
     // next job
     int nv = v, ngrp = grp, nch = ch + 1;
-    if (nch == a.cin_chunks) { nch = 0; ++ngrp; if (ngrp == a.groups) { ngrp = 0; nv = v + gridDim.x; } }
-    const bool more = nv < ntiles;
+    if (nch == a.cin_chunks) { nch = 0; nv = v + ustep; ngrp = GROUPS ? nv % ngroups : 0; }
+    const bool more = nv < nunits;
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     if (more) {
-      const int ntile = nv == v ? tile : xcd_swizzle(nv, ntiles);
+      const int ntile = nv == v ? tile : tbase + (GROUPS ? nv / ngroups : nv);
       if (ntile != dma_tile) { tile_offsets(ntile); dma_tile = ntile; }
     }
     if (ch == 0) {
@@ -248,7 +257,9 @@ template <typename K>
 hipError_t launch_sp(K k, const SpArgs& a, size_t lds, hipStream_t s, int threads) {
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  const int ntiles = a.tiles_x * a.tiles_y, grid = ntiles < num_cus() ? ntiles : num_cus();
+  // (tile, group) units per XCD queue x 8 queues, capped at one workgroup per CU; a multiple of 8 (workgroup b -> XCD b & 7)
+  const int ntiles = a.tiles_x * a.tiles_y, want = 8 * ((ntiles + 7) / 8) * a.groups, cus = num_cus() & ~7;
+  const int grid = want < cus ? want : cus;
   hipLaunchKernelGGL(k, dim3(grid), dim3(threads), lds, s, a);
   return hipGetLastError();
 }
