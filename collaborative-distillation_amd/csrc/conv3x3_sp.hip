@@ -7,8 +7,8 @@
 // staging costs no VGPRs, no VALU and no ds_write, and a 16-channel chunk can be in flight into the second LDS
 // stage while the matrix cores work on the first:
 //
-//   persistent workgroup (one per CU, 8 waves = 32 x 16 output pixels, wave w owns rows 2w, 2w+1), job list =
-//   (tile, cout group, 16-channel chunk) in that order; per job
+//   persistent workgroup (one per CU, 8 waves = 32 x 16 output pixels, wave w owns rows 2w, 2w+1); work units are
+//   (tile, cout group) pairs dealt out per XCD, a job is one 16-channel chunk of a unit; per job
 //       s_waitcnt vmcnt(0); s_barrier      -- this job's stage has landed for every wave, the other stage is free
 //       9 taps x CT x 2 x 3 MFMAs (32x32x16 f16) on this stage, and INSIDE the tap loop, a slice per tap,
 //         - the DMA of the NEXT job (also across tile boundaries: no exposed prologue)
@@ -21,8 +21,8 @@
 // LDS (16-B units): stage = act[640 pixel slots][4 pieces, XOR-swizzled] (612 halo pixels of the 34 x 18 tile)
 //                          + wgt[tap][hl][kh][COW];  2 stages + bias = 154 KB at COW = 64.
 // Every MFMA operand is one conflict-free ds_read_b128 (see sp_slot below for the activation layout).
-// 128 and more couts run as cout groups of 64 (the activation tile is re-read from L2 per group; a 128-wide weight
-// slab would not leave room for the second stage).
+// 128 and more couts run as cout groups of 64 (a 128-wide weight slab would not leave room for the second stage); the
+// groups of a tile are separate work units on the same XCD, so the activation tile is shared through that XCD's L2.
 #include "wct_common.h"
 #include "conv_f16_dev.h"
 #include <cstdlib>
