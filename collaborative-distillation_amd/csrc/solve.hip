@@ -103,7 +103,8 @@ __global__ void cov_kernel(int C, double n, const double* sum, const double* sum
 // The launch schedule is fixed (no host round trip): stage kernels of iteration k return at once when the
 // residual of iteration k-1 is already below NS_TOL.  If the budget runs out (singular or very ill-conditioned
 // matrix, e.g. fewer pixels than channels) ok stays 0 and the Jacobi path below takes over (C <= 128: one gated
-// launch; C > 128: decided on the host after reading the flag back, see launch_eig).
+// launch).  C > 128 -- and the 128-channel level of a model that has wider ones -- runs the DEFLATED, optimally scaled
+// form of the same iteration instead (below: singular matrices included, 19 iterations); only its outcome is read back.
 constexpr int NS_MAXIT = 26, NS_MAXIT_REG = 96;   // default budget; size of the residual array (WCT_NS_MAXIT may raise the budget)
 constexpr double NS_TOL = 1e-7;   // on max|ZY - I| BEFORE an update; the update squares it (quadratic convergence)
 // Condition gate of the inverse square root: Z -> (A/s)^(-1/2), so ||Z||_F >= (lambda_min/s)^(-1/2) (and <= sqrt(C) times it).

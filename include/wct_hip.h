@@ -90,7 +90,8 @@ int wct_moments(wct_ctx* ctx, const float* feat, int C, int h, int w, int x0, in
 
 /* (n, sum, sumsq) of content and style -> csF = M cF + b.  M [C*C] row-major, b [C], device f64.
  * Replaces svd / pow / diag / mm of util_wct.py:74-125 and the blend of :219.  info (HOST, may be NULL)
- * receives the Jacobi sweep counts {content, style} after an internal stream sync. */
+ * receives, after an internal stream sync, how {content, style} were solved: n < 100 = Newton-Schulz iterations
+ * (19 for the deflated iteration of C > 128), 100 + n = the Jacobi fallback ran n sweeps. */
 int wct_solve(wct_ctx* ctx, int C, double n_c, const double* sum_c, const double* sumsq_c, double n_s,
               const double* sum_s, const double* sumsq_s, double alpha, double* M, double* b, int* info);
 
