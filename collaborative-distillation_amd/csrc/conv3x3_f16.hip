@@ -209,7 +209,7 @@ __global__ __launch_bounds__(32 * TH) void conv3x3_f16_kernel(F16Args a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           float v = fmaxf(acc[c][0][4 * q + r], acc[c][1][4 * q + r]);
-          v = fmaxf(v, __shfl_xor(v, 1));
+          v = fmaxf(v, lane_xor1(v));
           v = v * inv + bias[r];
           m[r] = a.relu ? fmaxf(v, 0.f) : v;
         }
@@ -315,7 +315,7 @@ __global__ __launch_bounds__(256) void conv3x3_f16_c16_kernel(F16Args a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float v = fmaxf(acc[0][h][r], acc[1][h][r]);
-        v = fmaxf(v, __shfl_xor(v, 1));
+        v = fmaxf(v, lane_xor1(v));
         v = v * inv + bias[r];
         m[r] = a.relu ? fmaxf(v, 0.f) : v;
       }
@@ -369,6 +369,7 @@ struct HeadArgs {   // conv11 (3->16, conv0 folded) + ReLU -> conv12 (16->16) + 
   const u32x4* w12; const float* b12; float inv12;
   int H, W, tiles_x, tiles_y;
   int out_sp;
+  unsigned tx_magic;   // tile_div_magic(tiles_x)
 };
 
 // Persistent: a workgroup walks tiles v, v + grid, ...; the image window of the NEXT tile is fetched into registers
@@ -377,6 +378,14 @@ struct HeadArgs {   // conv11 (3->16, conv0 folded) + ReLU -> conv12 (16->16) + 
 //   slot s = 4 kb + kq  ->  image row dy = s >> 1, pixels 2 (s & 1) + {0, 1}, 4 channels each (RGB0)
 // so that a lane's B operand is 16 contiguous bytes of the RGB0 f16 tile (ds_read2_b64); the 4th pixel / 4th channel /
 // 4th row slots carry zero weights.  (fp32 MFMA for this layer cost 9 x 32 issue cycles per 16 pixels, this 6 x 16.)
+#ifdef WCT_HEAD_TIMING   // tools/experiments/head_timing.sh: shader-clock cycles per phase, summed over wave 0 of every workgroup
+__device__ unsigned long long g_head_t[8];
+#define HT_STAMP(i) do { if (tid == 0) { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+                         ht[i] += t_ - tl; tl = t_; __builtin_amdgcn_sched_barrier(0); } } while (0)
+#else
+#define HT_STAMP(i)
+#endif
+
 __global__ __launch_bounds__(256, 3) void enc_head_kernel(HeadArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NPP = npp(8), NPH = nph(8);
@@ -427,16 +436,31 @@ __global__ __launch_bounds__(256, 3) void enc_head_kernel(HeadArgs a) {
 
   float pxr[2][3];
   int v = blockIdx.x;
+  int ty0 = 0, tx0 = 0;            // origin of the current tile (uniform; carried from the previous trip's look-ahead)
   if (v < ntiles) {
-    head_fetch(a.img, a.H, a.W, a.tiles_x, pxr, soff, xcd_swizzle(v, ntiles), tid);
+    int tr, tc;
+    tile_rc(xcd_swizzle(v, ntiles), a.tiles_x, a.tx_magic, tr, tc);
+    ty0 = tr * 8; tx0 = tc * FTW;
+    head_fetch(a.img, a.H, a.W, pxr, soff, ty0, tx0, tid);
     head_commit(pxr, imgH, imgL, tid);
   }
+  // per-lane part of the pooled output address: pixel li >> 1 of the half-tile, channels 4 kq .. 4 kq + 3
+  const int out_lane = a.out_sp ? (li >> 1) * 64 + (kq >> 1) * 32 + (kq & 1) * 8 : ((li >> 1) * 16 + 4 * kq) * 4;
+#ifdef WCT_HEAD_TIMING
+  unsigned long long ht[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tl = __builtin_amdgcn_s_memtime();
+#endif
   for (; v < ntiles; v += gridDim.x) {
-    const int tile = xcd_swizzle(v, ntiles);
-    const int ty0 = (tile / a.tiles_x) * 8, tx0 = (tile % a.tiles_x) * FTW;
     __syncthreads();   // image window of this tile is in LDS; every wave is done with the previous tile's planes
+    HT_STAMP(0);
     const int vn = v + gridDim.x;
-    if (vn < ntiles) head_fetch(a.img, a.H, a.W, a.tiles_x, pxr, soff, xcd_swizzle(vn, ntiles), tid);
+    int nty0 = 0, ntx0 = 0;
+    if (vn < ntiles) {
+      int tr, tc;
+      tile_rc(xcd_swizzle(vn, ntiles), a.tiles_x, a.tx_magic, tr, tc);
+      nty0 = tr * 8; ntx0 = tc * FTW;
+      head_fetch(a.img, a.H, a.W, pxr, soff, nty0, ntx0, tid);
+    }
+    HT_STAMP(1);
     const bool interior = tile_interior(ty0, tx0, a.H, a.W);
     // ---- conv11 on the 340 halo pixels, three 16-pixel groups in flight per wave
 #pragma unroll
@@ -476,7 +500,9 @@ __global__ __launch_bounds__(256, 3) void enc_head_kernel(HeadArgs a) {
         if (gok[i + u]) store_split4(act, NPP, gpix[i + u], kq, x);
       }
     }
+    HT_STAMP(2);
     __syncthreads();
+    HT_STAMP(3);
     // ---- conv12 + ReLU + 2x2 max-pool (the arithmetic of conv3x3_f16_c16_kernel<POOL>)
     f32x4 acc[2][2];
 #pragma unroll
@@ -484,26 +510,40 @@ __global__ __launch_bounds__(256, 3) void enc_head_kernel(HeadArgs a) {
 #pragma unroll
       for (int h = 0; h < 2; ++h) acc[r][h] = f32x4{0.f, 0.f, 0.f, 0.f};
     c16_compute(act, wgt, wave, li, kq, acc);
-    const int co = 4 * kq;
+    HT_STAMP(4);
+    const int oy = (ty0 >> 1) + wave;                                   // uniform
+    char* orow = reinterpret_cast<char*>(a.out) + ((size_t)oy * Wp + (tx0 >> 1)) * 64;   // uniform: SALU address arithmetic
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      const int gx = tx0 + h * 16 + li;
       f32x4 m;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float x = fmaxf(acc[0][h][r], acc[1][h][r]);
-        x = fmaxf(x, __shfl_xor(x, 1));
+        x = fmaxf(x, lane_xor1(x));
         x = x * a.inv12 + bias12[r];
         m[r] = fmaxf(x, 0.f);
       }
-      const int oy = (ty0 + wave * 2) >> 1, ox = gx >> 1;
+      const int ox = (tx0 >> 1) + h * 8 + (li >> 1);
       if (!(li & 1) && oy < Hp && ox < Wp) {
-        if (a.out_sp) sp16_store4(reinterpret_cast<char*>(a.out) + ((size_t)oy * Wp + ox) * 64, kq, m);
-        else *reinterpret_cast<f32x4*>(a.out + ((size_t)oy * Wp + ox) * 16 + co) = m;
+        char* dst = orow + h * 8 * 64 + out_lane;
+        if (a.out_sp) {
+          u32x2 hi, lo;
+          split4(m, hi, lo);
+          *reinterpret_cast<u32x2*>(dst) = hi;
+          *reinterpret_cast<u32x2*>(dst + 16) = lo;
+        } else {
+          *reinterpret_cast<f32x4*>(dst) = m;
+        }
       }
     }
+    HT_STAMP(5);
     if (vn < ntiles) head_commit(pxr, imgH, imgL, tid);   // conv11 of this tile is behind the barrier above
+    HT_STAMP(6);
+    ty0 = nty0; tx0 = ntx0;
   }
+#ifdef WCT_HEAD_TIMING
+  if (tid == 0) { for (int i = 0; i < 7; ++i) atomicAdd(&g_head_t[i], ht[i]); atomicAdd(&g_head_t[7], 1ull); }
+#endif
 }
 
 struct TailArgs {   // conv12 (16->16 on the nearest-x2 upsampled input) + ReLU -> conv11 (16->3) + ReLU -> planar image
@@ -519,8 +559,10 @@ struct TailRegs { f32x4 v0[TAIL_SL], v1[TAIL_SL]; };
 
 // soff[k]: tile-independent element offset of slot k from the window origin, valid for interior tiles (the window
 // origin (ty0 - 2, tx0 - 2) is even, so the nearest-x2 shift distributes over origin + offset)
-__device__ __forceinline__ void tail_fetch(const TailArgs& a, TailRegs& r, const int (&soff)[TAIL_SL], int tile, int tid) {
-  const int ty0 = (tile / a.tiles_x) * 8, tx0 = (tile % a.tiles_x) * FTW;
+__device__ __forceinline__ void tail_fetch(const TailArgs& a, unsigned txm, TailRegs& r, const int (&soff)[TAIL_SL], int tile, int tid) {
+  int trow_, tcol_;
+  tile_rc(tile, a.tiles_x, txm, trow_, tcol_);
+  const int ty0 = trow_ * 8, tx0 = tcol_ * FTW;
   if (tile_interior(ty0, tx0, a.H, a.W)) {
     const float* base = a.in + ((size_t)((ty0 - 2) >> a.up_in) * a.inW + ((tx0 - 2) >> a.up_in)) * 16;
 #pragma unroll
@@ -572,6 +614,7 @@ __global__ __launch_bounds__(256, 2) void dec_tail_kernel(TailArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, kq = lane >> 4, kh = kq & 1, ts = kq >> 1;
   const int ntiles = a.tiles_x * a.tiles_y;
+  const unsigned txm = tile_div_magic(a.tiles_x);   // once per workgroup; tile_rc() then stays on the scalar unit
   for (int e = tid; e < 640; e += 256) { wg12[e] = a.w12[e]; wg11[e] = a.w11[e]; }
   const float inv12 = a.inv12_ptr ? *a.inv12_ptr : a.inv12;
   const f32x4 bias12 = *reinterpret_cast<const f32x4*>(a.b12 + 4 * kq);
@@ -601,15 +644,17 @@ __global__ __launch_bounds__(256, 2) void dec_tail_kernel(TailArgs a) {
   TailRegs tr;
   int v = blockIdx.x;
   if (v < ntiles) {
-    tail_fetch(a, tr, soff, xcd_swizzle(v, ntiles), tid);
+    tail_fetch(a, txm, tr, soff, xcd_swizzle(v, ntiles), tid);
     tail_commit(tr, act0, tid, a.in_sp);
   }
   for (; v < ntiles; v += gridDim.x) {
     const int tile = xcd_swizzle(v, ntiles);
-    const int ty0 = (tile / a.tiles_x) * 8, tx0 = (tile % a.tiles_x) * FTW;
+    int trow_, tcol_;
+    tile_rc(tile, a.tiles_x, txm, trow_, tcol_);
+    const int ty0 = trow_ * 8, tx0 = tcol_ * FTW;
     __syncthreads();   // act0 of this tile is in LDS; every wave is done with the previous tile's act1
     const int vn = v + gridDim.x;
-    if (vn < ntiles) tail_fetch(a, tr, soff, xcd_swizzle(vn, ntiles), tid);
+    if (vn < ntiles) tail_fetch(a, txm, tr, soff, xcd_swizzle(vn, ntiles), tid);
     // ---- conv12 on the 340 halo pixels (evaluated at their reflected image coordinates), into act1.
     //      All six groups are in flight together (tap loop outermost): the operand reads of the next tap pair overlap
     //      the MFMAs of this one.
@@ -757,6 +802,7 @@ hipError_t launch_enc_head(const ConvDesc& d0, const ConvDesc& d1, const float* 
   a.w11 = reinterpret_cast<const u32x4*>(d0.wpk16); a.b11 = d0.bias; a.inv11 = d0.inv_scale;
   a.w12 = reinterpret_cast<const u32x4*>(d1.wpk16); a.b12 = d1.bias; a.inv12 = d1.inv_scale;
   a.H = H; a.W = W; a.tiles_x = (W + FTW - 1) / FTW; a.tiles_y = (H + 7) / 8;
+  a.tx_magic = tile_div_magic(a.tiles_x);
   a.out_sp = (d1.flags & CONV_OUT_SP16) ? 1 : 0;
   const size_t lds = (size_t)2 * IMG_E * 8 + (size_t)4 * npp(8) * 16 + 640 * 16;   // 39.7 KB: 4 workgroups per CU
   const int ntiles = a.tiles_x * a.tiles_y, grid = ntiles < 3 * num_cus() ? ntiles : 3 * num_cus();
@@ -843,3 +889,11 @@ hipError_t launch_conv3x3_f16(const ConvDesc& d, const float* in, float* out, in
   }
 #undef WCT_F16_CASE
 }
+
+#ifdef WCT_HEAD_TIMING
+extern "C" int wct_debug_head_timing(unsigned long long* out8) {   // read and reset
+  unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_head_t), sizeof(z)) != hipSuccess) return -1;
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_head_t), z, sizeof(z)) == hipSuccess ? 0 : -1;
+}
+#endif

@@ -139,7 +139,7 @@ __global__ __launch_bounds__(512) void conv3x3_sp_kernel(SpArgs a) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         float t = fmaxf(r[c][0][4 * q + k], r[c][1][4 * q + k]);
-        t = fmaxf(t, __shfl_xor(t, 1));
+        t = fmaxf(t, lane_xor1(t));
         t = t * inv + bias[k];
         x[k] = a.relu ? fmaxf(t, 0.f) : t;
       }

@@ -106,15 +106,33 @@ __device__ __forceinline__ bool tile_interior(int ty0, int tx0, int H, int W) {
 
 // next tile's 36 x 12 x 3 image window -> 6 registers per thread (unconditional, clamped).  soff[k]: tile-independent
 // offset of the thread's pixel k from the window origin, valid for interior tiles.
-__device__ __forceinline__ void head_fetch(const float* img, int H, int W, int tiles_x, float (&r)[2][3], const int (&soff)[2], int tile, int tid) {
-  const int ty0 = (tile / tiles_x) * 8, tx0 = (tile % tiles_x) * FTW;
+// uniform tile index -> (tile row, tile column) on the SCALAR unit: hipcc expands even a uniform integer division through
+// v_rcp_iflag_f32 and ~25 VALU instructions, and the persistent fused kernels -- VALU-issue-bound -- did two or three of
+// them per tile.  q = mulhi(tile, ceil(2^32 / tiles_x)) is exact while tile * tiles_x < 2^32.
+__host__ __device__ inline unsigned tile_div_magic(int tiles_x) { return tiles_x > 1 ? (unsigned)(((1ull << 32) + tiles_x - 1) / tiles_x) : 0u; }
+__device__ __forceinline__ void tile_rc(int tile, int tiles_x, unsigned magic, int& row, int& col) {
+  const unsigned t = (unsigned)__builtin_amdgcn_readfirstlane(tile);
+  row = tiles_x > 1 ? (int)__umulhi(t, magic) : (int)t;
+  col = (int)t - row * tiles_x;
+}
+
+// horizontal neighbour (lane ^ 1) through DPP quad_perm [1,0,3,2]: one VALU move instead of ds_bpermute + address
+__device__ __forceinline__ float lane_xor1(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, true));
+}
+
+__device__ __forceinline__ void head_fetch(const float* img, int H, int W, float (&r)[2][3], const int (&soff)[2], int ty0, int tx0, int tid) {
   const size_t plane = (size_t)H * W;
   if (tile_interior(ty0, tx0, H, W)) {
+    // uniform base per plane + the thread's UNSIGNED 32-bit offset: global_load with an SGPR base (a signed index is widened
+    // to a 64-bit VGPR pair per load)
     const float* base = img + (size_t)(ty0 - 2) * W + (tx0 - 2);
 #pragma unroll
-    for (int k = 0; k < 2; ++k)
+    for (int c = 0; c < 3; ++c) {
+      const float* pc = base + c * plane;
 #pragma unroll
-      for (int c = 0; c < 3; ++c) r[k][c] = base[c * plane + soff[k]];
+      for (int k = 0; k < 2; ++k) r[k][c] = pc[(unsigned)soff[k]];
+    }
     return;
   }
 #pragma unroll
@@ -126,6 +144,12 @@ __device__ __forceinline__ void head_fetch(const float* img, int H, int W, int t
 #pragma unroll
     for (int c = 0; c < 3; ++c) r[k][c] = img[c * plane + off];
   }
+}
+
+__device__ __forceinline__ void head_fetch(const float* img, int H, int W, int tiles_x, unsigned tx_magic, float (&r)[2][3], const int (&soff)[2], int tile, int tid) {
+  int tr, tc;
+  tile_rc(tile, tiles_x, tx_magic, tr, tc);
+  head_fetch(img, H, W, r, soff, tr * 8, tc * FTW, tid);
 }
 
 __device__ __forceinline__ void head_commit(const float (&r)[2][3], u32x2* imgH, u32x2* imgL, int tid) {

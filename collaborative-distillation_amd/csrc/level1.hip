@@ -37,6 +37,7 @@ __global__ __launch_bounds__(256, 3) void l1_encode_kernel(L1EncArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, kq = lane >> 4;
   const int ntiles = a.tiles_x * a.tiles_y;
+  const unsigned txm = tile_div_magic(a.tiles_x);   // once per workgroup; tile_rc() then stays on the scalar unit
   if (tid < 4) { imgH[NPI2 + tid] = u32x2{0u, 0u}; imgL[NPI2 + tid] = u32x2{0u, 0u}; }
   L1Weights w;
   l1_load_weights(a.c, li, kq, w);
@@ -50,15 +51,17 @@ __global__ __launch_bounds__(256, 3) void l1_encode_kernel(L1EncArgs a) {
   float pxr[2][3];
   int v = blockIdx.x;
   if (v < ntiles) {
-    head_fetch(a.img, a.H, a.W, a.tiles_x, pxr, soff, xcd_swizzle(v, ntiles), tid);
+    head_fetch(a.img, a.H, a.W, a.tiles_x, txm, pxr, soff, xcd_swizzle(v, ntiles), tid);
     head_commit(pxr, imgH, imgL, tid);
   }
   for (; v < ntiles; v += gridDim.x) {
     const int tile = xcd_swizzle(v, ntiles);
-    const int ty0 = (tile / a.tiles_x) * 8, tx0 = (tile % a.tiles_x) * FTW;
+    int trow_, tcol_;
+    tile_rc(tile, a.tiles_x, txm, trow_, tcol_);
+    const int ty0 = trow_ * 8, tx0 = tcol_ * FTW;
     __syncthreads();
     const int vn = v + gridDim.x;
-    if (vn < ntiles) head_fetch(a.img, a.H, a.W, a.tiles_x, pxr, soff, xcd_swizzle(vn, ntiles), tid);
+    if (vn < ntiles) head_fetch(a.img, a.H, a.W, a.tiles_x, txm, pxr, soff, xcd_swizzle(vn, ntiles), tid);
 #pragma unroll
     for (int r = 0; r < 2; ++r)
 #pragma unroll
@@ -89,6 +92,7 @@ __global__ __launch_bounds__(256, 2) void l1_decode_kernel(L1DecArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, kq = lane >> 4;
   const int ntiles = a.tiles_x * a.tiles_y;
+  const unsigned txm = tile_div_magic(a.tiles_x);   // once per workgroup; tile_rc() then stays on the scalar unit
   for (int e = tid; e < 2 * 640; e += 256) wgt[e] = a.w2[e];
   if (tid < 4) { imgH[NPI2 + tid] = u32x2{0u, 0u}; imgL[NPI2 + tid] = u32x2{0u, 0u}; }
   L1Weights w;
@@ -116,15 +120,17 @@ __global__ __launch_bounds__(256, 2) void l1_decode_kernel(L1DecArgs a) {
   float pxr[2][3];
   int v = blockIdx.x;
   if (v < ntiles) {
-    head_fetch(a.img, a.H, a.W, a.tiles_x, pxr, soff, xcd_swizzle(v, ntiles), tid);
+    head_fetch(a.img, a.H, a.W, a.tiles_x, txm, pxr, soff, xcd_swizzle(v, ntiles), tid);
     head_commit(pxr, imgH, imgL, tid);
   }
   for (; v < ntiles; v += gridDim.x) {
     const int tile = xcd_swizzle(v, ntiles);
-    const int ty0 = (tile / a.tiles_x) * 8, tx0 = (tile % a.tiles_x) * FTW;
+    int trow_, tcol_;
+    tile_rc(tile, a.tiles_x, txm, trow_, tcol_);
+    const int ty0 = trow_ * 8, tx0 = tcol_ * FTW;
     __syncthreads();   // image window in LDS; previous tile's planes consumed
     const int vn = v + gridDim.x;
-    if (vn < ntiles) head_fetch(a.img, a.H, a.W, a.tiles_x, pxr, soff, xcd_swizzle(vn, ntiles), tid);
+    if (vn < ntiles) head_fetch(a.img, a.H, a.W, a.tiles_x, txm, pxr, soff, xcd_swizzle(vn, ntiles), tid);
     const bool interior = tile_interior(ty0, tx0, a.H, a.W);
     // ---- relu1_1 on the 340 halo pixels, each evaluated at its REFLECTED image coordinate (the decoder's own padding)
 #pragma unroll

@@ -219,6 +219,7 @@ __global__ __launch_bounds__(256, 2) void l1_moments_kernel(L1MomArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, kq = lane >> 4;     // conv roles; the pair loop uses the same split (c = li, pk = kq)
   const int ntiles = a.tiles_x * a.tiles_y;
+  const unsigned txm = tile_div_magic(a.tiles_x);   // once per workgroup; tile_rc() then stays on the scalar unit
   if (tid < 4) { imgH[NPI2 + tid] = u32x2{0u, 0u}; imgL[NPI2 + tid] = u32x2{0u, 0u}; }
   for (int e = tid; e < MP * a.Cs; e += 256) feat[e] = 0.f;   // columns >= 32 are never written
   L1Weights w;
@@ -240,15 +241,17 @@ __global__ __launch_bounds__(256, 2) void l1_moments_kernel(L1MomArgs a) {
   float pxr[2][3];
   int v = blockIdx.x;
   if (v < ntiles) {
-    head_fetch(a.img, a.H, a.W, a.tiles_x, pxr, soff, xcd_swizzle(v, ntiles), tid);
+    head_fetch(a.img, a.H, a.W, a.tiles_x, txm, pxr, soff, xcd_swizzle(v, ntiles), tid);
     head_commit(pxr, imgH, imgL, tid);
   }
   for (; v < ntiles; v += gridDim.x) {
     const int tile = xcd_swizzle(v, ntiles);
-    const int ty0 = (tile / a.tiles_x) * 8, tx0 = (tile % a.tiles_x) * FTW;
+    int trow_, tcol_;
+    tile_rc(tile, a.tiles_x, txm, trow_, tcol_);
+    const int ty0 = trow_ * 8, tx0 = tcol_ * FTW;
     __syncthreads();   // image window in LDS; the previous tile's features consumed
     const int vn = v + gridDim.x;
-    if (vn < ntiles) head_fetch(a.img, a.H, a.W, a.tiles_x, pxr, soff, xcd_swizzle(vn, ntiles), tid);
+    if (vn < ntiles) head_fetch(a.img, a.H, a.W, a.tiles_x, txm, pxr, soff, xcd_swizzle(vn, ntiles), tid);
 #pragma unroll
     for (int r = 0; r < 2; ++r)
 #pragma unroll
