@@ -258,7 +258,7 @@ hipError_t launch_sp(K k, const SpArgs& a, size_t lds, hipStream_t s, int thread
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   // (tile, group) units per XCD queue x 8 queues, capped at one workgroup per CU; a multiple of 8 (workgroup b -> XCD b & 7)
-  const int ntiles = a.tiles_x * a.tiles_y, want = 8 * ((ntiles + 7) / 8) * a.groups, cus = num_cus() & ~7;
+  const int ntiles = a.tiles_x * a.tiles_y, want = 8 * ((ntiles + 7) / 8) * a.groups, cus = (num_cus() & ~7) > 8 ? (num_cus() & ~7) : 8;
   const int grid = want < cus ? want : cus;
   hipLaunchKernelGGL(k, dim3(grid), dim3(threads), lds, s, a);
   return hipGetLastError();

@@ -383,6 +383,25 @@ def test_levels_vs_oracle(torch_cuda, wct16, oracle, weights16x, H, W, Hs, Ws):
         img = ref
 
 
+@pytest.mark.parametrize("mode,H,W,Hs,Ws,alpha", [("16x", 42, 410, 604, 229, 1.0), ("16x", 343, 748, 195, 56, 0.6), ("16x", 166, 581, 257, 430, 0.6),
+                                                   ("original", 97, 47, 34, 217, 1.0), ("original", 118, 158, 146, 111, 0.6)])
+def test_odd_shapes_vs_oracle(torch_cuda, oracle, weights16x, mode, H, W, Hs, Ws, alpha):
+    """Shapes drawn by tools/experiments/fuzz_sizes.py (thin strips, fewer tiles than XCDs, feature maps of a few pixels under
+    512 channels -> singular covariances through the deflated iteration), every level on the checker's own level input."""
+    from wct_hip import WCT
+    w = weights16x if mode == "16x" else model_zoo.synth_weights("original", 7)
+    wct = WCT(types.SimpleNamespace(mode=mode, alpha=alpha), weights=w)
+    mods = oracle.Modules(mode, w)
+    rng = np.random.default_rng(H * 1000 + W)
+    img, s = rng.random((3, H, W), dtype=np.float32), rng.random((3, Hs, Ws), dtype=np.float32)
+    for k in (5, 4, 3, 2, 1):
+        ref = oracle.style_transfer(mods, k, img, s, alpha)
+        got = wct.style_transfer_level(k, cu(torch_cuda, img)[None], cu(torch_cuda, s)[None]).cpu().numpy()[0]
+        assert got.shape == ref.shape
+        assert rel_err(got, ref) < 2e-4, k
+        img = ref
+
+
 # --------------------------------------------------------------------------- properties at full size
 def test_full_size_properties_config2(torch_cuda, wct16):
     """BASELINE config 2 (3840x2160 content, 2048x2048 style): the oracle would take minutes, so check
