@@ -230,6 +230,19 @@ def main():
             torch.cuda.synchronize()
             msc = e0.elapsed_time(e1) / 5
             cached = {"ms": round(msc, 3), "MPs": round(H * W / 1e6 / msc * 1e3, 1)}
+            # the same with three frames in flight on this GPU (wct_hip/pipeline.py; throughput of the batch / video case)
+            from wct_hip.pipeline import FramePipeline
+            pipe = FramePipeline(lambda: WCT(types.SimpleNamespace(mode="16x", alpha=1.0), weights=weights), slots=3)
+            pipe.set_style(style)
+            frames = [content4k] * 12
+            pipe.stylize_many(frames[:6])
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            pipe.stylize_many(frames)
+            torch.cuda.synchronize()
+            msp = (time.perf_counter() - t0) / len(frames) * 1e3
+            cached["three_frames_in_flight"] = {"ms_per_frame": round(msp, 3), "MPs": round(H * W / 1e6 / msp * 1e3, 1)}
+            del pipe
         passes = {"style_cached_cascade": cached, "relu4_1_encode": {"ms": round(ms, 3), "algo_GBs": round(364.0 * H * W / ms / 1e6, 1),
                                      "frac_hbm_8TBs": round(364.0 * H * W / ms / 1e6 / PEAK_HBM_GBS, 4),
                                      "tflops": round(30816.0 * H * W / ms / 1e9, 2),

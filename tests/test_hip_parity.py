@@ -565,3 +565,21 @@ def test_original_mode_from_t7_checkpoints(torch_cuda, tmp_path):
     c, s = torch_cuda.rand((1, 3, 96, 80), device="cuda", generator=g), torch_cuda.rand((1, 3, 64, 112), device="cuda", generator=g)
     ya, yb = a.stylize(c, s), b.stylize(c, s)
     assert torch_cuda.isfinite(ya).all() and torch_cuda.equal(ya, yb)
+
+
+def test_frame_pipeline_equals_single_engine(torch_cuda, wct16, weights16x):
+    """wct_hip/pipeline.py: three frames of different sizes in flight on two engines = the single-engine results, bit for bit."""
+    from wct_hip import WCT
+    from wct_hip.pipeline import FramePipeline
+    g = torch_cuda.Generator(device="cuda").manual_seed(9)
+    style = torch_cuda.rand((3, 200, 312), device="cuda", generator=g)
+    frames = [torch_cuda.rand((3, h, w), device="cuda", generator=g) for h, w in ((160, 240), (96, 400), (333, 250), (160, 240))]
+    pipe = FramePipeline(lambda: WCT(types.SimpleNamespace(mode="16x", alpha=1.0), weights=weights16x), slots=2)
+    got = pipe.stylize_many(frames, style=style)
+    torch_cuda.cuda.synchronize()
+    wct16.style_prepare(style)
+    for f, y in zip(frames, got):
+        ref = wct16.stylize_prepared(f)
+        assert y.shape == ref.shape and torch_cuda.equal(y, ref)
+    with pytest.raises(RuntimeError):
+        FramePipeline(lambda: wct16, slots=1).stylize_many(frames[:1])
