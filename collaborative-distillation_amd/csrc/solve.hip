@@ -804,7 +804,8 @@ hipError_t launch_eig(int C, double n, const double* sum, const double* sumsq, i
     // then maps both ends of [x, 1] to the same value) -- small eigenvalues grow 6.75x per step instead of 2.25x and the
     // whole spectrum arrives together: 19 iterations for ANY matrix instead of 15 (cond 1e3) .. 39 (singular).  The schedule
     // depends on l0 alone, so it is computed here; numpy prototype: same accuracy as the plain iteration.
-    double xlow = big ? sqrt(NS_DEFLATE / (1.0 + NS_DEFLATE)) : 1.0;
+    static const double guess_env = [] { const char* e = getenv("WCT_NS_GUESS"); return e ? atof(e) : 0.0; }();
+    double xlow = big ? sqrt(NS_DEFLATE / (1.0 + NS_DEFLATE)) : (guess_env > 0. ? sqrt(guess_env) : 1.0);
     static const bool sk_env = [] { const char* e = getenv("WCT_NS_SPLITK"); return e ? atoi(e) != 0 : true; }();
     const bool splitk128 = sk_env && Cp % 64 == 0;
     for (int it = 0; it < maxit; ++it) {
@@ -813,12 +814,17 @@ hipError_t launch_eig(int C, double n, const double* sum, const double* sumsq, i
         xlow = mu * xlow * (3.0 - mu * mu * xlow * xlow) / 2.0;
         hipLaunchKernelGGL(ns_stage1_wide_kernel, g1, dim3(256), 0, s, w, Cp, it, 1.5 * mu, 0.5 * mu * mu * mu);
         hipLaunchKernelGGL(ns_stage2_wide_kernel, g2, dim3(256), 0, s, w, Cp, it);
-      } else if (splitk128) {   // Cp = 128, plain adaptive iteration on the split-k tiles (2 k-blocks per wave instead of 8)
-        hipLaunchKernelGGL(ns_stage1_wide_kernel, g1, dim3(256), 0, s, w, Cp, it, 1.5, 0.5);
-        hipLaunchKernelGGL(ns_stage2_wide_kernel, g2, dim3(256), 0, s, w, Cp, it);
       } else {
-        hipLaunchKernelGGL(ns_stage1_kernel, g1, dim3(256), 0, s, w, Cp, it, 1.5, 0.5);
-        hipLaunchKernelGGL(ns_stage2_kernel, g2, dim3(256), 0, s, w, Cp, it);
+        const double mu = xlow <= 0.9 ? sqrt(3.0 / (1.0 + xlow + xlow * xlow)) : 1.0;
+        xlow = mu * xlow * (3.0 - mu * mu * xlow * xlow) / 2.0;
+        const double ca = 1.5 * mu, cb = 0.5 * mu * mu * mu;
+        if (splitk128) {   // Cp = 128, adaptive iteration on the split-k tiles (2 k-blocks per wave instead of 8)
+          hipLaunchKernelGGL(ns_stage1_wide_kernel, g1, dim3(256), 0, s, w, Cp, it, ca, cb);
+          hipLaunchKernelGGL(ns_stage2_wide_kernel, g2, dim3(256), 0, s, w, Cp, it);
+        } else {
+          hipLaunchKernelGGL(ns_stage1_kernel, g1, dim3(256), 0, s, w, Cp, it, ca, cb);
+          hipLaunchKernelGGL(ns_stage2_kernel, g2, dim3(256), 0, s, w, Cp, it);
+        }
       }
     }
     const double* deflated = nullptr;
