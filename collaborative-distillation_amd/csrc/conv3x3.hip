@@ -20,6 +20,7 @@
 // operands) and both reads are bank-conflict free (16 consecutive 16-B slots per plane, plane stride a
 // multiple of 256 B -- MI355X_MICROARCH "LDS" table).
 #include "wct_common.h"
+#include "conv_f16_dev.h"
 
 namespace {
 
@@ -41,23 +42,11 @@ struct ConvArgs {
   int cout_pad;      // total padded couts in wpk
   int tiles_x, tiles_y;
   int up_in, relu;
+  int out_sp;        // SP16 output (conv_f16_dev.h): the consumer is an f16x3 layer and takes the split as it is
 };
 
-__device__ __forceinline__ int reflect_clamp(int i, int n) {
-  // ReflectionPad2d(1): -1 -> 1, n -> n-2; tiles hanging over the image edge are clamped (never stored)
-  if (i < 0) i = -i;
-  if (i >= n) i = 2 * n - 2 - i;
-  i = i < 0 ? 0 : i;
-  return i >= n ? n - 1 : i;
-}
-
-// XCD-aware tile order: consecutive block ids land on different XCDs (b % 8); give each XCD a contiguous
-// run of tiles so neighbouring halos share that XCD's L2 (cdna_hip_programming.md T1, bijective form).
-__device__ __forceinline__ int xcd_swizzle(int bid, int n) {
-  const int q = n >> 3, r = n & 7, xcd = bid & 7, idx = bid >> 3;
-  const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-  return base + idx;
-}
+// reflect_clamp (ReflectionPad2d(1): -1 -> 1, n -> n-2; tiles hanging over the image edge are clamped, never stored) and
+// xcd_swizzle (each XCD gets a contiguous run of tiles so neighbouring halos share its L2) come from conv_f16_dev.h
 
 template <int CT, bool IN3, bool POOL, bool OUT3>
 __global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a) {
@@ -191,7 +180,8 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a) {
               a.out[2 * plane + off] = v[2];
             }
           } else if (co < a.cout) {
-            *reinterpret_cast<f32x4*>(a.out + ((size_t)gy * a.W + gx) * a.cout + co) = v;
+            if (a.out_sp) sp16_store4(reinterpret_cast<char*>(a.out) + (size_t)(co >> 4) * sp16_plane_bytes(a.H, a.W) + ((size_t)gy * a.W + gx) * 64, kq, v);
+            else *reinterpret_cast<f32x4*>(a.out + ((size_t)gy * a.W + gx) * a.cout + co) = v;
           }
         }
       }
@@ -224,7 +214,9 @@ hipError_t launch_conv3x3(const ConvDesc& d, const float* in, float* out, int H,
   a.cin = d.cin; a.cout = d.cout; a.cin_chunks = d.cin_chunks; a.cout_pad = d.cout_pad;
   a.tiles_x = (W + TW - 1) / TW; a.tiles_y = (H + TH - 1) / TH;
   a.relu = (d.flags & CONV_NO_RELU) ? 0 : 1;
+  a.out_sp = (d.flags & CONV_OUT_SP16) ? 1 : 0;
   const bool in3 = d.flags & CONV_IN_NCHW3, pool = d.flags & CONV_POOL_OUT, out3 = d.flags & CONV_OUT_NCHW3;
+  if (a.out_sp && (pool || out3 || (d.cout & 15))) return hipErrorInvalidValue;   // SP16 from the plain epilogue only, whole 16-channel chunks
   if (H < 2 || W < 2) return hipErrorInvalidValue;  // reflect pad needs >= 2 samples
   int ct = d.cout_pad / 16, groups = 1;
   if (ct > 8) {

@@ -170,7 +170,8 @@ int run_conv(wct_ctx* ctx, Lane& ln, const ConvDesc& d, const float* in, float* 
   char name[48];
   const bool f16 = conv_runs_f16(ctx, d);
   const bool spk = f16 && (d.flags & CONV_IN_SP16) && conv_sp_supported(d);   // DMA-staged persistent kernel
-  if (!f16 && (d.flags & (CONV_IN_SP16 | CONV_OUT_SP16))) return fail(ctx, WCT_ERR_INVALID, "SP16 activations need the f16x3 path");
+  if (!f16 && ((d.flags & CONV_IN_SP16) || ((d.flags & CONV_OUT_SP16) && !(d.flags & CONV_IN_NCHW3))))
+    return fail(ctx, WCT_ERR_INVALID, "SP16 activations need the f16x3 path");
   snprintf(name, sizeof name, "conv3x3%s<co=%d%s%s%s%s>", f16 ? "_f16x3" : "_f32", d.cout_pad > 128 ? 128 : d.cout_pad,
            (d.flags & CONV_IN_NCHW3) ? ",in3" : "", (d.flags & CONV_POOL_OUT) ? ",pool" : "", (d.flags & CONV_OUT_NCHW3) ? ",out3" : "",
            spk ? ",dma" : "");
@@ -359,7 +360,9 @@ int encode_impl(wct_ctx* ctx, Lane& ln, int level, const float* img, int H, int 
     const bool last = i + 1 == m.layers.size();
     float* dst = last ? feat_nhwc : reinterpret_cast<float*>((i & 1) ? ln.actB.p : ln.actA.p);
     ConvDesc d = l.d;
-    const bool out_sp = conv_runs_f16(ctx, d) && wants_sp(i);
+    // the image-input conv runs on the fp32 MFMA kernel; it can hand SP16 to an f16x3 consumer all the same
+    const bool img_in = (d.flags & CONV_IN_NCHW3) && !(d.flags & CONV_POOL_OUT) && (d.cout & 15) == 0;
+    const bool out_sp = (conv_runs_f16(ctx, d) || img_in) && wants_sp(i);
     if (cur_sp) d.flags |= CONV_IN_SP16;
     if (out_sp) d.flags |= CONV_OUT_SP16;
     if (int rc = run_conv(ctx, ln, d, cur, dst, h, w)) return rc;
