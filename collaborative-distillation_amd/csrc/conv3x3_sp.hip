@@ -61,6 +61,14 @@ typedef __attribute__((address_space(3))) void* lds_ptr;
 // VGPR cap, 1.5x the LDS operand reads and a 16-wave barrier.  Kept out.)
 // GROUPS (more than one cout group, i.e. >= 128 couts) changes no code: it gives those launches their own kernel name
 // so that profiler rows (rocprofv3, PMC) can be matched to the library's profile families.
+#ifdef WCT_SP_TIMING   // tools/experiments/sp_timing.sh: shader-clock cycles per phase, wave 0 of every workgroup, summed over all launches
+__device__ unsigned long long g_sp_t[4];   // wait for the stage + barrier | tap loop (MFMA + riding DMA / epilogue slices) | rest | jobs
+#define SP_STAMP(i) do { if (threadIdx.x == 0) { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+                         spt[i] += t_ - sptl; sptl = t_; __builtin_amdgcn_sched_barrier(0); } } while (0)
+#else
+#define SP_STAMP(i)
+#endif
+
 template <int CT, bool POOL, bool OUTF32, bool GROUPS>
 __global__ __launch_bounds__(512) void conv3x3_sp_kernel(SpArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -125,8 +133,14 @@ __global__ __launch_bounds__(512) void conv3x3_sp_kernel(SpArgs a) {
   // in the SAME tap (4 pieces per tap on the first NPIECE / 4 taps): spread over four taps the lines were written back
   // half-filled in between (PMC: +18 % HBM write traffic).
   constexpr int PPT = 4;
-  auto epilogue_piece = [&](const f32x16 (&r)[CPW][2], int piece, int ptile, int pgrp) {
-    const int ty0 = (ptile / a.tiles_x) * SPH, tx0 = (ptile % a.tiles_x) * FTW;
+  // The pieces ride on the LAST taps of a job, after the job's DMA slices (taps 0 .. SP_ACT_PER_WAVE - 1).  (Tried on top of
+  // that order: waiting for vmcnt(NPIECE) instead of vmcnt(0) at the top of a job -- gfx9 counts stores in vmcnt and retires
+  // it in order, so the stage has landed while the stores may still be in flight.  No gain: the 2.7 k of 11.7 k cycles per
+  // job that wave 0 spends at the wait + barrier (tools/experiments/sp_timing.sh) are the other wave of its SIMD still on
+  // the matrix core, not write acknowledgements.)
+  constexpr int EP_TAP0 = 9 - (NPIECE + PPT - 1) / PPT;
+  static_assert(EP_TAP0 >= SP_ACT_PER_WAVE, "epilogue slices after the DMA slices");
+  auto epilogue_piece = [&](const f32x16 (&r)[CPW][2], int piece, int ty0, int tx0, int pgrp) {
     const int gx = tx0 + li;
     const int oH = POOL ? a.H >> 1 : a.H, oW = POOL ? a.W >> 1 : a.W;
     const int q = piece & 3, cp = piece >> 2, p = POOL ? 0 : cp & 1, c = POOL ? cp : cp >> 1;
@@ -177,11 +191,15 @@ __global__ __launch_bounds__(512) void conv3x3_sp_kernel(SpArgs a) {
   int grp = GROUPS ? v % ngroups : 0;
   int tile = tbase + (GROUPS ? v / ngroups : v);
   int dma_tile = tile;          // tile the offsets in poff[] belong to
-  int ptile = 0, pgrp = 0;      // tile / group whose finished accumulators wait in pend[]
+  int pgrp = 0, pty0 = 0, ptx0 = 0;   // group / origin of the tile whose finished accumulators wait in pend[]
   bool have_pend = false;
+  const unsigned txm = tile_div_magic(a.tiles_x);
   tile_offsets(tile);
 #pragma unroll
   for (int i = 0; i < SP_ACT_PER_WAVE; ++i) issue_slice(i, 0, grp, 0);
+#ifdef WCT_SP_TIMING
+  unsigned long long spt[4] = {0, 0, 0, 0}, sptl = __builtin_amdgcn_s_memtime();
+#endif
   while (true) {
     // next job
     int nv = v, ngrp = grp, nch = ch + 1;
@@ -190,6 +208,7 @@ __global__ __launch_bounds__(512) void conv3x3_sp_kernel(SpArgs a) {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    SP_STAMP(0);
     if (more) {
       const int ntile = nv == v ? tile : tbase + (GROUPS ? nv / ngroups : nv);
       if (ntile != dma_tile) { tile_offsets(ntile); dma_tile = ntile; }
@@ -222,10 +241,10 @@ __global__ __launch_bounds__(512) void conv3x3_sp_kernel(SpArgs a) {
       }
       // riding on this tap: a slice of the next job's DMA and a slice of the previous tile's epilogue
       if (tap < SP_ACT_PER_WAVE && more) issue_slice(tap, nch, ngrp, stage ^ 1);
-      if (have_pend) {
+      if (tap >= EP_TAP0 && have_pend) {
 #pragma unroll
         for (int k = 0; k < PPT; ++k)
-          if (tap * PPT + k < NPIECE) epilogue_piece(pend, tap * PPT + k, ptile, pgrp);
+          if ((tap - EP_TAP0) * PPT + k < NPIECE) epilogue_piece(pend, (tap - EP_TAP0) * PPT + k, pty0, ptx0, pgrp);
       }
 #pragma unroll
       for (int term = 0; term < 3; ++term)
@@ -235,22 +254,33 @@ __global__ __launch_bounds__(512) void conv3x3_sp_kernel(SpArgs a) {
           for (int p = 0; p < 2; ++p)
             acc[c][p] = __builtin_amdgcn_mfma_f32_32x32x16_f16(term == 2 ? al[c] : ah[c], term == 1 ? bl[p] : bh[p], acc[c][p], 0, 0, 0);
     }
+    SP_STAMP(1);
     have_pend = false;
     if (ch + 1 == a.cin_chunks) {   // park the finished tile; its stores ride on the next job
 #pragma unroll
       for (int c = 0; c < CPW; ++c)
 #pragma unroll
         for (int p = 0; p < 2; ++p) pend[c][p] = acc[c][p];
-      ptile = tile; pgrp = grp; have_pend = true;
+      int trow_, tcol_;
+      tile_rc(tile, a.tiles_x, txm, trow_, tcol_);
+      pty0 = trow_ * SPH; ptx0 = tcol_ * FTW; pgrp = grp; have_pend = true;
     }
+#ifdef WCT_SP_TIMING
+    spt[3] += 1;
+#endif
     if (!more) break;
     if (nv != v) { v = nv; tile = dma_tile; }
     grp = ngrp; ch = nch; stage ^= 1;
+    SP_STAMP(2);
   }
   if (have_pend) {
 #pragma unroll
-    for (int k = 0; k < NPIECE; ++k) epilogue_piece(pend, k, ptile, pgrp);
+    for (int k = 0; k < NPIECE; ++k) epilogue_piece(pend, k, pty0, ptx0, pgrp);
   }
+#ifdef WCT_SP_TIMING
+  SP_STAMP(2);
+  if (threadIdx.x == 0) for (int i = 0; i < 4; ++i) atomicAdd(&g_sp_t[i], spt[i]);
+#endif
 }
 
 template <typename K>
@@ -307,3 +337,11 @@ hipError_t launch_conv3x3_sp(const ConvDesc& d, const void* in, void* out, int H
 #undef WCT_SP_CASE
   return hipErrorInvalidValue;
 }
+
+#ifdef WCT_SP_TIMING
+extern "C" int wct_debug_sp_timing(unsigned long long* out4) {   // read and reset
+  unsigned long long z[4] = {0, 0, 0, 0};
+  if (hipMemcpyFromSymbol(out4, HIP_SYMBOL(g_sp_t), sizeof(z)) != hipSuccess) return -1;
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_sp_t), z, sizeof(z)) == hipSuccess ? 0 : -1;
+}
+#endif

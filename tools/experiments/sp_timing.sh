@@ -3,5 +3,4 @@ set -e
 cd collaborative-distillation_amd
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DWCT_SP_TIMING -o libwct_hip_timing.so csrc/conv3x3.hip csrc/conv3x3_f16.hip csrc/conv3x3_sp.hip csrc/level1.hip csrc/moments.hip csrc/solve.hip csrc/misc.hip csrc/wct_api.hip
 cd ..
-echo "built collaborative-distillation_amd/libwct_hip_timing.so; run on the GPU box:"
-echo "  WCT_LIB_PATH=\$PWD/collaborative-distillation_amd/libwct_hip_timing.so WCT_DBG=1 WCT_OVERLAP=0 python bench.py --steps 1 --warmup 1 --no-cpu-baseline 2>&1 | python tools/experiments/sp_timing_summary.py"
+echo "built collaborative-distillation_amd/libwct_hip_timing.so; on the GPU box: WCT_LIB_PATH=\$PWD/collaborative-distillation_amd/libwct_hip_timing.so python tools/experiments/sp_timing.py"
