@@ -14,12 +14,15 @@ coupling is (n, SUM x, SUM x x^T) of the content feature map (util_wct.py:68-70)
     construction; reflect padding happens only at the true image borders;
   * moments are accumulated over OWNED columns only and summed with one all-reduce (fp64, C*C + C values:
     132 KB at C = 128, latency-bound on xGMI) per level;
-  * rank 0 turns the global moments into the colouring map (M, b) and broadcasts it (<= 2.1 MB at C = 512),
-    so every rank folds the SAME matrices into its decoder;
   * the style side (five encodes + moments + matrix square roots, a third of a single-GPU step) depends only on the
-    style image, and only the rank that solves needs its result: level L's style statistics are computed by rank
-    (5 - L) mod world on its side stream, overlapping that rank's content work, and reach rank 0 by one broadcast of
-    C*C + C fp64 values per level (132 KB at C = 128) instead of every rank repeating all five levels.
+    style image: level L's style statistics are computed by rank (5 - L) mod world on its side stream, overlapping that
+    rank's content work, and broadcast -- C*C + C fp64 values per level, 132 KB at C = 128 -- instead of every rank
+    repeating all five levels;
+  * the colouring map (M, b): every rank now holds the same global content moments (the all-reduce returns identical bits
+    everywhere) and the same style statistics, and the solver is deterministic, so every rank solves for itself and folds
+    the SAME matrices into its decoder -- two collectives per level.  `broadcast_map=True` keeps the other arrangement
+    (rank 0 solves and broadcasts (M, b), <= 2.1 MB at C = 512; style statistics only travel to rank 0): three collectives
+    per level, one solve per node.
 
 The orchestration is backend-agnostic: `engine` is a wct_hip.WCT on the GPU (RCCL = torch.distributed "nccl"),
 and tests run the same code under gloo with a CPU checker as the engine.
@@ -52,8 +55,9 @@ def ext_bounds(own: Tuple[int, int], W: int, halo: int) -> Tuple[int, int]:
 
 class ShardedStylizer:
     def __init__(self, engine, dist, H: int, W_total: int, Hs: int, Ws: int, rank: Optional[int] = None,
-                 world: Optional[int] = None, alpha: float = 1.0):
+                 world: Optional[int] = None, alpha: float = 1.0, broadcast_map: bool = False):
         self.e, self.dist = engine, dist
+        self.broadcast_map = broadcast_map
         self.rank = dist.get_rank() if rank is None else rank
         self.world = dist.get_world_size() if world is None else world
         self.H, self.W, self.Hs, self.Ws = H, W_total, Hs, Ws
@@ -100,23 +104,27 @@ class ShardedStylizer:
             packed = torch.cat([sum_c.reshape(-1), sumsq_c.reshape(-1)])
             if self.world > 1:
                 dist.all_reduce(packed)                                # SUM, fp64, C*C + C values
-            if self.world > 1 and owner(L) != 0:                       # the level's style statistics -> the solving rank
+            solvers = (0,) if self.broadcast_map else range(self.world)   # ranks that need the level's style statistics
+            if self.world > 1 and any(r != owner(L) for r in solvers):
                 if rank == owner(L):
                     stats = e.style_export(L)
                 else:
                     stats = torch.empty(e.style_stats_count(L), dtype=torch.float64, device=packed.device)
                 dist.broadcast(stats, src=owner(L))
-                if rank == 0:
+                if rank != owner(L) and rank in solvers:
                     e.style_import(L, stats)
             n_c = float(h * (W_cur >> sh))                             # feature pixels of the whole image
-            Mb = torch.empty(C * C + C, dtype=torch.float64, device=packed.device)
-            if self.rank == 0:
-                M, b = e.content_solve(L, n_c, packed[:C], packed[C:].reshape(C, C), self.alpha)
-                Mb[:C * C] = M.reshape(-1)
-                Mb[C * C:] = b
-            if self.world > 1:
+            if self.broadcast_map and self.world > 1:
+                Mb = torch.empty(C * C + C, dtype=torch.float64, device=packed.device)
+                if rank == 0:
+                    M, b = e.content_solve(L, n_c, packed[:C], packed[C:].reshape(C, C), self.alpha)
+                    Mb[:C * C] = M.reshape(-1)
+                    Mb[C * C:] = b
                 dist.broadcast(Mb, src=0)                              # the colouring map, identical on every rank
-            img = e.content_decode(L, Mb[:C * C].reshape(C, C), Mb[C * C:], H_in, W_in)   # [1,3,h<<sh, w_ext<<sh]
+                M, b = Mb[:C * C].reshape(C, C), Mb[C * C:]
+            else:
+                M, b = e.content_solve(L, n_c, packed[:C], packed[C:].reshape(C, C), self.alpha)
+            img = e.content_decode(L, M, b, H_in, W_in)               # [1,3,h<<sh, w_ext<<sh]
             # floor-mode pooling may have dropped trailing columns/rows of the full image
             W_cur = (W_cur >> sh) << sh
             hi = lo + int(img.shape[-1])

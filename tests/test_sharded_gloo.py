@@ -87,7 +87,7 @@ class OracleEngine:
         return torch.from_numpy(self.m.decode(level, y))[None]
 
 
-def _worker(rank, world, port, H, W, out_path):
+def _worker(rank, world, port, H, W, out_path, broadcast_map=False):
     for p in (REPO, PKG):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -104,7 +104,7 @@ def _worker(rank, world, port, H, W, out_path):
         rng = np.random.default_rng(5)
         content = rng.random((3, H, W), dtype=np.float32)
         style = rng.random((3, 80, 96), dtype=np.float32)
-        sh = ShardedStylizer(eng, dist, H, W, 80, 96, alpha=1.0)
+        sh = ShardedStylizer(eng, dist, H, W, 80, 96, alpha=1.0, broadcast_map=broadcast_map)
         x0, x1 = sh.input_columns()
         strip = sh.stylize_strip(torch.from_numpy(np.ascontiguousarray(content[:, :, x0:x1])), torch.from_numpy(style))
         parts = [None] * world
@@ -124,10 +124,11 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("world,H,W", [(2, 64, 1280), (3, 48, 1925), (6, 32, 1152)])   # 6 ranks: every level's style side on another rank, rank 5 none
-def test_sharded_equals_untiled(tmp_path, oracle, weights16x, world, H, W):
+@pytest.mark.parametrize("world,H,W,bmap", [(2, 64, 1280, False), (3, 48, 1925, False), (6, 32, 1152, False),   # 6 ranks: every level's style side on another rank, rank 5 none
+                                            (3, 48, 1925, True)])                                               # rank 0 solves and broadcasts (M, b)
+def test_sharded_equals_untiled(tmp_path, oracle, weights16x, world, H, W, bmap):
     out = str(tmp_path / "sharded.npy")
-    mp.spawn(_worker, args=(world, _free_port(), H, W, out), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), H, W, out, bmap), nprocs=world, join=True)
     got = np.load(out)
     rng = np.random.default_rng(5)
     content = rng.random((3, H, W), dtype=np.float32)
