@@ -300,7 +300,8 @@ bool conv_sp_supported(const ConvDesc& d) {
   // WCT_SP_DMA_MASK (experiments): which layer families take the DMA kernel -- 1: 32 couts, 2: 32 couts + pool,
   // 4: 64 couts, 8: 64 couts + pool, 16: >= 128 couts.  Measured (4K bench, ms per step, DMA vs register-staged on the
   // same SP16 input): 32: 1.29 / 1.30, 32+pool: 0.72 / 0.59, 64: 1.90 / 1.95, 64+pool: 0.33 / 0.33, >=128: 1.31 / 1.70
-  // -> default 29: everything but the pooled 32-cout layers.
+  // -> default 29: everything but the pooled 32-cout layers (re-measured after the chunk-planar SP16 layout and the
+  // per-XCD work units: 0.565 / 0.565 ms there now -- a tie, left as it was).
   static const int mask = [] { const char* e = getenv("WCT_SP_DMA_MASK"); return e ? atoi(e) : 29; }();
   const bool pool = d.flags & CONV_POOL_OUT;
   const int fam = d.cout_pad >= 128 ? 16 : d.cout_pad == 64 ? (pool ? 8 : 4) : (pool ? 2 : 1);
