@@ -60,6 +60,69 @@ __global__ __launch_bounds__(256) void fold_row_kernel(const float* w, const flo
   if (maxbits && (tid & 63) == 0) atomicMax(maxbits, __float_as_uint(mx));
 }
 
+// cin >= 256 (--mode original): the same fold with OB output channels per workgroup and one input column i per thread.  The
+// row-per-workgroup kernel above makes every one of its 512 workgroups stream all of M (2 MB at C = 512) through a
+// dependent 512-step loop -- 0.58 ms per launch; here an M element is loaded once per OB * 9 products, the weight rows sit in
+// LDS and are read wave-uniformly.  Same summation order over c for every (o, tap, i): bit-identical results.
+template <int OB>
+__global__ __launch_bounds__(256) void fold_block_kernel(const float* w, const float* bias, int cout, int cin, int cout_pad,
+                                                           const double* M, const double* b, float* wpk, float* bias_out, unsigned* maxbits) {
+  extern __shared__ float wrow[];          // [OB][cin * 9]
+  __shared__ double red[256];
+  const int o0 = blockIdx.x * OB, tid = threadIdx.x, i = blockIdx.y * 256 + tid;
+  const int chunks = (cin + 15) / 16, ipad = chunks * 16, row = cin * 9;
+  for (int e = tid; e < OB * row; e += 256) {
+    const int o = o0 + e / row;
+    wrow[e] = o < cout ? w[(size_t)o * row + (e - (e / row) * row)] : 0.f;
+  }
+  __syncthreads();
+  double s[OB][9];
+#pragma unroll
+  for (int o = 0; o < OB; ++o)
+#pragma unroll
+    for (int t = 0; t < 9; ++t) s[o][t] = 0.;
+  if (i < cin) {
+    for (int c = 0; c < cin; ++c) {
+      const double m = M[(size_t)c * cin + i];
+#pragma unroll
+      for (int o = 0; o < OB; ++o)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) s[o][t] += (double)wrow[o * row + c * 9 + t] * m;
+    }
+  }
+  float mx = 0.f;
+  if (i < ipad) {
+    const int chunk = i >> 4, kq = (i >> 2) & 3, r = i & 3;
+#pragma unroll
+    for (int o = 0; o < OB; ++o) {
+      if (o0 + o >= cout_pad) break;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const float v = (float)s[o][t];
+        mx = fmaxf(mx, fabsf(v));
+        wpk[((((size_t)chunk * 9 + t) * 4 + kq) * cout_pad + o0 + o) * 4 + r] = v;
+      }
+    }
+  }
+  if (blockIdx.y == 0) {   // b'[o] = bias[o] + sum_c (sum_t W[o][c][t]) b[c]
+    for (int o = 0; o < OB && o0 + o < cout_pad; ++o) {
+      double part = 0.;
+      for (int c = tid; c < cin; c += 256) {
+        double ws = 0.;
+        for (int t = 0; t < 9; ++t) ws += (double)wrow[o * row + c * 9 + t];
+        part += ws * b[c];
+      }
+      __syncthreads();
+      red[tid] = part;
+      __syncthreads();
+      for (int k = 128; k > 0; k >>= 1) { if (tid < k) red[tid] += red[tid + k]; __syncthreads(); }
+      if (tid == 0) bias_out[o0 + o] = (o0 + o < cout) ? (float)((double)bias[o0 + o] + red[0]) : 0.f;
+    }
+  }
+  for (int k = 32; k > 0; k >>= 1) mx = fmaxf(mx, __shfl_xor(mx, k));
+  if (maxbits && (tid & 63) == 0) atomicMax(maxbits, __float_as_uint(mx));
+}
+
 // 1x1 affine as a centre-tap-only 3x3: used by wct_apply / wct_transform (the un-fused drop-in surface)
 __global__ void pack_center_kernel(const double* M, const double* b, int C, int cout_pad, float* wpk, float* bias_out) {
   const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -160,6 +223,16 @@ hipError_t launch_fold_affine(const float* w, const float* bias, int cout, int c
   if (maxbits_dev) {
     hipError_t e = hipMemsetAsync(maxbits_dev, 0, sizeof(unsigned), s);
     if (e != hipSuccess) return e;
+  }
+  if (cin >= 256) {
+    constexpr int OB = 4;
+    const size_t lds = (size_t)OB * cin * 9 * sizeof(float);   // 73.7 KB at cin = 512
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fold_block_kernel<OB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    const int ipad = (cin + 15) / 16 * 16;
+    hipLaunchKernelGGL(fold_block_kernel<OB>, dim3((unsigned)((cout_pad + OB - 1) / OB), (unsigned)((ipad + 255) / 256)), dim3(256), lds, s, w, bias,
+                       cout, cin, cout_pad, M, b, wpk_out, bias_out, maxbits_dev);
+    return hipGetLastError();
   }
   hipLaunchKernelGGL(fold_row_kernel, dim3((unsigned)cout_pad), dim3(256), (size_t)cin * 9 * sizeof(float), s, w, bias, cout, cin, cout_pad, M, b,
                      wpk_out, bias_out, maxbits_dev);
