@@ -9,7 +9,7 @@ TAG=${1:-rXX}
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-CMD="python $PWD/bench.py --steps 4 --warmup 1 --no-cpu-baseline"
+CMD="python $PWD/bench.py --steps 4 --warmup 1 --no-cpu-baseline --steps-only"
 cd /tmp
 WCT_OVERLAP=0 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o stats -- $CMD > $OUT/stats_bench.log 2>&1 || echo "stats pass failed"
 WCT_OVERLAP=0 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o pmc -- $CMD > $OUT/pmc_fetch.log 2>&1 || echo "fetch pass failed"
