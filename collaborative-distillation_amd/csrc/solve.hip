@@ -781,8 +781,15 @@ hipError_t launch_eig(int C, double n, const double* sum, const double* sumsq, i
   w.dead = w.iters + 2;
   const bool big = C > 128 || (wide_model && C > 64 && ns_pad(C) % 64 == 0);   // deflated, scaled iteration + host check of the outcome
   static const int maxit_env = [] { const char* e = getenv("WCT_NS_MAXIT"); const int v = e ? atoi(e) : 0; return v < 1 ? 0 : (v > NS_MAXIT_REG ? NS_MAXIT_REG : v); }();
+  // 64 < Cp <= 128 without deflation (the 128-channel levels of --mode 16x): the iteration is scaled with an ASSUMED lower
+  // spectral bound 1e-5 (see the schedule below) -- a wrong guess costs iterations, never correctness (only the upper bound 1
+  // matters for safety, eigenvalues below the guess still grow 2.6x per scaled step) -- which reaches cond ~1e7 in 16
+  // iterations like the plain iteration in 26: 20 fewer always-enqueued stage launches per solve, 13/10 -> 11/11 executed
+  // iterations on the 4K bench frame, 1.4 % of a cached-style frame (A/B on one box, tools/experiments/ns_guess.py).
+  static const double guess_env = [] { const char* e = getenv("WCT_NS_GUESS"); return e ? atof(e) : -1.0; }();
+  const double guess = big || Cp <= 64 ? 0.0 : (guess_env >= 0. ? guess_env : 1e-5);
   // C > 128 (original mode): the deflated, optimally scaled iteration takes 19-20 iterations whatever the matrix
-  const int maxit = maxit_env ? maxit_env : (C > 128 ? 24 : NS_MAXIT);
+  const int maxit = maxit_env ? maxit_env : (C > 128 ? 24 : (guess > 0. ? 16 : NS_MAXIT));
   if (Cp <= 64) {
     // one workgroup, iterates in LDS (see ns_lds_kernel)
     auto go = [&](auto kern, int cp) -> hipError_t {
@@ -804,8 +811,7 @@ hipError_t launch_eig(int C, double n, const double* sum, const double* sumsq, i
     // then maps both ends of [x, 1] to the same value) -- small eigenvalues grow 6.75x per step instead of 2.25x and the
     // whole spectrum arrives together: 19 iterations for ANY matrix instead of 15 (cond 1e3) .. 39 (singular).  The schedule
     // depends on l0 alone, so it is computed here; numpy prototype: same accuracy as the plain iteration.
-    static const double guess_env = [] { const char* e = getenv("WCT_NS_GUESS"); return e ? atof(e) : 0.0; }();
-    double xlow = big ? sqrt(NS_DEFLATE / (1.0 + NS_DEFLATE)) : (guess_env > 0. ? sqrt(guess_env) : 1.0);
+    double xlow = big ? sqrt(NS_DEFLATE / (1.0 + NS_DEFLATE)) : (guess > 0. ? sqrt(guess) : 1.0);
     static const bool sk_env = [] { const char* e = getenv("WCT_NS_SPLITK"); return e ? atoi(e) != 0 : true; }();
     const bool splitk128 = sk_env && Cp % 64 == 0;
     for (int it = 0; it < maxit; ++it) {
