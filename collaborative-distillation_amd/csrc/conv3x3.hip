@@ -43,6 +43,7 @@ struct ConvArgs {
   int tiles_x, tiles_y;
   int up_in, relu;
   int out_sp;        // SP16 output (conv_f16_dev.h): the consumer is an f16x3 layer and takes the split as it is
+  unsigned* sat;     // sticky saturation counter of the context (SP16 output only), may be null
 };
 
 // reflect_clamp (ReflectionPad2d(1): -1 -> 1, n -> n-2; tiles hanging over the image edge are clamped, never stored) and
@@ -64,6 +65,7 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a) {
   const int tile = xcd_swizzle(blockIdx.x, ntiles);
   const int ty0 = (tile / a.tiles_x) * TH, tx0 = (tile % a.tiles_x) * TW;
   const int co0 = blockIdx.y * COW;
+  SatTrack sat;
 
   f32x4 acc[CT][PT];
 #pragma unroll
@@ -180,13 +182,14 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a) {
               a.out[2 * plane + off] = v[2];
             }
           } else if (co < a.cout) {
-            if (a.out_sp) sp16_store4(reinterpret_cast<char*>(a.out) + (size_t)(co >> 4) * sp16_plane_bytes(a.H, a.W) + ((size_t)gy * a.W + gx) * 64, kq, v);
+            if (a.out_sp) sp16_store4(reinterpret_cast<char*>(a.out) + (size_t)(co >> 4) * sp16_plane_bytes(a.H, a.W) + ((size_t)gy * a.W + gx) * 64, kq, v, sat, a.relu != 0);
             else *reinterpret_cast<f32x4*>(a.out + ((size_t)gy * a.W + gx) * a.cout + co) = v;
           }
         }
       }
     }
   }
+  sat.commit(a.sat);
 }
 
 template <int CT, bool IN3, bool POOL, bool OUT3>
@@ -215,6 +218,7 @@ hipError_t launch_conv3x3(const ConvDesc& d, const float* in, float* out, int H,
   a.tiles_x = (W + TW - 1) / TW; a.tiles_y = (H + TH - 1) / TH;
   a.relu = (d.flags & CONV_NO_RELU) ? 0 : 1;
   a.out_sp = (d.flags & CONV_OUT_SP16) ? 1 : 0;
+  a.sat = d.sat;
   const bool in3 = d.flags & CONV_IN_NCHW3, pool = d.flags & CONV_POOL_OUT, out3 = d.flags & CONV_OUT_NCHW3;
   if (a.out_sp && (pool || out3 || (d.cout & 15))) return hipErrorInvalidValue;   // SP16 from the plain epilogue only, whole 16-channel chunks
   if (H < 2 || W < 2) return hipErrorInvalidValue;  // reflect pad needs >= 2 samples

@@ -40,6 +40,7 @@ struct F16Args {
   int tiles_x, tiles_y;
   int up_in, relu;
   int in_sp, out_sp;   // SP16 input (16-byte groups taken as they are) / SP16 output (split in the epilogue)
+  unsigned* sat;       // sticky saturation counter of the context (may be null)
 };
 
 // stage one 16-channel chunk of the halo tile, converting fp32 -> (hi, lo) f16 planes.
@@ -73,7 +74,7 @@ __device__ __forceinline__ void fetch_act(const F16Args& a, ActRegs& r, int ch, 
 }
 
 template <int TH>
-__device__ __forceinline__ void commit_act(const F16Args& a, const ActRegs& r, u32x4* act, int ch, int tid) {
+__device__ __forceinline__ void commit_act(const F16Args& a, const ActRegs& r, u32x4* act, int ch, int tid, SatTrack& sat) {
   constexpr int NPH = nph(TH), NPP = npp(TH), NT = 32 * TH;
   const int cbase = ch * 16;
 #pragma unroll
@@ -85,7 +86,7 @@ __device__ __forceinline__ void commit_act(const F16Args& a, const ActRegs& r, u
       const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f}, w0 = ok ? r.v0[k] : z, w1 = ok ? r.v1[k] : z;
       f16x8 hi, lo;
       if (a.in_sp) { hi = __builtin_bit_cast(f16x8, w0); lo = __builtin_bit_cast(f16x8, w1); }   // the same 32 bytes hold [8 hi | 8 lo]
-      else split8(w0, w1, hi, lo);
+      else split8(w0, w1, hi, lo, sat);
       act[(0 * 2 + kh) * NPP + pix] = __builtin_bit_cast(u32x4, hi);
       act[(1 * 2 + kh) * NPP + pix] = __builtin_bit_cast(u32x4, lo);
     }
@@ -129,6 +130,7 @@ __global__ __launch_bounds__(32 * TH) void conv3x3_f16_kernel(F16Args a) {
   const int tile = xcd_swizzle(blockIdx.x, a.tiles_x * a.tiles_y);
   const int ty0 = (tile / a.tiles_x) * FTH, tx0 = (tile % a.tiles_x) * FTW;
   const int co0 = blockIdx.y * COW;
+  SatTrack sat;
 
   f32x16 acc[CT][2];
 #pragma unroll
@@ -161,7 +163,7 @@ __global__ __launch_bounds__(32 * TH) void conv3x3_f16_kernel(F16Args a) {
         wgt[e] = wsrc[(size_t)seg * a.cout_pad + co0 + j];
       }
     }
-    commit_act<TH>(a, ar, act, ch, tid);
+    commit_act<TH>(a, ar, act, ch, tid, sat);
     __syncthreads();
     if (ch + 1 < a.cin_chunks) {
       if constexpr (PREA) fetch_act<TH>(a, ar, ch + 1, ty0, tx0, tid);
@@ -216,7 +218,7 @@ __global__ __launch_bounds__(32 * TH) void conv3x3_f16_kernel(F16Args a) {
         const int oy = (ty0 + wave * 2) >> 1, ox = gx >> 1;
         const bool ok = !(li & 1) && oy < Hp && ox < Wp && co < a.cout;
         if (a.out_sp) {
-          const u32x4 w = sp16_pair_exchange(m);
+          const u32x4 w = sp16_pair_exchange(m, sat, a.relu != 0);
           if (ok) *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(a.out) + sp16_piece(sp16_plane_bytes(Hp, Wp), (size_t)oy * Wp + ox, co >> 3, kh)) = w;
         } else if (ok) {
           *reinterpret_cast<f32x4*>(a.out + ((size_t)oy * Wp + ox) * a.cout + co) = m;
@@ -233,7 +235,7 @@ __global__ __launch_bounds__(32 * TH) void conv3x3_f16_kernel(F16Args a) {
           }
           const bool ok = gy < a.H && gx < a.W && co < a.cout;
           if (a.out_sp) {
-            const u32x4 w = sp16_pair_exchange(v);
+            const u32x4 w = sp16_pair_exchange(v, sat, a.relu != 0);
             if (ok) *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(a.out) + sp16_piece(sp16_plane_bytes(a.H, a.W), (size_t)gy * a.W + gx, co >> 3, kh)) = w;
           } else if (ok) {
             *reinterpret_cast<f32x4*>(a.out + ((size_t)gy * a.W + gx) * a.cout + co) = v;
@@ -242,6 +244,7 @@ __global__ __launch_bounds__(32 * TH) void conv3x3_f16_kernel(F16Args a) {
       }
     }
   }
+  sat.commit(a.sat);
 }
 
 // ------------------------------------------------------------------------------------------------ Cout <= 16
@@ -255,6 +258,7 @@ __global__ __launch_bounds__(256) void conv3x3_f16_c16_kernel(F16Args a) {
   const int li = lane & 15, kq = lane >> 4, kh = kq & 1, ts = kq >> 1;
   const int tile = xcd_swizzle(blockIdx.x, a.tiles_x * a.tiles_y);
   const int ty0 = (tile / a.tiles_x) * FTH, tx0 = (tile % a.tiles_x) * FTW;
+  SatTrack sat;
 
   f32x4 acc[2][2];  // [row][half row]
 #pragma unroll
@@ -269,7 +273,7 @@ __global__ __launch_bounds__(256) void conv3x3_f16_c16_kernel(F16Args a) {
   fetch_w<NW, 16>(a, wr, 0, 0, tid);
   for (int ch = 0; ch < a.cin_chunks; ++ch) {
     if (ch) __syncthreads();
-    commit_act<8>(a, ar, act, ch, tid);
+    commit_act<8>(a, ar, act, ch, tid, sat);
     commit_w<NW>(wr, wgt, tid);
     __syncthreads();
     if (ch + 1 < a.cin_chunks) {
@@ -321,7 +325,7 @@ __global__ __launch_bounds__(256) void conv3x3_f16_c16_kernel(F16Args a) {
       }
       const int oy = (ty0 + wave * 2) >> 1, ox = gx >> 1;
       if (!(li & 1) && oy < Hp && ox < Wp && co < a.cout) {
-        if (a.out_sp) sp16_store4(reinterpret_cast<char*>(a.out) + ((size_t)oy * Wp + ox) * a.cout * 4, kq, m);
+        if (a.out_sp) sp16_store4(reinterpret_cast<char*>(a.out) + ((size_t)oy * Wp + ox) * a.cout * 4, kq, m, sat, a.relu != 0);
         else *reinterpret_cast<f32x4*>(a.out + ((size_t)oy * Wp + ox) * a.cout + co) = m;
       }
     } else {
@@ -343,13 +347,14 @@ __global__ __launch_bounds__(256) void conv3x3_f16_c16_kernel(F16Args a) {
               a.out[2 * plane + off] = v[2];
             }
           } else if (co < a.cout) {
-            if (a.out_sp) sp16_store4(reinterpret_cast<char*>(a.out) + ((size_t)gy * a.W + gx) * a.cout * 4, kq, v);
+            if (a.out_sp) sp16_store4(reinterpret_cast<char*>(a.out) + ((size_t)gy * a.W + gx) * a.cout * 4, kq, v, sat, a.relu != 0);
             else *reinterpret_cast<f32x4*>(a.out + ((size_t)gy * a.W + gx) * a.cout + co) = v;
           }
         }
       }
     }
   }
+  sat.commit(a.sat);
 }
 
 
@@ -370,6 +375,7 @@ struct HeadArgs {   // conv11 (3->16, conv0 folded) + ReLU -> conv12 (16->16) + 
   int H, W, tiles_x, tiles_y;
   int out_sp;
   unsigned tx_magic;   // tile_div_magic(tiles_x)
+  unsigned* sat;
 };
 
 // Persistent: a workgroup walks tiles v, v + grid, ...; the image window of the NEXT tile is fetched into registers
@@ -435,6 +441,7 @@ __global__ __launch_bounds__(256, 3) void enc_head_kernel(HeadArgs a) {
   }
 
   float pxr[2][3];
+  SatTrack sat;
   int v = blockIdx.x;
   int ty0 = 0, tx0 = 0;            // origin of the current tile (uniform; carried from the previous trip's look-ahead)
   if (v < ntiles) {
@@ -442,7 +449,7 @@ __global__ __launch_bounds__(256, 3) void enc_head_kernel(HeadArgs a) {
     tile_rc(xcd_swizzle(v, ntiles), a.tiles_x, a.tx_magic, tr, tc);
     ty0 = tr * 8; tx0 = tc * FTW;
     head_fetch(a.img, a.H, a.W, pxr, soff, ty0, tx0, tid);
-    head_commit(pxr, imgH, imgL, tid);
+    head_commit(pxr, imgH, imgL, tid, sat);
   }
   // per-lane part of the pooled output address: pixel li >> 1 of the half-tile, channels 4 kq .. 4 kq + 3
   const int out_lane = a.out_sp ? (li >> 1) * 64 + (kq >> 1) * 32 + (kq & 1) * 8 : ((li >> 1) * 16 + 4 * kq) * 4;
@@ -497,7 +504,7 @@ __global__ __launch_bounds__(256, 3) void enc_head_kernel(HeadArgs a) {
         f32x4 x;
 #pragma unroll
         for (int r = 0; r < 4; ++r) x[r] = fmaxf(acc[u][r] * a.inv11 + bias11[r], 0.f);
-        if (gok[i + u]) store_split4(act, NPP, gpix[i + u], kq, x);
+        if (gok[i + u]) store_split4(act, NPP, gpix[i + u], kq, x, sat);
       }
     }
     HT_STAMP(2);
@@ -528,7 +535,7 @@ __global__ __launch_bounds__(256, 3) void enc_head_kernel(HeadArgs a) {
         char* dst = orow + h * 8 * 64 + out_lane;
         if (a.out_sp) {
           u32x2 hi, lo;
-          split4(m, hi, lo);
+          split4(m, hi, lo, sat, true);
           *reinterpret_cast<u32x2*>(dst) = hi;
           *reinterpret_cast<u32x2*>(dst + 16) = lo;
         } else {
@@ -537,10 +544,11 @@ __global__ __launch_bounds__(256, 3) void enc_head_kernel(HeadArgs a) {
       }
     }
     HT_STAMP(5);
-    if (vn < ntiles) head_commit(pxr, imgH, imgL, tid);   // conv11 of this tile is behind the barrier above
+    if (vn < ntiles) head_commit(pxr, imgH, imgL, tid, sat);   // conv11 of this tile is behind the barrier above
     HT_STAMP(6);
     ty0 = nty0; tx0 = ntx0;
   }
+  sat.commit(a.sat);
 #ifdef WCT_HEAD_TIMING
   if (tid == 0) { for (int i = 0; i < 7; ++i) atomicAdd(&g_head_t[i], ht[i]); atomicAdd(&g_head_t[7], 1ull); }
 #endif
@@ -552,6 +560,7 @@ struct TailArgs {   // conv12 (16->16 on the nearest-x2 upsampled input) + ReLU 
   const u32x4* w11; const float* b11; float inv11;
   int H, W, inW, up_in, tiles_x, tiles_y;
   int in_sp;
+  unsigned* sat;
 };
 
 constexpr int TAIL_SL = (NPI2 * 2 + 255) / 256;  // 4 register slots of 8 channels per thread
@@ -586,14 +595,14 @@ __device__ __forceinline__ void tail_fetch(const TailArgs& a, unsigned txm, Tail
   }
 }
 
-__device__ __forceinline__ void tail_commit(const TailRegs& r, u32x4* act0, int tid, int in_sp) {
+__device__ __forceinline__ void tail_commit(const TailRegs& r, u32x4* act0, int tid, int in_sp, SatTrack& sat) {
 #pragma unroll
   for (int k = 0; k < TAIL_SL; ++k) {
     const int e = tid + 256 * k;
     if (e < NPI2 * 2) {
       f16x8 hi, lo;
       if (in_sp) { hi = __builtin_bit_cast(f16x8, r.v0[k]); lo = __builtin_bit_cast(f16x8, r.v1[k]); }
-      else split8(r.v0[k], r.v1[k], hi, lo);
+      else split8(r.v0[k], r.v1[k], hi, lo, sat);
       act0[(0 * 2 + (e & 1)) * NPI2 + (e >> 1)] = __builtin_bit_cast(u32x4, hi);
       act0[(1 * 2 + (e & 1)) * NPI2 + (e >> 1)] = __builtin_bit_cast(u32x4, lo);
     }
@@ -642,10 +651,11 @@ __global__ __launch_bounds__(256, 2) void dec_tail_kernel(TailArgs a) {
   }
 
   TailRegs tr;
+  SatTrack sat;
   int v = blockIdx.x;
   if (v < ntiles) {
     tail_fetch(a, txm, tr, soff, xcd_swizzle(v, ntiles), tid);
-    tail_commit(tr, act0, tid, a.in_sp);
+    tail_commit(tr, act0, tid, a.in_sp, sat);
   }
   for (; v < ntiles; v += gridDim.x) {
     const int tile = xcd_swizzle(v, ntiles);
@@ -698,7 +708,7 @@ __global__ __launch_bounds__(256, 2) void dec_tail_kernel(TailArgs a) {
         f32x4 x;
 #pragma unroll
         for (int r = 0; r < 4; ++r) x[r] = fmaxf(acc[u][r] * inv12 + bias12[r], 0.f);
-        if (gok[u]) store_split4(act1, NPP, gpix[u], kq, x);
+        if (gok[u]) store_split4(act1, NPP, gpix[u], kq, x, sat);
       }
     }
     __syncthreads();
@@ -725,8 +735,9 @@ __global__ __launch_bounds__(256, 2) void dec_tail_kernel(TailArgs a) {
         }
       }
     }
-    if (vn < ntiles) tail_commit(tr, act0, tid, a.in_sp);   // conv12 of this tile is behind the barrier above
+    if (vn < ntiles) tail_commit(tr, act0, tid, a.in_sp, sat);   // conv12 of this tile is behind the barrier above
   }
+  sat.commit(a.sat);
 }
 
 template <typename K>
@@ -804,6 +815,7 @@ hipError_t launch_enc_head(const ConvDesc& d0, const ConvDesc& d1, const float* 
   a.H = H; a.W = W; a.tiles_x = (W + FTW - 1) / FTW; a.tiles_y = (H + 7) / 8;
   a.tx_magic = tile_div_magic(a.tiles_x);
   a.out_sp = (d1.flags & CONV_OUT_SP16) ? 1 : 0;
+  a.sat = d1.sat;
   const size_t lds = (size_t)2 * IMG_E * 8 + (size_t)4 * npp(8) * 16 + 640 * 16;   // 39.7 KB: 4 workgroups per CU
   const int ntiles = a.tiles_x * a.tiles_y, grid = ntiles < 3 * num_cus() ? ntiles : 3 * num_cus();
   hipLaunchKernelGGL(enc_head_kernel, dim3(grid), dim3(256), lds, s, a);
@@ -818,6 +830,7 @@ hipError_t launch_dec_tail(const ConvDesc& d0, const ConvDesc& d1, const float* 
   a.w11 = reinterpret_cast<const u32x4*>(d1.wpk16); a.b11 = d1.bias; a.inv11 = d1.inv_scale;
   a.H = H; a.W = W; a.up_in = (d0.flags & CONV_UP_IN) ? 1 : 0; a.inW = a.up_in ? W / 2 : W;
   a.in_sp = (d0.flags & CONV_IN_SP16) ? 1 : 0;
+  a.sat = d1.sat;
   a.tiles_x = (W + FTW - 1) / FTW; a.tiles_y = (H + 7) / 8;
   const size_t lds = ((size_t)4 * NPI2 + 640 + (size_t)4 * npp(8) + 640) * 16;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(dec_tail_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -858,6 +871,7 @@ hipError_t launch_conv3x3_f16(const ConvDesc& d, const float* in, float* out, in
   a.tiles_x = (W + FTW - 1) / FTW; a.tiles_y = (H + 7) / 8;
   a.relu = (d.flags & CONV_NO_RELU) ? 0 : 1;
   a.in_sp = (d.flags & CONV_IN_SP16) ? 1 : 0; a.out_sp = (d.flags & CONV_OUT_SP16) ? 1 : 0;
+  a.sat = d.sat;
   const bool pool = d.flags & CONV_POOL_OUT, out3 = d.flags & CONV_OUT_NCHW3;
   if (out3 && a.out_sp) return hipErrorInvalidValue;
   const size_t act_b = (size_t)4 * npp(8) * 16;

@@ -53,6 +53,7 @@ struct SpArgs {
   int H, W, inW, inH;
   int cin, cout, cin_chunks, cout_pad, groups;
   int tiles_x, tiles_y, up_in, relu;
+  unsigned* sat;         // sticky saturation counter of the context (may be null)
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr;
@@ -87,6 +88,11 @@ __global__ __launch_bounds__(512) void conv3x3_sp_kernel(SpArgs a) {
   for (int e = tid; e < a.cout_pad; e += NWV * 64) biasL[e] = a.bias[e];
   const float inv = a.inv_scale_ptr ? *a.inv_scale_ptr : a.inv_scale;
   const size_t in_plane = sp16_plane_bytes(a.inH, a.inW);
+  // saturation record (conv_f16_dev.h SatTrack): this kernel sits at 256 VGPRs, and any per-lane running maximum spilled
+  // 7..18 of them (80 -> 92 us per launch of the 64-cout layers) -- so the "|x| > 65504" lane masks are OR-ed in SCALAR
+  // registers instead (v_cmp + s_or_b64 per value; the epilogue runs with all 64 lanes active)
+  unsigned long long satmask = 0ull;
+  SatTrack sat_unused;
 
   // ---- DMA of one job into a stage.  Activations: wave-instruction idx = wave + 8 i covers pixel block idx % 10 of
   // plane idx / 10; each lane's pixel offset for the wave's five blocks is recomputed when the tile changes.
@@ -171,7 +177,9 @@ __global__ __launch_bounds__(512) void conv3x3_sp_kernel(SpArgs a) {
     if constexpr (OUTF32) {
       if (ok) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.out) + ((size_t)oy * oW + ox) * a.cout + co) = x;
     } else {
-      const u32x4 w = sp16_pair_exchange(x);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) satmask |= __ballot(fabsf(x[k]) > 65504.f);
+      const u32x4 w = sp16_pair_exchange<false>(x, sat_unused, true);
       if (ok) *reinterpret_cast<u32x4*>(a.out + sp16_piece(sp16_plane_bytes(oH, oW), (size_t)oy * oW + ox, co >> 3, kh)) = w;
     }
   };
@@ -277,6 +285,7 @@ __global__ __launch_bounds__(512) void conv3x3_sp_kernel(SpArgs a) {
 #pragma unroll
     for (int k = 0; k < NPIECE; ++k) epilogue_piece(pend, k, pty0, ptx0, pgrp);
   }
+  if (satmask != 0ull && lane == 0 && a.sat) atomicAdd(a.sat, 1u);
 #ifdef WCT_SP_TIMING
   SP_STAMP(2);
   if (threadIdx.x == 0) for (int i = 0; i < 4; ++i) atomicAdd(&g_sp_t[i], spt[i]);
@@ -302,7 +311,7 @@ bool conv_sp_supported(const ConvDesc& d) {
   // same SP16 input): 32: 1.29 / 1.30, 32+pool: 0.72 / 0.59, 64: 1.90 / 1.95, 64+pool: 0.33 / 0.33, >=128: 1.31 / 1.70
   // -> default 29: everything but the pooled 32-cout layers (re-measured after the chunk-planar SP16 layout and the
   // per-XCD work units: 0.565 / 0.565 ms there now -- a tie, left as it was).
-  static const int mask = [] { const char* e = getenv("WCT_SP_DMA_MASK"); return e ? atoi(e) : 29; }();
+  static const int mask = [] { const char* e = wct_debug_env("WCT_SP_DMA_MASK"); return e ? atoi(e) : 29; }();
   const bool pool = d.flags & CONV_POOL_OUT;
   const int fam = d.cout_pad >= 128 ? 16 : d.cout_pad == 64 ? (pool ? 8 : 4) : (pool ? 2 : 1);
   if (!(mask & fam)) return false;
@@ -323,6 +332,7 @@ hipError_t launch_conv3x3_sp(const ConvDesc& d, const void* in, void* out, int H
   a.cin = d.cin; a.cout = d.cout; a.cin_chunks = d.cin_chunks; a.cout_pad = d.cout_pad;
   a.tiles_x = (W + FTW - 1) / FTW; a.tiles_y = (H + SPH - 1) / SPH;
   a.relu = (d.flags & CONV_NO_RELU) ? 0 : 1;
+  a.sat = d.sat;
   const bool pool = d.flags & CONV_POOL_OUT, f32 = !(d.flags & CONV_OUT_SP16);
   const int ct = (d.cout_pad % 64 == 0) ? 2 : 1;
   a.groups = d.cout_pad / (ct * 32);

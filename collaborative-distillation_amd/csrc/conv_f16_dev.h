@@ -30,7 +30,37 @@ __device__ __forceinline__ int xcd_swizzle(int bid, int n) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
-__device__ __forceinline__ void split8(const f32x4& a, const f32x4& b, f16x8& hi, f16x8& lo) {
+// ---- saturation tracking.  The split clamps to the f16 range (+-65504); a clamp that actually changes a value is a
+// deviation from the fp32 reference, so every clamp site feeds a per-thread running maximum and the kernel raises the
+// context's sticky counter once per thread at its end (wct_saturation_count).  Two forms, both 2 VALU per four values:
+//   note()     max |x| of the fp32 values (v_max3_f32 with |.| modifiers): exact (x > 65504), any sign
+//   note_hi()  packed-u16 max of the hi halves AFTER the conversion (v_pk_max_u16): needs only registers that are live
+//              anyway -- the DMA conv kernel sits at 256 VGPRs and spilled 18 of them with note().  hi == 0x7BFF means
+//              x >= 65488 (everything that rounds to the largest f16), i.e. it also fires in the last 0.02 % below the limit.
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+struct SatTrack {
+  float m = 0.f;
+  unsigned mu = 0u;
+  __device__ __forceinline__ void note(const f32x4& v) {
+    m = fmaxf(fmaxf(m, fabsf(v[0])), fabsf(v[1]));
+    m = fmaxf(fmaxf(m, fabsf(v[2])), fabsf(v[3]));
+  }
+  __device__ __forceinline__ void note3(float a, float b, float c) { m = fmaxf(fmaxf(m, fabsf(a)), fabsf(b)); m = fmaxf(m, fabsf(c)); }
+  // hi0 / hi1: two packed f16 pairs; nonneg (uniform): the values went through a ReLU, so their sign bits are clear
+  __device__ __forceinline__ void note_hi(unsigned hi0, unsigned hi1, bool nonneg) {
+    if (!nonneg) { hi0 &= 0x7fff7fffu; hi1 &= 0x7fff7fffu; }
+    u16x2 a = __builtin_bit_cast(u16x2, mu);
+    a = __builtin_elementwise_max(a, __builtin_bit_cast(u16x2, hi0));
+    a = __builtin_elementwise_max(a, __builtin_bit_cast(u16x2, hi1));
+    mu = __builtin_bit_cast(unsigned, a);
+  }
+  __device__ __forceinline__ void commit(unsigned* counter) const {
+    if (counter && (m > 65504.f || (mu & 0xffffu) >= 0x7BFFu || (mu >> 16) >= 0x7BFFu)) atomicAdd(counter, 1u);
+  }
+};
+
+__device__ __forceinline__ void split8(const f32x4& a, const f32x4& b, f16x8& hi, f16x8& lo, SatTrack& sat) {
+  sat.note(a); sat.note(b);
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     float x = j < 4 ? a[j] : b[j - 4];
@@ -57,7 +87,8 @@ __device__ __forceinline__ size_t sp16_piece(size_t plane_bytes, size_t pixel, i
 }
 
 // 4 consecutive channels -> (hi, lo) as 2 + 2 dwords
-__device__ __forceinline__ void split4(const f32x4& v, u32x2& hi, u32x2& lo) {
+template <bool TRACK = true>
+__device__ __forceinline__ void split4(const f32x4& v, u32x2& hi, u32x2& lo, SatTrack& sat, bool nonneg) {
   f16x4 h, l;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
@@ -67,15 +98,18 @@ __device__ __forceinline__ void split4(const f32x4& v, u32x2& hi, u32x2& lo) {
   }
   hi = __builtin_bit_cast(u32x2, h);
   lo = __builtin_bit_cast(u32x2, l);
+  if constexpr (TRACK) sat.note_hi(hi[0], hi[1], nonneg);
 }
 
 // 32x32 MFMA accumulator layout: lanes l and l + 32 hold channels 8q + {0..3} and 8q + {4..7} of the SAME pixel.
 // v_permlane32_swap hands the low lane both hi halves and the high lane both lo halves, so each lane writes one
 // 16-byte group: returns the 16 bytes this lane stores at  record + group * 32 + (lane >> 5) * 16.
 // Must be executed by all 64 lanes (no divergence).
-__device__ __forceinline__ u32x4 sp16_pair_exchange(const f32x4& v) {
+// TRACK = false: the caller keeps its own saturation record (the DMA kernel: wave-wide masks in scalar registers)
+template <bool TRACK = true>
+__device__ __forceinline__ u32x4 sp16_pair_exchange(const f32x4& v, SatTrack& sat, bool nonneg) {
   u32x2 hi, lo;
-  split4(v, hi, lo);
+  split4<TRACK>(v, hi, lo, sat, nonneg);
   const auto ra = __builtin_amdgcn_permlane32_swap(hi[0], lo[0], false, false);
   const auto rb = __builtin_amdgcn_permlane32_swap(hi[1], lo[1], false, false);
   return u32x4{ra[0], rb[0], ra[1], rb[1]};
@@ -83,9 +117,9 @@ __device__ __forceinline__ u32x4 sp16_pair_exchange(const f32x4& v) {
 
 // 16x16 MFMA accumulator layout: lane (pixel, kq) holds channels 4 kq .. 4 kq + 3 -> two 8-byte stores into the
 // pixel's record (group kq >> 1, half kq & 1)
-__device__ __forceinline__ void sp16_store4(char* record, int kq, const f32x4& v) {
+__device__ __forceinline__ void sp16_store4(char* record, int kq, const f32x4& v, SatTrack& sat, bool nonneg) {
   u32x2 hi, lo;
-  split4(v, hi, lo);
+  split4(v, hi, lo, sat, nonneg);
   char* g = record + (kq >> 1) * 32 + (kq & 1) * 8;
   *reinterpret_cast<u32x2*>(g) = hi;
   *reinterpret_cast<u32x2*>(g + 16) = lo;
@@ -152,10 +186,11 @@ __device__ __forceinline__ void head_fetch(const float* img, int H, int W, int t
   head_fetch(img, H, W, r, soff, tr * 8, tc * FTW, tid);
 }
 
-__device__ __forceinline__ void head_commit(const float (&r)[2][3], u32x2* imgH, u32x2* imgL, int tid) {
+__device__ __forceinline__ void head_commit(const float (&r)[2][3], u32x2* imgH, u32x2* imgL, int tid, SatTrack& sat) {
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
     const int e = tid + 256 * k;
+    sat.note3(r[k][0], r[k][1], r[k][2]);
     if (e < NPI2) {
       f16x4 h = {0, 0, 0, 0}, l = {0, 0, 0, 0};
 #pragma unroll
@@ -170,8 +205,9 @@ __device__ __forceinline__ void head_commit(const float (&r)[2][3], u32x2* imgH,
   }
 }
 
-__device__ __forceinline__ void store_split4(u32x4* planes, int npp, int pix, int kq, const f32x4& v) {
+__device__ __forceinline__ void store_split4(u32x4* planes, int npp, int pix, int kq, const f32x4& v, SatTrack& sat) {
   // 4 consecutive channels 4kq..4kq+3 of halo pixel `pix` -> 8 bytes in the hi plane and 8 in the lo plane
+  sat.note(v);
   _Float16 h[4], l[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {

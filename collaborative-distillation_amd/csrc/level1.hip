@@ -21,12 +21,14 @@ struct L1DecArgs {
   const u32x4* w2; const float* b2;          // folded decoder conv: [2 chunks][10 taps][hl][kh][16] x 16 B, bias [16]
   const float* inv2_ptr; float inv2;
   int H, W, tiles_x, tiles_y;
+  unsigned* sat;
 };
 
 struct L1EncArgs {
   const float* img; float* out;              // out: NHWC fp32 [H*W][C]
   L1Conv c;
   int C, H, W, tiles_x, tiles_y;
+  unsigned* sat;
 };
 
 // image -> relu1_1 (NHWC fp32)
@@ -49,10 +51,11 @@ __global__ __launch_bounds__(256, 3) void l1_encode_kernel(L1EncArgs a) {
     soff[k] = (e / I2W) * a.W + e % I2W;
   }
   float pxr[2][3];
+  SatTrack sat;
   int v = blockIdx.x;
   if (v < ntiles) {
     head_fetch(a.img, a.H, a.W, a.tiles_x, txm, pxr, soff, xcd_swizzle(v, ntiles), tid);
-    head_commit(pxr, imgH, imgL, tid);
+    head_commit(pxr, imgH, imgL, tid, sat);
   }
   for (; v < ntiles; v += gridDim.x) {
     const int tile = xcd_swizzle(v, ntiles);
@@ -77,8 +80,9 @@ __global__ __launch_bounds__(256, 3) void l1_encode_kernel(L1EncArgs a) {
         }
       }
     __syncthreads();
-    if (vn < ntiles) head_commit(pxr, imgH, imgL, tid);
+    if (vn < ntiles) head_commit(pxr, imgH, imgL, tid, sat);
   }
+  sat.commit(a.sat);
 }
 
 // image -> relu1_1 on the 34 x 10 halo (LDS, split f16) -> folded decoder conv (24 -> 3) + ReLU -> planar image
@@ -118,10 +122,11 @@ __global__ __launch_bounds__(256, 2) void l1_decode_kernel(L1DecArgs a) {
     gpx[u] = gpix[u] - gpy[u] * FHW;
   }
   float pxr[2][3];
+  SatTrack sat;
   int v = blockIdx.x;
   if (v < ntiles) {
     head_fetch(a.img, a.H, a.W, a.tiles_x, txm, pxr, soff, xcd_swizzle(v, ntiles), tid);
-    head_commit(pxr, imgH, imgL, tid);
+    head_commit(pxr, imgH, imgL, tid, sat);
   }
   for (; v < ntiles; v += gridDim.x) {
     const int tile = xcd_swizzle(v, ntiles);
@@ -145,7 +150,7 @@ __global__ __launch_bounds__(256, 2) void l1_decode_kernel(L1DecArgs a) {
 #pragma unroll
       for (int ct = 0; ct < 2; ++ct) {
         const f32x4 x = l1_conv_group(imgH, imgL, base, kq, w, ct);
-        if (gok[u]) store_split4(act + ct * 4 * NPP, NPP, gpix[u], kq, x);
+        if (gok[u]) store_split4(act + ct * 4 * NPP, NPP, gpix[u], kq, x, sat);
       }
     }
     __syncthreads();
@@ -173,8 +178,9 @@ __global__ __launch_bounds__(256, 2) void l1_decode_kernel(L1DecArgs a) {
         }
       }
     }
-    if (vn < ntiles) head_commit(pxr, imgH, imgL, tid);
+    if (vn < ntiles) head_commit(pxr, imgH, imgL, tid, sat);
   }
+  sat.commit(a.sat);
 }
 
 }  // namespace
@@ -189,6 +195,7 @@ hipError_t launch_l1_encode(const ConvDesc& e, const float* img, float* out, int
   a.img = img; a.out = out;
   a.c.w = reinterpret_cast<const u32x4*>(e.l1w16); a.c.b = e.l1bias; a.c.inv = e.l1inv;
   a.C = e.cout; a.H = H; a.W = W; a.tiles_x = (W + FTW - 1) / FTW; a.tiles_y = (H + 7) / 8;
+  a.sat = e.sat;
   const size_t lds = (size_t)2 * IMG_E * 8;
   const int ntiles = a.tiles_x * a.tiles_y, grid = ntiles < 3 * num_cus() ? ntiles : 3 * num_cus();
   hipLaunchKernelGGL(l1_encode_kernel, dim3(grid), dim3(256), lds, s, a);
@@ -205,6 +212,7 @@ hipError_t launch_l1_decode(const ConvDesc& e, const ConvDesc& dec0, const float
   a.c.w = reinterpret_cast<const u32x4*>(e.l1w16); a.c.b = e.l1bias; a.c.inv = e.l1inv;
   a.w2 = reinterpret_cast<const u32x4*>(dec0.wpk16); a.b2 = dec0.bias; a.inv2_ptr = dec0.inv_scale_ptr; a.inv2 = dec0.inv_scale;
   a.H = H; a.W = W; a.tiles_x = (W + FTW - 1) / FTW; a.tiles_y = (H + 7) / 8;
+  a.sat = e.sat;
   const size_t lds = (size_t)2 * IMG_E * 8 + ((size_t)2 * 4 * npp(8) + 2 * 640) * 16;   // 72.5 KB: 2 per CU
   hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(l1_decode_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (err != hipSuccess) return err;

@@ -208,6 +208,7 @@ struct L1MomArgs {
   int Cs;                // LDS row stride (floats): 48
   double* part_sq;       // [grid][3][256]
   double* part_sum;      // [grid][32]
+  unsigned* sat;         // sticky saturation counter of the context (image values beyond the f16 range), may be null
 };
 
 __global__ __launch_bounds__(256, 2) void l1_moments_kernel(L1MomArgs a) {
@@ -239,10 +240,11 @@ __global__ __launch_bounds__(256, 2) void l1_moments_kernel(L1MomArgs a) {
   }
   const int xhi = a.x1 < a.W ? a.x1 : a.W;
   float pxr[2][3];
+  SatTrack sat;
   int v = blockIdx.x;
   if (v < ntiles) {
     head_fetch(a.img, a.H, a.W, a.tiles_x, txm, pxr, soff, xcd_swizzle(v, ntiles), tid);
-    head_commit(pxr, imgH, imgL, tid);
+    head_commit(pxr, imgH, imgL, tid, sat);
   }
   for (; v < ntiles; v += gridDim.x) {
     const int tile = xcd_swizzle(v, ntiles);
@@ -269,8 +271,9 @@ __global__ __launch_bounds__(256, 2) void l1_moments_kernel(L1MomArgs a) {
     __syncthreads();
     const int st0 = wave * (MP / 16);
     tile_steps3(feat, a.Cs, st0, st0 + MP / 16, kq, offA, offB, acc[0], acc[1], acc[2], s[0], s[1], s[2]);
-    if (vn < ntiles) head_commit(pxr, imgH, imgL, tid);
+    if (vn < ntiles) head_commit(pxr, imgH, imgL, tid, sat);
   }
+  sat.commit(a.sat);
   // add the four waves' partial sets through LDS, fixed order (as moments_kernel's pixel-split tail)
   __syncthreads();
   double* red = reinterpret_cast<double*>(feat);   // [4][NP][256] + [4][T*16]
@@ -341,7 +344,7 @@ MomArgs plan(int C, long npix) {
   a.MP = std::min(256, (MAXLD * 256 * 4 / C) / 16 * 16);  // MP * C / 4 <= 8 * 256 float4 slots; multiple of 16
   const int MP = a.MP;
   a.npix = npix;
-  static long npc_target = [] { const char* e = getenv("WCT_MOM_NPC"); return e ? atol(e) : 512L; }();
+  static long npc_target = [] { const char* e = wct_debug_env("WCT_MOM_NPC"); return e ? atol(e) : 512L; }();
   long npc = npc_target / a.NPG;           // ~8 workgroups per CU in total
   if (a.NP > 16 && npc > 512) npc = 512;   // bound the partial buffer (NPC * NP * 2 KB)
   const long maxc = (npix + MP - 1) / MP;
@@ -409,6 +412,7 @@ hipError_t launch_l1_moments(const ConvDesc& e, const float* img, int H, int W, 
   a.c.w = reinterpret_cast<const u32x4*>(e.l1w16); a.c.b = e.l1bias; a.c.inv = e.l1inv;
   a.H = H; a.W = W; a.x0 = x0; a.x1 = x1; a.tiles_x = (W + FTW - 1) / FTW; a.tiles_y = (H + 7) / 8;
   a.Cs = 48;
+  a.sat = e.sat;
   const int ntiles = a.tiles_x * a.tiles_y, grid = ntiles < 2 * num_cus() ? ntiles : 2 * num_cus();
   a.part_sq = reinterpret_cast<double*>(ws);
   a.part_sum = a.part_sq + (size_t)grid * 3 * 256;

@@ -38,7 +38,7 @@ typedef double f64x2 __attribute__((ext_vector_type(2)));
 constexpr int MAX_SWEEPS = 40;
 constexpr double ROT_TOL = 1e-12;  // relative off-diagonal; quadratic convergence overshoots this by far
 constexpr double ABS_FLOOR = 1e-13;
-static const double REL_THRESH = [] { const char* e = getenv("WCT_REL_THRESH"); return e ? atof(e) : 1e-12; }();
+static const double REL_THRESH = [] { const char* e = wct_debug_env("WCT_REL_THRESH"); return e ? atof(e) : 1e-12; }();
 
 __device__ __forceinline__ void tournament_pair(int n, int round, int k, int& p, int& q) {
   // circle method: player n-1 stays, the others rotate
@@ -113,7 +113,7 @@ constexpr double NS_TOL = 1e-7;   // on max|ZY - I| BEFORE an update; the update
 // make of it (util_wct.py:117-120): ok stays 0 and the Jacobi path drops those directions (REL_THRESH, above).  Below it
 // every direction is genuine and kept, as the reference does; the iteration's error there is ~10 cond eps (8e-5 of max|M|
 // at lambda_min = 1e-11 lambda_max, tools/experiments/solve_cond.py).
-static const double NS_ZMAX = [] { const char* e = getenv("WCT_NS_ZMAX"); return e ? atof(e) : 1e6; }();
+static const double NS_ZMAX = [] { const char* e = wct_debug_env("WCT_NS_ZMAX"); return e ? atof(e) : 1e6; }();
 
 struct NsWs {           // carved from the eig workspace
   double* Y[2]; double* Z[2]; double* T;
@@ -780,13 +780,13 @@ hipError_t launch_eig(int C, double n, const double* sum, const double* sumsq, i
   w.ok = w.iters + 1;
   w.dead = w.iters + 2;
   const bool big = C > 128 || (wide_model && C > 64 && ns_pad(C) % 64 == 0);   // deflated, scaled iteration + host check of the outcome
-  static const int maxit_env = [] { const char* e = getenv("WCT_NS_MAXIT"); const int v = e ? atoi(e) : 0; return v < 1 ? 0 : (v > NS_MAXIT_REG ? NS_MAXIT_REG : v); }();
+  static const int maxit_env = [] { const char* e = wct_debug_env("WCT_NS_MAXIT"); const int v = e ? atoi(e) : 0; return v < 1 ? 0 : (v > NS_MAXIT_REG ? NS_MAXIT_REG : v); }();
   // 64 < Cp <= 128 without deflation (the 128-channel levels of --mode 16x): the iteration is scaled with an ASSUMED lower
   // spectral bound 1e-5 (see the schedule below) -- a wrong guess costs iterations, never correctness (only the upper bound 1
   // matters for safety, eigenvalues below the guess still grow 2.6x per scaled step) -- which reaches cond ~1e7 in 16
   // iterations like the plain iteration in 26: 20 fewer always-enqueued stage launches per solve, 13/10 -> 11/11 executed
   // iterations on the 4K bench frame, 1.4 % of a cached-style frame (A/B on one box, tools/experiments/ns_guess.py).
-  static const double guess_env = [] { const char* e = getenv("WCT_NS_GUESS"); return e ? atof(e) : -1.0; }();
+  static const double guess_env = [] { const char* e = wct_debug_env("WCT_NS_GUESS"); return e ? atof(e) : -1.0; }();
   const double guess = big || Cp <= 64 ? 0.0 : (guess_env >= 0. ? guess_env : 1e-5);
   // C > 128 (original mode): the deflated, optimally scaled iteration takes 19-20 iterations whatever the matrix
   const int maxit = maxit_env ? maxit_env : (C > 128 ? 24 : (guess > 0. ? 16 : NS_MAXIT));
@@ -812,7 +812,7 @@ hipError_t launch_eig(int C, double n, const double* sum, const double* sumsq, i
     // whole spectrum arrives together: 19 iterations for ANY matrix instead of 15 (cond 1e3) .. 39 (singular).  The schedule
     // depends on l0 alone, so it is computed here; numpy prototype: same accuracy as the plain iteration.
     double xlow = big ? sqrt(NS_DEFLATE / (1.0 + NS_DEFLATE)) : (guess > 0. ? sqrt(guess) : 1.0);
-    static const bool sk_env = [] { const char* e = getenv("WCT_NS_SPLITK"); return e ? atoi(e) != 0 : true; }();
+    static const bool sk_env = [] { const char* e = wct_debug_env("WCT_NS_SPLITK"); return e ? atoi(e) != 0 : true; }();
     const bool splitk128 = sk_env && Cp % 64 == 0;
     for (int it = 0; it < maxit; ++it) {
       if (big) {
@@ -901,7 +901,7 @@ hipError_t launch_eig(int C, double n, const double* sum, const double* sumsq, i
     }
   } else {
     const size_t lds = ((size_t)C * ((C + 31) / 32 * 32 + 2) + C) * sizeof(double) + (size_t)(C + 4) * sizeof(int);
-    static int lpp = [] { const char* e = getenv("WCT_JACOBI_LPP"); return e ? atoi(e) : 16; }();
+    static int lpp = [] { const char* e = wct_debug_env("WCT_JACOBI_LPP"); return e ? atoi(e) : 16; }();
     auto go = [&](auto kern, int LPPv) -> hipError_t {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return e;

@@ -69,9 +69,11 @@ struct wct_ctx {
   bool wide_model = false;  // a loaded encoder ends wider than 128 channels (--mode original): see launch_eig
   int l1fuse = 1;     // 1: level 1 of the 16x cascade without materialising relu1_1 (level1.hip)
   int sp = 1;         // 1: intermediate activations of the f16x3 path in SP16 (split at the producer, DMA-staged consumers)
+  int u8fuse = 1;     // 1: wct_stylize_u8 reads / writes uint8 inside the first / last kernel where one exists (reserved)
   int fuse = 1;       // 1: fused conv11+conv12+pool / conv12+conv11 kernels at the full-resolution ends of the 16x networks
   int overlap = 1;    // 1: style side on the side lane (overlaps the content side); 0: everything on the caller's stream
   int conv_mode = 1;  // 0: exact-fp32 MFMA everywhere; 1: split-f16 (f16x3) MFMA for all but the first conv
+  unsigned* sat_dev = nullptr;   // sticky saturation counter (conv_f16_dev.h SatTrack): threads that clamped an activation to +-65504
   // profiling
   bool prof = false;
   std::vector<ProfRec> recs;
@@ -98,9 +100,23 @@ int fail(wct_ctx* ctx, int code, const char* fmt, ...) {
                   #expr, hipGetErrorString(e__), __FILE__, __LINE__);                              \
   } while (0)
 
+// Every entry point runs with the context's device current and restores the caller's device on return: the process's
+// current device is the caller's (PyTorch's) state, and streams / allocations of a context live on ctx->device.
+struct DevGuard {
+  int prev = -1;
+  bool switched = false;
+  explicit DevGuard(const wct_ctx* ctx) {
+    if (!ctx) return;
+    if (hipGetDevice(&prev) == hipSuccess && prev != ctx->device) switched = hipSetDevice(ctx->device) == hipSuccess;
+  }
+  ~DevGuard() { if (switched) (void)hipSetDevice(prev); }
+  DevGuard(const DevGuard&) = delete;
+  DevGuard& operator=(const DevGuard&) = delete;
+};
+#define WCT_GUARD(ctx) DevGuard dev_guard__(ctx)
+
 int ensure(wct_ctx* ctx, DevBuf& b, size_t bytes) {
   if (b.cap >= bytes) return WCT_OK;
-  HIPCHK(ctx, hipSetDevice(ctx->device));
   if (b.p) {
     HIPCHK(ctx, hipStreamSynchronize(ctx->main.stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->side.stream));
@@ -613,26 +629,28 @@ int wct_create(int device, wct_ctx** out) {
   *out = nullptr;
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return WCT_ERR_HIP;
-  if (hipSetDevice(device) != hipSuccess) return WCT_ERR_HIP;
   wct_ctx* c = new (std::nothrow) wct_ctx();
   if (!c) return WCT_ERR_NOMEM;
   c->device = device;
-  if (const char* m = getenv("WCT_CONV_MODE")) c->conv_mode = (m[0] == '0' || !strcmp(m, "fp32")) ? 0 : 1;
-  if (const char* m = getenv("WCT_OVERLAP")) c->overlap = m[0] != '0';
-  if (const char* m = getenv("WCT_FUSE")) c->fuse = m[0] != '0';
-  if (const char* m = getenv("WCT_SP")) c->sp = m[0] != '0';
-  if (const char* m = getenv("WCT_L1FUSE")) c->l1fuse = m[0] != '0';
+  WCT_GUARD(c);
+  if (const char* m = wct_debug_env("WCT_CONV_MODE")) c->conv_mode = (m[0] == '0' || !strcmp(m, "fp32")) ? 0 : 1;
+  if (const char* m = wct_debug_env("WCT_OVERLAP")) c->overlap = m[0] != '0';
+  if (const char* m = wct_debug_env("WCT_FUSE")) c->fuse = m[0] != '0';
+  if (const char* m = wct_debug_env("WCT_SP")) c->sp = m[0] != '0';
+  if (const char* m = wct_debug_env("WCT_L1FUSE")) c->l1fuse = m[0] != '0';
   bool ok = hipStreamCreateWithFlags(&c->side.stream, hipStreamNonBlocking) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess;
   for (int l = 1; l <= 5 && ok; ++l) ok = hipEventCreateWithFlags(&c->ev_style[l], hipEventDisableTiming) == hipSuccess;
-  if (!ok) { delete c; return WCT_ERR_HIP; }
+  ok = ok && hipMalloc(reinterpret_cast<void**>(&c->sat_dev), 256) == hipSuccess && hipMemset(c->sat_dev, 0, 256) == hipSuccess;
+  if (!ok) { wct_destroy(c); return WCT_ERR_HIP; }
   *out = c;
   return WCT_OK;
 }
 
 void wct_destroy(wct_ctx* ctx) {
   if (!ctx) return;
-  (void)hipSetDevice(ctx->device);
+  {
+  WCT_GUARD(ctx);
   (void)hipStreamSynchronize(ctx->main.stream);
   (void)hipStreamSynchronize(ctx->side.stream);
   prof_collect(ctx);
@@ -647,6 +665,8 @@ void wct_destroy(wct_ctx* ctx) {
   }
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
   if (ctx->side.stream) (void)hipStreamDestroy(ctx->side.stream);
+  if (ctx->sat_dev) (void)hipFree(ctx->sat_dev);
+  }
   delete ctx;
 }
 
@@ -654,23 +674,54 @@ const char* wct_last_error(const wct_ctx* ctx) { return ctx ? ctx->err.c_str() :
 
 int wct_set_stream(wct_ctx* ctx, void* s) {
   if (!ctx) return WCT_ERR_INVALID;
+  WCT_GUARD(ctx);
   ctx->main.stream = reinterpret_cast<hipStream_t>(s);
   return WCT_OK;
 }
 
 int wct_sync(wct_ctx* ctx) {
   if (!ctx) return WCT_ERR_INVALID;
+  WCT_GUARD(ctx);
   HIPCHK(ctx, hipStreamSynchronize(ctx->side.stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->main.stream));
+  unsigned n = 0;
+  HIPCHK(ctx, hipMemcpy(&n, ctx->sat_dev, sizeof n, hipMemcpyDeviceToHost));
+  if (n) return fail(ctx, WCT_ERR_RANGE, "%u thread(s) clamped an activation to the f16x3 range (|x| > 65504): results deviate from the fp32 "
+                     "reference; use conv mode 0 (exact fp32) for these weights / inputs.  wct_saturation_count(ctx, 1, ..) resets the flag", n);
+  return WCT_OK;
+}
+
+int wct_saturation_count(wct_ctx* ctx, int reset, unsigned long long* count) {
+  if (!ctx) return WCT_ERR_INVALID;
+  WCT_GUARD(ctx);
+  HIPCHK(ctx, hipStreamSynchronize(ctx->side.stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->main.stream));
+  unsigned n = 0;
+  HIPCHK(ctx, hipMemcpy(&n, ctx->sat_dev, sizeof n, hipMemcpyDeviceToHost));
+  if (reset && n) HIPCHK(ctx, hipMemset(ctx->sat_dev, 0, sizeof n));
+  if (count) *count = n;
+  return WCT_OK;
+}
+
+int wct_debug_set(wct_ctx* ctx, const char* key, double value) {
+  if (!ctx || !key) return WCT_ERR_INVALID;
+  WCT_GUARD(ctx);
+  const int v = value != 0.0;
+  if (!strcmp(key, "fuse")) ctx->fuse = v;
+  else if (!strcmp(key, "sp")) ctx->sp = v;
+  else if (!strcmp(key, "l1fuse")) ctx->l1fuse = v;
+  else if (!strcmp(key, "u8fuse")) ctx->u8fuse = v;
+  else return fail(ctx, WCT_ERR_INVALID, "debug_set: unknown key '%s' (fuse, sp, l1fuse, u8fuse)", key);
+  HIPCHK(ctx, hipStreamSynchronize(ctx->side.stream));
   return WCT_OK;
 }
 
 int wct_load_module(wct_ctx* ctx, int kind, int level, int n_layers, const wct_layer* layers, const float* c0w,
                     const float* c0b) {
   if (!ctx) return WCT_ERR_INVALID;
+  WCT_GUARD(ctx);
   if ((kind != WCT_KIND_ENC && kind != WCT_KIND_DEC) || !valid_level(level) || n_layers < 1 || !layers)
     return fail(ctx, WCT_ERR_INVALID, "load_module: bad kind/level/layers (%d, %d, %d)", kind, level, n_layers);
-  HIPCHK(ctx, hipSetDevice(ctx->device));
   for (int i = 0; i < n_layers; ++i) {
     const wct_layer& L = layers[i];
     if (!L.weight || !L.bias || L.cin < 1 || L.cout < 1 || L.cin > 512 || L.cout > 512)
@@ -694,7 +745,7 @@ int wct_load_module(wct_ctx* ctx, int kind, int level, int n_layers, const wct_l
     const bool out3 = kind == WCT_KIND_DEC && i == n_layers - 1;
     ld.pool_after = L.pool_after; ld.up_after = L.up_after;
     ld.d.cin = L.cin; ld.d.cout = L.cout;
-    if (kind == WCT_KIND_ENC && i == n_layers - 1 && L.cout > 128) ctx->wide_model = true;
+    ld.d.sat = ctx->sat_dev;
     ld.d.cin_chunks = in3 ? 1 : (L.cin + 15) / 16;
     ld.d.cout_pad = pad_cout(L.cout);
     ld.d.flags = (in3 ? CONV_IN_NCHW3 : 0) | (out3 ? CONV_OUT_NCHW3 : 0) | (L.pool_after ? CONV_POOL_OUT : 0) |
@@ -736,6 +787,13 @@ int wct_load_module(wct_ctx* ctx, int kind, int level, int n_layers, const wct_l
     }
   }
   m.loaded = true;
+  // a loaded encoder ends wider than 128 channels (--mode original): recomputed over ALL loaded encoders on every load, so
+  // that re-loading narrower modules clears it
+  ctx->wide_model = false;
+  for (int l = 1; l <= 5; ++l) {
+    const Module& e = ctx->mod[WCT_KIND_ENC][l];
+    if (e.loaded && e.layers.back().d.cout > 128) ctx->wide_model = true;
+  }
   return WCT_OK;
 }
 
@@ -752,6 +810,7 @@ int wct_feature_shape(const wct_ctx* ctx, int level, int H, int W, int* C, int* 
 
 int wct_encode(wct_ctx* ctx, int level, const float* img, int H, int W, float* feat, int layout) {
   if (!ctx) return WCT_ERR_INVALID;
+  WCT_GUARD(ctx);
   if (!valid_level(level) || !img || !feat || H < 1 || W < 1) return fail(ctx, WCT_ERR_INVALID, "encode: bad arguments");
   if (layout == WCT_LAYOUT_NHWC) return encode_impl(ctx, ctx->main, level, img, H, W, feat, nullptr, nullptr);
   if (layout != WCT_LAYOUT_NCHW) return fail(ctx, WCT_ERR_INVALID, "encode: bad layout %d", layout);
@@ -765,6 +824,7 @@ int wct_encode(wct_ctx* ctx, int level, const float* img, int H, int W, float* f
 
 int wct_decode(wct_ctx* ctx, int level, const float* feat, int h, int w, int layout, float* img) {
   if (!ctx) return WCT_ERR_INVALID;
+  WCT_GUARD(ctx);
   if (!valid_level(level) || !img || !feat || h < 1 || w < 1) return fail(ctx, WCT_ERR_INVALID, "decode: bad arguments");
   Module& m = ctx->mod[WCT_KIND_DEC][level];
   if (!m.loaded) return fail(ctx, WCT_ERR_STATE, "decoder %d not loaded", level);
@@ -782,6 +842,7 @@ int wct_decode(wct_ctx* ctx, int level, const float* feat, int h, int w, int lay
 
 int wct_moments(wct_ctx* ctx, const float* feat, int C, int h, int w, int x0, int x1, double* sum, double* sumsq) {
   if (!ctx) return WCT_ERR_INVALID;
+  WCT_GUARD(ctx);
   if (!feat || !sum || !sumsq) return fail(ctx, WCT_ERR_INVALID, "moments: NULL pointer");
   return moments_impl(ctx, ctx->main, feat, C, h, w, x0, x1, sum, sumsq);
 }
@@ -789,6 +850,7 @@ int wct_moments(wct_ctx* ctx, const float* feat, int C, int h, int w, int x0, in
 int wct_solve(wct_ctx* ctx, int C, double n_c, const double* sum_c, const double* sumsq_c, double n_s,
               const double* sum_s, const double* sumsq_s, double alpha, double* M, double* b, int* info) {
   if (!ctx) return WCT_ERR_INVALID;
+  WCT_GUARD(ctx);
   if (!sum_c || !sumsq_c || !sum_s || !sumsq_s || !M || !b) return fail(ctx, WCT_ERR_INVALID, "solve: NULL pointer");
   SumsView sv;
   if (int rc = sums_view(ctx, ctx->main, sv)) return rc;
@@ -804,6 +866,7 @@ int wct_solve(wct_ctx* ctx, int C, double n_c, const double* sum_c, const double
 
 int wct_apply(wct_ctx* ctx, const float* feat, int C, int h, int w, int layout, const double* M, const double* b, float* out) {
   if (!ctx) return WCT_ERR_INVALID;
+  WCT_GUARD(ctx);
   if (!feat || !M || !b || !out || h < 2 || w < 2 || C < 4 || (C & 3) || C > 512) return fail(ctx, WCT_ERR_INVALID, "apply: bad arguments");
   const int cp = pad_cout(C), chunks = (C + 15) / 16;
   const size_t wfl = (size_t)chunks * 36 * cp * 4;
@@ -828,6 +891,7 @@ int wct_apply(wct_ctx* ctx, const float* feat, int C, int h, int w, int layout, 
 int wct_transform(wct_ctx* ctx, const float* cF, int C, int h, int w, const float* sF, int hs, int ws, float alpha,
                   int layout, float* out) {
   if (!ctx) return WCT_ERR_INVALID;
+  WCT_GUARD(ctx);
   if (!cF || !sF || !out || h < 1 || w < 1 || hs < 1 || ws < 1) return fail(ctx, WCT_ERR_INVALID, "transform: bad arguments");
   if (layout != WCT_LAYOUT_NHWC && layout != WCT_LAYOUT_NCHW) return fail(ctx, WCT_ERR_INVALID, "transform: bad layout %d", layout);
   if (h < 2 || w < 2) return fail(ctx, WCT_ERR_INVALID, "transform: feature %dx%d too small", h, w);
@@ -855,6 +919,7 @@ int wct_transform(wct_ctx* ctx, const float* cF, int C, int h, int w, const floa
 
 int wct_decode_affine(wct_ctx* ctx, int level, const float* feat, int h, int w, const double* M, const double* b, float* img) {
   if (!ctx) return WCT_ERR_INVALID;
+  WCT_GUARD(ctx);
   if (!valid_level(level) || !feat || !M || !b || !img) return fail(ctx, WCT_ERR_INVALID, "decode_affine: bad arguments");
   ConvDesc first;
   if (int rc = fold_impl(ctx, level, M, b, first)) return rc;
@@ -864,6 +929,7 @@ int wct_decode_affine(wct_ctx* ctx, int level, const float* feat, int h, int w, 
 int wct_style_transfer_level(wct_ctx* ctx, int level, const float* content, int H, int W, const float* style, int Hs,
                              int Ws, float alpha, float* out, int* Ho, int* Wo) {
   if (!ctx) return WCT_ERR_INVALID;
+  WCT_GUARD(ctx);
   if (!valid_level(level) || !content || !style || !out) return fail(ctx, WCT_ERR_INVALID, "style_transfer_level: bad arguments");
   if (int rc = fork_side(ctx)) return rc;
   if (int rc = style_side(ctx, level, style, Hs, Ws)) return rc;
@@ -874,6 +940,7 @@ int wct_style_transfer_level(wct_ctx* ctx, int level, const float* content, int 
 //      between wct_content_encode and wct_content_solve and may broadcast (M, b) before wct_content_decode.
 int wct_style_prepare_levels(wct_ctx* ctx, const float* style, int Hs, int Ws, unsigned level_mask) {
   if (!ctx) return WCT_ERR_INVALID;
+  WCT_GUARD(ctx);
   if (!style) return fail(ctx, WCT_ERR_INVALID, "style_prepare: NULL style");
   if (int rc = fork_side(ctx)) return rc;
   for (int level = 5; level >= 1; --level)
@@ -896,6 +963,7 @@ int wct_style_stats_count(const wct_ctx* ctx, int level, size_t* n_doubles) {
 // stats = cov_s^(1/2) [C*C] | mu_s [C]  (the two parts of the EigResult that launch_assemble consumes)
 int wct_style_export(wct_ctx* ctx, int level, double* stats) {
   if (!ctx) return WCT_ERR_INVALID;
+  WCT_GUARD(ctx);
   if (!valid_level(level) || !stats) return fail(ctx, WCT_ERR_INVALID, "style_export: bad arguments");
   Module& me = ctx->mod[WCT_KIND_ENC][level];
   if (!me.loaded || !ctx->eigS[level].p) return fail(ctx, WCT_ERR_STATE, "style_export: wct_style_prepare has not run for level %d", level);
@@ -910,6 +978,7 @@ int wct_style_export(wct_ctx* ctx, int level, double* stats) {
 
 int wct_style_import(wct_ctx* ctx, int level, const double* stats) {
   if (!ctx) return WCT_ERR_INVALID;
+  WCT_GUARD(ctx);
   if (!valid_level(level) || !stats) return fail(ctx, WCT_ERR_INVALID, "style_import: bad arguments");
   Module& me = ctx->mod[WCT_KIND_ENC][level];
   if (!me.loaded) return fail(ctx, WCT_ERR_STATE, "encoder %d not loaded", level);
@@ -926,6 +995,7 @@ int wct_style_import(wct_ctx* ctx, int level, const double* stats) {
 int wct_content_encode(wct_ctx* ctx, int level, const float* content, int H, int W, int x0, int x1, double* sum,
                        double* sumsq, int* h_out, int* w_out) {
   if (!ctx) return WCT_ERR_INVALID;
+  WCT_GUARD(ctx);
   if (!valid_level(level) || !content || !sum || !sumsq) return fail(ctx, WCT_ERR_INVALID, "content_encode: bad arguments");
   Module& me = ctx->mod[WCT_KIND_ENC][level];
   if (!me.loaded) return fail(ctx, WCT_ERR_STATE, "encoder %d not loaded", level);
@@ -954,6 +1024,7 @@ int wct_content_encode(wct_ctx* ctx, int level, const float* content, int H, int
 int wct_content_solve(wct_ctx* ctx, int level, double n_c, const double* sum_c, const double* sumsq_c, float alpha, double* M,
                       double* b) {
   if (!ctx) return WCT_ERR_INVALID;
+  WCT_GUARD(ctx);
   if (!valid_level(level) || !sum_c || !sumsq_c || !M || !b) return fail(ctx, WCT_ERR_INVALID, "content_solve: bad arguments");
   Module& me = ctx->mod[WCT_KIND_ENC][level];
   if (!me.loaded) return fail(ctx, WCT_ERR_STATE, "encoder %d not loaded", level);
@@ -968,6 +1039,7 @@ int wct_content_solve(wct_ctx* ctx, int level, double n_c, const double* sum_c, 
 
 int wct_content_decode(wct_ctx* ctx, int level, const double* M, const double* b, float* out, int* Ho, int* Wo) {
   if (!ctx) return WCT_ERR_INVALID;
+  WCT_GUARD(ctx);
   if (!valid_level(level) || !M || !b || !out) return fail(ctx, WCT_ERR_INVALID, "content_decode: bad arguments");
   if (ctx->cur_level != level) return fail(ctx, WCT_ERR_STATE, "content_decode: wct_content_encode(level %d) has not run", level);
   ConvDesc first;
@@ -1008,6 +1080,7 @@ int cascade(wct_ctx* ctx, const float* content, int H, int W, float alpha, int n
 int wct_stylize(wct_ctx* ctx, const float* content, int H, int W, const float* style, int Hs, int Ws, float alpha,
                 int num_run, float* out, int* Ho, int* Wo) {
   if (!ctx) return WCT_ERR_INVALID;
+  WCT_GUARD(ctx);
   if (!content || !style || !out || num_run < 1) return fail(ctx, WCT_ERR_INVALID, "stylize: bad arguments");
   // style side of all five levels first, on the side lane: it only depends on the style image (the SAME image at
   // every level and every run, WCT.py:121-125), so it is computed once and overlaps the content cascade
@@ -1020,6 +1093,7 @@ int wct_stylize(wct_ctx* ctx, const float* content, int H, int W, const float* s
 int wct_stylize_prepared(wct_ctx* ctx, const float* content, int H, int W, float alpha, int num_run, float* out, int* Ho,
                          int* Wo) {
   if (!ctx) return WCT_ERR_INVALID;
+  WCT_GUARD(ctx);
   if (!content || !out || num_run < 1) return fail(ctx, WCT_ERR_INVALID, "stylize_prepared: bad arguments");
   for (int level = 5; level >= 1; --level)
     if (!ctx->eigS[level].p) return fail(ctx, WCT_ERR_STATE, "stylize_prepared: no style statistics for level %d (wct_style_prepare / wct_style_import)", level);
@@ -1028,6 +1102,7 @@ int wct_stylize_prepared(wct_ctx* ctx, const float* content, int H, int W, float
 
 int wct_u8_to_planar(wct_ctx* ctx, const uint8_t* hwc, int H, int W, float* planar) {
   if (!ctx) return WCT_ERR_INVALID;
+  WCT_GUARD(ctx);
   if (!hwc || !planar || H < 1 || W < 1) return fail(ctx, WCT_ERR_INVALID, "u8_to_planar: bad arguments");
   ProfScope ps(ctx, ctx->main.stream, "u8_to_planar", 0, 15.0 * H * W);
   HIPCHK(ctx, launch_u8_to_planar(hwc, (long)H * W, planar, ctx->main.stream));
@@ -1036,6 +1111,7 @@ int wct_u8_to_planar(wct_ctx* ctx, const uint8_t* hwc, int H, int W, float* plan
 
 int wct_planar_to_u8(wct_ctx* ctx, const float* planar, int H, int W, uint8_t* hwc, int round_mode) {
   if (!ctx) return WCT_ERR_INVALID;
+  WCT_GUARD(ctx);
   if (!hwc || !planar || H < 1 || W < 1 || (round_mode != 0 && round_mode != 1)) return fail(ctx, WCT_ERR_INVALID, "planar_to_u8: bad arguments");
   ProfScope ps(ctx, ctx->main.stream, "planar_to_u8", 0, 15.0 * H * W);
   HIPCHK(ctx, launch_planar_to_u8(planar, (long)H * W, hwc, round_mode, ctx->main.stream));
@@ -1045,6 +1121,7 @@ int wct_planar_to_u8(wct_ctx* ctx, const float* planar, int H, int W, uint8_t* h
 int wct_stylize_u8(wct_ctx* ctx, const uint8_t* content_hwc, int H, int W, const uint8_t* style_hwc, int Hs, int Ws,
                    float alpha, int num_run, uint8_t* out_hwc, int* Ho, int* Wo, int round_mode) {
   if (!ctx) return WCT_ERR_INVALID;
+  WCT_GUARD(ctx);
   if (!content_hwc || !style_hwc || !out_hwc) return fail(ctx, WCT_ERR_INVALID, "stylize_u8: bad arguments");
   if (int rc = ensure(ctx, ctx->u8c, (size_t)3 * H * W * sizeof(float))) return rc;
   if (int rc = ensure(ctx, ctx->u8s, (size_t)3 * Hs * Ws * sizeof(float))) return rc;
@@ -1085,6 +1162,7 @@ size_t wct_workspace_bytes(const wct_ctx* ctx, int H, int W, int Hs, int Ws) {
 
 int wct_reserve(wct_ctx* ctx, int H, int W, int Hs, int Ws) {
   if (!ctx) return WCT_ERR_INVALID;
+  WCT_GUARD(ctx);
   size_t act = 0, acts = 0, featc = 0, feats = 0, momc = 0, moms = 0;
   int cmax = 2;
   for (int level = 1; level <= 5; ++level) {
@@ -1129,12 +1207,14 @@ int wct_reserve(wct_ctx* ctx, int H, int W, int Hs, int Ws) {
 
 int wct_set_numpy_variant(wct_ctx* ctx, int on) {
   if (!ctx) return WCT_ERR_INVALID;
+  WCT_GUARD(ctx);
   ctx->numpy_variant = on ? 1 : 0;
   return WCT_OK;
 }
 
 int wct_set_overlap(wct_ctx* ctx, int on) {
   if (!ctx) return WCT_ERR_INVALID;
+  WCT_GUARD(ctx);
   HIPCHK(ctx, hipStreamSynchronize(ctx->side.stream));
   ctx->overlap = on != 0;
   return WCT_OK;
@@ -1142,6 +1222,7 @@ int wct_set_overlap(wct_ctx* ctx, int on) {
 
 int wct_set_conv_mode(wct_ctx* ctx, int mode) {
   if (!ctx) return WCT_ERR_INVALID;
+  WCT_GUARD(ctx);
   if (mode != 0 && mode != 1) return fail(ctx, WCT_ERR_INVALID, "conv mode must be 0 (fp32) or 1 (f16x3)");
   ctx->conv_mode = mode;
   return WCT_OK;
@@ -1149,6 +1230,7 @@ int wct_set_conv_mode(wct_ctx* ctx, int mode) {
 
 int wct_profile_enable(wct_ctx* ctx, int on) {
   if (!ctx) return WCT_ERR_INVALID;
+  WCT_GUARD(ctx);
   if (!on) prof_collect(ctx);
   ctx->prof = on != 0;
   return WCT_OK;
@@ -1156,6 +1238,7 @@ int wct_profile_enable(wct_ctx* ctx, int on) {
 
 int wct_profile_reset(wct_ctx* ctx) {
   if (!ctx) return WCT_ERR_INVALID;
+  WCT_GUARD(ctx);
   prof_collect(ctx);
   ctx->prof_acc.clear();
   return WCT_OK;

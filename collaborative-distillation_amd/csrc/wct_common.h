@@ -4,8 +4,18 @@
 #include <stdint.h>
 #include <stddef.h>
 
+#include <stdlib.h>
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+// Experiment / debug switches read from the environment are honoured ONLY when WCT_DEBUG is set (to anything but "0"): a
+// stray WCT_* variable in a production environment must never change results.  Contexts have wct_debug_set() instead.
+static inline const char* wct_debug_env(const char* name) {
+  const char* g = getenv("WCT_DEBUG");
+  if (!g || !g[0] || (g[0] == '0' && !g[1])) return nullptr;
+  return getenv(name);
+}
 
 // ---- conv3x3 (reflect-pad + 3x3 conv + bias + ReLU, optional fused nearest-x2 input / 2x2 max-pool output)
 enum ConvFlags : int {
@@ -34,6 +44,9 @@ struct ConvDesc {
   const void* l1w16 = nullptr;
   const float* l1bias = nullptr;   // [32], zero padded
   float l1inv = 1.f;
+  // the context's sticky saturation counter (device): raised by the f16x3 kernels when an activation exceeded +-65504 and
+  // was clamped (conv_f16_dev.h SatTrack); may be null
+  unsigned* sat = nullptr;
 };
 
 // Launch one conv layer.  (H, W) = spatial size the convolution runs at (after the fused upsample,

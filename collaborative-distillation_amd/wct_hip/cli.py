@@ -148,7 +148,20 @@ def main(argv: Optional[List[str]] = None) -> int:
         else:
             for L, stats in style_cache[sfile].items():
                 wct.style_import(L, stats)
-        out = wct.to_u8(wct.stylize_prepared(wct.to_tensor_u8(c_u8), args.alpha, args.num_run), args.round_mode).cpu().numpy()   # .cpu() syncs
+        c_f32 = wct.to_tensor_u8(c_u8)
+        res = wct.stylize_prepared(c_f32, args.alpha, args.num_run)
+        if wct.saturation_count(reset=True):
+            # an activation left the f16x3 range (+-65504) and was clamped: a deviation from the fp32 reference -- never
+            # silent.  Recompute this pair with the exact-fp32 convolutions (style statistics included).
+            logprinter("WARNING: f16x3 range exceeded for this pair -> recomputing it with exact-fp32 convolutions")
+            wct.set_conv_mode("fp32")
+            style_img = wct.to_tensor_u8(s_u8 if s_u8 is not None else
+                                         torch.from_numpy(load_rgb_u8(os.path.join(style_dir, sfile), args.style_size)).cuda())
+            res = wct.stylize(c_f32, style_img, args.alpha, args.num_run)
+            wct.sync()
+            wct.set_conv_mode("f16x3")
+            style_cache.pop(sfile, None)          # its cached statistics may carry the clamp too
+        out = wct.to_u8(res, args.round_mode).cpu().numpy()   # .cpu() syncs
         path = out_name(args, imname)
         Image.fromarray(out).save(path)
         dt = time.time() - t0

@@ -12,13 +12,13 @@ _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # WCT_LIB_PATH: load an instrumented build of the same library (tools/experiments/sp_timing.sh); default = the in-tree build
 LIB_PATH = os.environ.get("WCT_LIB_PATH") or os.path.join(_PKG, "libwct_hip.so")
 
-WCT_OK, WCT_ERR_INVALID, WCT_ERR_HIP, WCT_ERR_NOMEM, WCT_ERR_STATE = 0, -1, -2, -3, -4
+WCT_OK, WCT_ERR_INVALID, WCT_ERR_HIP, WCT_ERR_NOMEM, WCT_ERR_STATE, WCT_ERR_RANGE = 0, -1, -2, -3, -4, -5
 KIND_ENC, KIND_DEC = 0, 1
 LAYOUT_NHWC, LAYOUT_NCHW = 0, 1
 
 # every symbol include/wct_hip.h declares (tests check that the built library exports all of them)
 SYMBOLS = [
-    "wct_version", "wct_create", "wct_destroy", "wct_last_error", "wct_set_stream", "wct_sync",
+    "wct_version", "wct_create", "wct_destroy", "wct_last_error", "wct_set_stream", "wct_sync", "wct_saturation_count", "wct_debug_set",
     "wct_load_module", "wct_feature_shape", "wct_encode", "wct_decode", "wct_moments", "wct_solve",
     "wct_apply", "wct_transform", "wct_decode_affine", "wct_style_transfer_level", "wct_stylize",
     "wct_style_prepare", "wct_content_encode", "wct_content_solve", "wct_content_decode",
@@ -70,6 +70,8 @@ def load() -> ctypes.CDLL:
     lib.wct_last_error.restype = c_char_p
     lib.wct_set_stream.argtypes = [c_void_p, c_void_p]
     lib.wct_sync.argtypes = [c_void_p]
+    lib.wct_saturation_count.argtypes = [c_void_p, c_int, POINTER(ctypes.c_ulonglong)]
+    lib.wct_debug_set.argtypes = [c_void_p, c_char_p, c_double]
     lib.wct_load_module.argtypes = [c_void_p, c_int, c_int, c_int, POINTER(WctLayer), fp, fp]
     lib.wct_feature_shape.argtypes = [c_void_p, c_int, c_int, c_int, ip, ip, ip]
     lib.wct_encode.argtypes = [c_void_p, c_int, vp, c_int, c_int, vp, c_int]
@@ -111,4 +113,6 @@ def check(lib, ctx, rc):
         msg = lib.wct_last_error(ctx).decode("utf-8", "replace") if ctx else "no context"
         if rc == WCT_ERR_INVALID:
             raise ValueError("libwct_hip: " + msg)
+        if rc == WCT_ERR_RANGE:
+            raise OverflowError("libwct_hip: " + msg)
         raise WctError(rc, msg)

@@ -170,7 +170,11 @@ def synth_weights(mode: str, seed: int) -> Dict[str, np.ndarray]:
     available (``original``: trained_models/original_wct_models/*.t7 are absent from the
     reference snapshot, README.md:26).  Used by tests, goldens (G6) and bench config 3.
     Only ``Generator.random`` (uniform doubles) is used so the stream is stable across
-    numpy versions."""
+    numpy versions.
+    (Orthogonalised / variance-preserving layers were tried as a better-conditioned alternative: the 5-level cascade of the
+    reference's own fp32 arithmetic sits 3.5e-3 from the exact fp64 result with either set at 384x384 -- random 512-channel
+    stacks are chaotic under the whitening whatever the init -- so end-to-end parity in this mode is judged against the fp64
+    "truth" arm, tests/test_hip_scale.py.)"""
     rng = np.random.default_rng(seed)
     w: Dict[str, np.ndarray] = {}
     for level in range(1, 6):

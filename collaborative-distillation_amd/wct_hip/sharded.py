@@ -6,12 +6,20 @@ coupling is (n, SUM x, SUM x x^T) of the content feature map (util_wct.py:68-70)
 
   * the content image is cut into `world` column strips whose origins are multiples of 16, so that all four
     2x2 pooling grids coincide with the untiled image's;
-  * rank r works on its strip plus a halo.  Halos are CUMULATIVE over the cascade: level L needs
-    A_L = (272, 112, 40, 16, 6)[5-L] extra columns per interior side, enough that after the level's own
-    encode->decode receptive field (160, 72, 24, 10, 2 columns) the still-exact region covers what
-    level L-1 needs.  Hence NO neighbour exchange between levels -- the halo is recomputed redundantly
-    (about +6% FLOPs at 3840-wide strips) and the result is bit-identical to the untiled cascade by
-    construction; reflect padding happens only at the true image borders;
+  * rank r works on its strip plus a halo; a level's encode->decode receptive field is (160, 72, 24, 10, 2) columns per
+    side at level 5..1 (LEVEL_HALO), reflect padding happens only at the true image borders, and with those
+    margins a strip's owned columns are bit-identical to the untiled level given the same (M, b).  Two ways to feed the
+    next level its halo (`halo_mode`):
+      "recompute"  halos are CUMULATIVE over the cascade: level L gets A_L = (272, 112, 40, 16, 6)[5-L] extra columns per
+                   interior side, enough that after the level's own receptive field the still-exact region covers what
+                   level L-1 needs.  NO neighbour exchange between levels; the extra columns cost FLOPs:
+                   2 A_L / strip width per level = +6 % of a frame at 3840-wide strips, +26 % at the 1280-wide strips of
+                   config 4 on 8 GPUs (42 % at level 5, which is 46 % of the FLOPs);
+      "exchange"   every level gets exactly its own margin (+15.6 % at 1280-wide strips) and, between levels, each rank
+                   sends its neighbours the (72, 24, 10, 2) outermost OWNED columns of the image it just decoded (exact
+                   there) -- two point-to-point messages per level boundary, 3 x H x halo fp32 (<= 3.5 MB at H = 4096) over
+                   xGMI -- SURVEY 8e's design;
+      "auto"       exchange for strips narrower than 2560 columns (config 4 on 8 GPUs), recompute otherwise;
   * moments are accumulated over OWNED columns only and summed with one all-reduce (fp64, C*C + C values:
     132 KB at C = 128, latency-bound on xGMI) per level;
   * the style side (five encodes + moments + matrix square roots, a third of a single-GPU step) depends only on the
@@ -37,6 +45,16 @@ import torch
 LEVEL_HALO = {5: 160, 4: 72, 3: 24, 2: 10, 1: 2}
 #: cumulative halo needed at the INPUT of level L (multiples of 2^(L-1); A_L - LEVEL_HALO[L] >= A_{L-1})
 CUM_HALO = {5: 272, 4: 112, 3: 40, 2: 16, 1: 6}
+#: strips narrower than this take the neighbour exchange under halo_mode="auto"
+AUTO_EXCHANGE_BELOW = 2560
+#: share of a frame's convolution FLOPs per level 5..1 (45 792 / 30 816 / 14 688 / 7 776 / 1 296 per pixel)
+LEVEL_FLOP_SHARE = {5: 0.456, 4: 0.307, 3: 0.146, 2: 0.077, 1: 0.013}
+
+
+def halo_flop_overhead(strip_width: int, mode: str) -> float:
+    """Extra convolution FLOPs of an interior strip relative to its owned columns (both sides carry a halo)."""
+    halo = CUM_HALO if mode == "recompute" else LEVEL_HALO
+    return sum(LEVEL_FLOP_SHARE[L] * 2.0 * halo[L] / strip_width for L in (5, 4, 3, 2, 1))
 
 
 def strip_bounds(W: int, world: int) -> List[Tuple[int, int]]:
@@ -55,7 +73,7 @@ def ext_bounds(own: Tuple[int, int], W: int, halo: int) -> Tuple[int, int]:
 
 class ShardedStylizer:
     def __init__(self, engine, dist, H: int, W_total: int, Hs: int, Ws: int, rank: Optional[int] = None,
-                 world: Optional[int] = None, alpha: float = 1.0, broadcast_map: bool = False):
+                 world: Optional[int] = None, alpha: float = 1.0, broadcast_map: bool = False, halo_mode: str = "auto"):
         self.e, self.dist = engine, dist
         self.broadcast_map = broadcast_map
         self.rank = dist.get_rank() if rank is None else rank
@@ -64,10 +82,64 @@ class ShardedStylizer:
         self.alpha = alpha
         self.bounds = strip_bounds(W_total, self.world)
         self.own = self.bounds[self.rank]
+        if halo_mode not in ("auto", "recompute", "exchange"):
+            raise ValueError("halo_mode must be auto, recompute or exchange")
+        narrowest = min(b[1] - b[0] for b in self.bounds)
+        if halo_mode == "auto":
+            halo_mode = "exchange" if (self.world > 1 and narrowest < AUTO_EXCHANGE_BELOW and narrowest >= 2 * LEVEL_HALO[4]) else "recompute"
+        if halo_mode == "exchange" and self.world > 1 and narrowest < 2 * LEVEL_HALO[4]:
+            # a neighbour must own the columns it is asked for (72 at most), also after the last strip's floor-pooling shrink
+            raise ValueError("halo_mode='exchange' needs strips of at least %d columns (narrowest: %d)" % (2 * LEVEL_HALO[4], narrowest))
+        self.halo_mode = halo_mode
+        self.halo = LEVEL_HALO if halo_mode == "exchange" else CUM_HALO
 
     def input_columns(self) -> Tuple[int, int]:
-        """Columns of the full content image this rank must be given (its strip + the level-5 halo)."""
-        return ext_bounds(self.own, self.W, CUM_HALO[5])
+        """Columns of the full content image this rank must be given (its strip + the level-5 halo of its halo mode)."""
+        return ext_bounds(self.own, self.W, self.halo[5])
+
+    # ---- neighbour exchange (halo_mode "exchange")
+    def _p2p(self, sends, recvs):
+        """sends: [(tensor, peer)], recvs: [(tensor, peer)] -- posted together, completed before returning.  NCCL (= RCCL):
+        one batched group on device buffers.  gloo has no device-side send/recv: staged through host memory."""
+        dist = self.dist
+        stage = dist.get_backend() != "nccl"
+        ops, staged = [], []
+        for t, peer in sends:
+            ops.append(dist.P2POp(dist.isend, t.cpu().contiguous() if stage else t.contiguous(), peer))
+        for t, peer in recvs:
+            buf = torch.empty(t.shape, dtype=t.dtype, device="cpu") if stage else t
+            staged.append((t, buf))
+            ops.append(dist.P2POp(dist.irecv, buf, peer))
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+        if stage:
+            for t, buf in staged:
+                t.copy_(buf)
+
+    def _exchange(self, out: torch.Tensor, lo: int, own: Tuple[int, int], W_cur: int, halo: int) -> Tuple[torch.Tensor, int]:
+        """`out` holds image columns [lo, lo + out.shape[-1]) of the level just decoded, exact on `own`.  Returns the next
+        level's input: `own` extended by `halo` columns per interior side, the extensions received from the neighbours
+        (their outermost owned columns), and its first column."""
+        rank, world = self.rank, self.world
+        owned = out[..., own[0] - lo:own[1] - lo]
+        nb = [(b[0], min(b[1], W_cur)) for b in self.bounds]          # every rank's owned range at this level
+        left_w = min(halo, nb[rank - 1][1] - nb[rank - 1][0]) if rank > 0 else 0
+        right_w = min(halo, nb[rank + 1][1] - nb[rank + 1][0]) if rank + 1 < world else 0
+        my_w = own[1] - own[0]
+        sends, recvs = [], []
+        if rank > 0:
+            sends.append((owned[..., :min(halo, my_w)], rank - 1))
+        if rank + 1 < world:
+            sends.append((owned[..., my_w - min(halo, my_w):], rank + 1))
+        shape = list(owned.shape)
+        left = torch.empty(shape[:-1] + [left_w], dtype=owned.dtype, device=owned.device)
+        right = torch.empty(shape[:-1] + [right_w], dtype=owned.dtype, device=owned.device)
+        if left_w:
+            recvs.append((left, rank - 1))
+        if right_w:
+            recvs.append((right, rank + 1))
+        self._p2p(sends, recvs)
+        return torch.cat([left, owned, right], dim=-1).contiguous(), own[0] - left_w
 
     @torch.no_grad()
     def stylize_strip(self, content_ext: torch.Tensor, style: torch.Tensor) -> torch.Tensor:
@@ -85,7 +157,8 @@ class ShardedStylizer:
         img = content_ext if content_ext.dim() == 4 else content_ext[None]
         W_cur = self.W                       # width of the (virtual) full image at the current level
         own = self.own
-        lo, hi = ext_bounds(own, W_cur, CUM_HALO[5])
+        halo, exchange = self.halo, self.halo_mode == "exchange" and self.world > 1
+        lo, hi = ext_bounds(own, W_cur, halo[5])
         assert img.shape[-1] == hi - lo, "expected columns [%d,%d) of the content" % (lo, hi)
         world, rank = self.world, self.rank
         owner = lambda lvl: (5 - lvl) % world           # rank 0 (the solver) owns level 5, the first one it needs
@@ -93,7 +166,8 @@ class ShardedStylizer:
         for L in (5, 4, 3, 2, 1):
             sh = L - 1
             # crop the running image to this level's extended strip
-            nlo, nhi = ext_bounds(own, W_cur, CUM_HALO[L])
+            nlo, nhi = ext_bounds(own, W_cur, halo[L])
+            assert lo <= nlo and nhi <= hi, (L, lo, hi, nlo, nhi)
             img = img[..., nlo - lo:nhi - lo].contiguous()
             lo, hi = nlo, nhi
             H_in, W_in = int(img.shape[-2]), int(img.shape[-1])
@@ -129,4 +203,8 @@ class ShardedStylizer:
             W_cur = (W_cur >> sh) << sh
             hi = lo + int(img.shape[-1])
             own = (own[0], min(own[1], W_cur))
+            if exchange and L > 1:
+                # the decoded strip is exact on the owned columns only: the next level's margin comes from the neighbours
+                img, lo = self._exchange(img, lo, own, W_cur, halo[L - 1])
+                hi = lo + int(img.shape[-1])
         return img[..., own[0] - lo:own[1] - lo].contiguous()

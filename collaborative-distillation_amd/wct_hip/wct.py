@@ -15,6 +15,7 @@ torch.distributed.  There is no CPU fallback.
 from __future__ import annotations
 
 import ctypes
+import logging
 import os
 from ctypes import c_size_t, byref, c_int, c_void_p
 from typing import Dict, Optional
@@ -25,6 +26,7 @@ import torch
 from . import lib as _lib
 from . import model_zoo
 
+_log = logging.getLogger("wct_hip")
 _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DEFAULT_16X_WEIGHTS = os.path.join(_PKG, "weights", "16x.npz")
 
@@ -36,7 +38,13 @@ def _fptr(a: np.ndarray):
 def _load_state(path: str) -> Dict[str, np.ndarray]:
     """A module's tensors from the reference's own checkpoint format (`{"epoch","model"}` or a bare
     state_dict, model_cd.py:712-718) -- torch is used for un-pickling only."""
-    sd = torch.load(path, map_location="cpu", weights_only=False)
+    try:
+        sd = torch.load(path, map_location="cpu", weights_only=True)   # plain tensors only: no arbitrary unpickling
+    except Exception as e:
+        if os.environ.get("WCT_ALLOW_UNSAFE_PICKLE") != "1":
+            raise RuntimeError("%s is not a plain tensor checkpoint (%s); set WCT_ALLOW_UNSAFE_PICKLE=1 to unpickle it "
+                               "with weights_only=False if you trust the file" % (path, e)) from e
+        sd = torch.load(path, map_location="cpu", weights_only=False)
     if isinstance(sd, dict) and "model" in sd:
         sd = sd["model"]
     return {k: v.detach().cpu().numpy().astype(np.float32) for k, v in sd.items()}
@@ -98,9 +106,18 @@ class WCT:
     def _weights_from_args(args, mode) -> Dict[str, np.ndarray]:
         paths = {("e%d" % k): getattr(args, "e%d" % k, None) for k in range(1, 6)}
         paths.update({("d%d" % k): getattr(args, "d%d" % k, None) for k in range(1, 6)})
-        have = [p for p in paths.values() if p and os.path.exists(p)]
+        have = {k: p for k, p in paths.items() if p and os.path.exists(p)}
+        if have and len(have) < 10:
+            # the reference fails in torch.load on the first missing file (model_cd.py:712-718); never stylise with a
+            # silent mix / substitute of weights
+            missing = ["%s=%s" % (k, paths[k]) for k in sorted(paths) if k not in have]
+            raise FileNotFoundError("checkpoints missing or not set for: " + ", ".join(missing))
         # per module: ".t7" (torch7, --mode original: model_original.py:24-30) or ".pth" (state_dict), as the reference asserts
-        if len(have) == 10 and all(p.endswith(".pth") or (p.endswith(".t7") and mode == "original") for p in have):
+        if len(have) == 10:
+            bad = [p for p in have.values() if not (p.endswith(".pth") or (p.endswith(".t7") and mode == "original"))]
+            if bad:
+                raise ValueError("unsupported checkpoint extension (expected .pth%s): %s" % (" or .t7" if mode == "original" else "", ", ".join(bad)))
+            _log.info("wct_hip: weights from the checkpoints in args.e1..d5 (%s ...)", paths["e1"])
             w = {}
             for key, p in paths.items():
                 if p.endswith(".t7"):
@@ -112,6 +129,7 @@ class WCT:
                         w["%s.%s" % (key, n)] = v
             return w
         if mode == "16x":
+            _log.info("wct_hip: no checkpoint path exists -> packaged 16x weights %s", DEFAULT_16X_WEIGHTS)
             return model_zoo.load_npz_weights(DEFAULT_16X_WEIGHTS)
         if mode == "16x_kd2sd":
             raise FileNotFoundError("mode '16x_kd2sd' needs trained_models/wct_se_16x_new_sd_kd2sd/{1..5}SD.pth (WCT.py:60-70; "
@@ -170,10 +188,42 @@ class WCT:
             x = x[0]
         if x.dim() != 3 or x.shape[0] != 3:
             raise ValueError("expected a [1,3,H,W] or [3,H,W] image, got %s" % (tuple(x.shape),))
-        return x.to(device="cuda:%d" % self.device, dtype=torch.float32).contiguous()
+        return self._dev_f32(x)
 
     def _chk(self, rc):
         _lib.check(self._lib, self._ctx, rc)
+
+    def saturation_count(self, reset: bool = False) -> int:
+        """Threads of the f16x3 kernels that clamped an activation to +-65504 since the last reset (a deviation from the
+        fp32 reference; synchronises the context's streams).  sync() raises OverflowError while it is non-zero."""
+        n = ctypes.c_ulonglong()
+        _lib.check(self._lib, self._ctx, self._lib.wct_saturation_count(self._ctx, int(reset), byref(n)))
+        return int(n.value)
+
+    def _dev_f32(self, x: torch.Tensor) -> torch.Tensor:
+        return x.to(device=self.stats_device, dtype=torch.float32).contiguous()
+
+    def _dev_f64(self, x: torch.Tensor, numel: int, what: str) -> torch.Tensor:
+        if x.numel() != numel:
+            raise ValueError("%s: expected %d values, got %d" % (what, numel, x.numel()))
+        return x.to(device=self.stats_device, dtype=torch.float64).contiguous()
+
+    def _nhwc(self, feat: torch.Tensor, C: Optional[int] = None) -> torch.Tensor:
+        f = feat[0] if feat.dim() == 4 else feat
+        if f.dim() != 3:
+            raise ValueError("expected an NHWC feature [1,h,w,C] or [h,w,C], got %s" % (tuple(feat.shape),))
+        if C is not None and int(f.shape[2]) != C:
+            raise ValueError("expected %d channels in the last (NHWC) dimension, got %s" % (C, tuple(f.shape)))
+        return self._dev_f32(f)
+
+    def _out_image(self, out: Optional[torch.Tensor], H: int, W: int) -> torch.Tensor:
+        """Caller-provided result buffer of stylize(): fp32, on this context's device, contiguous, >= 3*H*W values."""
+        if out is None:
+            return torch.empty((3, H, W), device=self.stats_device, dtype=torch.float32)
+        if out.dtype != torch.float32 or not out.is_cuda or out.device.index != self.device or not out.is_contiguous() \
+                or out.numel() < 3 * H * W:
+            raise ValueError("out must be a contiguous fp32 tensor on cuda:%d with at least %d values" % (self.device, 3 * H * W))
+        return out
 
     def feature_shape(self, level: int, H: int, W: int):
         C, h, w = c_int(), c_int(), c_int()
@@ -196,7 +246,9 @@ class WCT:
     @torch.no_grad()
     def decode(self, level: int, feat: torch.Tensor, layout: str = "nchw") -> torch.Tensor:
         f = feat[0] if feat.dim() == 4 else feat
-        f = f.to(device="cuda:%d" % self.device, dtype=torch.float32).contiguous()
+        if f.dim() != 3:
+            raise ValueError("expected a [1,C,h,w] / [C,h,w] (nchw) or [1,h,w,C] / [h,w,C] (nhwc) feature, got %s" % (tuple(feat.shape),))
+        f = self._dev_f32(f)
         nchw = layout == "nchw"
         C = model_zoo.feature_channels(self.mode, level)
         if nchw:
@@ -218,9 +270,9 @@ class WCT:
         csF [1,C,h,w] fp32 on the GPU.  If `csF` is given it is resized in place, filled and returned
         (the reference's `csF.data.resize_().copy_()`, which silently stopped working in torch>=1.1)."""
         alpha = self.alpha if alpha is None else float(alpha)
-        dev = "cuda:%d" % self.device
-        c = (cF[0] if cF.dim() == 4 else cF).to(device=dev, dtype=torch.float32).contiguous()
-        s = (sF[0] if sF.dim() == 4 else sF).to(device=dev, dtype=torch.float32).contiguous()
+        dev = self.stats_device
+        c = self._dev_f32(cF[0] if cF.dim() == 4 else cF)
+        s = self._dev_f32(sF[0] if sF.dim() == 4 else sF)
         if c.dim() != 3 or s.dim() != 3 or c.shape[0] != s.shape[0]:
             raise ValueError("transform expects cF [C,h,w] and sF [C,h',w'] with equal C")
         C, h, w = (int(v) for v in c.shape)
@@ -238,7 +290,7 @@ class WCT:
     @torch.no_grad()
     def moments(self, feat_nhwc: torch.Tensor, x0: int = 0, x1: Optional[int] = None):
         """Raw fp64 sums over columns [x0,x1) of an NHWC feature [1,h,w,C]: (n, sum[C], sumsq[C,C])."""
-        f = feat_nhwc[0] if feat_nhwc.dim() == 4 else feat_nhwc
+        f = self._nhwc(feat_nhwc)
         h, w, C = (int(v) for v in f.shape)
         x1 = w if x1 is None else x1
         s = torch.empty(C, device=f.device, dtype=torch.float64)
@@ -251,6 +303,8 @@ class WCT:
     def solve(self, n_c, sum_c, sumsq_c, n_s, sum_s, sumsq_s, alpha: Optional[float] = None, want_info=False):
         alpha = self.alpha if alpha is None else float(alpha)
         C = int(sum_c.numel())
+        sum_c, sumsq_c = self._dev_f64(sum_c, C, "sum_c"), self._dev_f64(sumsq_c, C * C, "sumsq_c")
+        sum_s, sumsq_s = self._dev_f64(sum_s, C, "sum_s"), self._dev_f64(sumsq_s, C * C, "sumsq_s")
         M = torch.empty(C, C, device=sum_c.device, dtype=torch.float64)
         b = torch.empty(C, device=sum_c.device, dtype=torch.float64)
         info = (c_int * 2)()
@@ -262,7 +316,9 @@ class WCT:
 
     @torch.no_grad()
     def decode_affine(self, level: int, feat_nhwc: torch.Tensor, M: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
-        f = feat_nhwc[0] if feat_nhwc.dim() == 4 else feat_nhwc
+        C = model_zoo.feature_channels(self.mode, level)
+        f = self._nhwc(feat_nhwc, C)
+        M, b = self._dev_f64(M, C * C, "M"), self._dev_f64(b, C, "b")
         h, w, _ = (int(v) for v in f.shape)
         out = torch.empty((1, 3, h << (level - 1), w << (level - 1)), device=f.device, dtype=torch.float32)
         self._stream()
@@ -290,7 +346,7 @@ class WCT:
         """Style statistics of a prepared level as one fp64 vector: cov_s^(1/2) [C*C] then mu_s [C]."""
         n = c_size_t()
         self._chk(self._lib.wct_style_stats_count(self._ctx, level, byref(n)))
-        buf = torch.empty(n.value, device="cuda", dtype=torch.float64)
+        buf = torch.empty(n.value, device=self.stats_device, dtype=torch.float64)
         self._stream()
         self._chk(self._lib.wct_style_export(self._ctx, level, buf.data_ptr()))
         return buf
@@ -300,7 +356,7 @@ class WCT:
         self._chk(self._lib.wct_style_stats_count(self._ctx, level, byref(n)))
         if stats.dtype != torch.float64 or not stats.is_cuda or stats.numel() != n.value:
             raise ValueError("style_import: expected %d fp64 values on the GPU" % n.value)
-        stats = stats.contiguous()
+        stats = stats.to(self.stats_device).contiguous()
         self._stream()
         self._chk(self._lib.wct_style_import(self._ctx, level, stats.data_ptr()))
 
@@ -312,21 +368,17 @@ class WCT:
         alpha = self.alpha if alpha is None else float(alpha)
         c = self._img(contentImg)
         H, W = int(c.shape[1]), int(c.shape[2])
-        if out is None:
-            out = torch.empty((3, H, W), device=c.device, dtype=torch.float32)
+        out = self._out_image(out, H, W)
         ho, wo = c_int(), c_int()
         self._stream()
         self._chk(self._lib.wct_stylize_prepared(self._ctx, c.data_ptr(), H, W, alpha, int(num_run), out.data_ptr(), byref(ho), byref(wo)))
         return out.view(-1)[: 3 * ho.value * wo.value].view(1, 3, ho.value, wo.value)
 
     # ------------------------------------------------------------------ image edge (ToTensor / save_image on the device)
-    @staticmethod
-    def _u8(img: torch.Tensor) -> torch.Tensor:
+    def _u8(self, img: torch.Tensor) -> torch.Tensor:
         if img.dtype != torch.uint8 or img.dim() != 3 or img.shape[2] != 3:
             raise ValueError("expected a uint8 H x W x 3 image, got %s %s" % (img.dtype, tuple(img.shape)))
-        if not img.is_cuda:
-            img = img.cuda()
-        return img.contiguous()
+        return img.to(self.stats_device).contiguous()
 
     @torch.no_grad()
     def to_tensor_u8(self, img_u8: torch.Tensor) -> torch.Tensor:
@@ -379,7 +431,8 @@ class WCT:
     @torch.no_grad()
     def content_solve(self, level: int, n_c: float, sum_c: torch.Tensor, sumsq_c: torch.Tensor, alpha: Optional[float] = None):
         alpha = self.alpha if alpha is None else float(alpha)
-        C = int(sum_c.numel())
+        C = model_zoo.feature_channels(self.mode, level)
+        sum_c, sumsq_c = self._dev_f64(sum_c, C, "sum_c"), self._dev_f64(sumsq_c, C * C, "sumsq_c")
         M = torch.empty(C, C, device=sum_c.device, dtype=torch.float64)
         b = torch.empty(C, device=sum_c.device, dtype=torch.float64)
         self._stream()
@@ -389,7 +442,8 @@ class WCT:
     @torch.no_grad()
     def content_decode(self, level: int, M: torch.Tensor, b: torch.Tensor, H: int, W: int) -> torch.Tensor:
         """H, W: size of the image wct.content_encode() was given (the output is floor-shrunk like the reference's)."""
-        _, h, w = self.feature_shape(level, H, W)
+        C, h, w = self.feature_shape(level, H, W)
+        M, b = self._dev_f64(M, C * C, "M"), self._dev_f64(b, C, "b")
         out = torch.empty((1, 3, h << (level - 1), w << (level - 1)), device=M.device, dtype=torch.float32)
         ho, wo = c_int(), c_int()
         self._stream()
@@ -421,8 +475,7 @@ class WCT:
         alpha = self.alpha if alpha is None else float(alpha)
         c, s = self._img(contentImg), self._img(styleImg)
         H, W, Hs, Ws = int(c.shape[1]), int(c.shape[2]), int(s.shape[1]), int(s.shape[2])
-        if out is None:
-            out = torch.empty((3, H, W), device=c.device, dtype=torch.float32)
+        out = self._out_image(out, H, W)
         ho, wo = c_int(), c_int()
         self._stream()
         self._chk(self._lib.wct_stylize(self._ctx, c.data_ptr(), H, W, s.data_ptr(), Hs, Ws, alpha, int(num_run),
@@ -432,6 +485,10 @@ class WCT:
     def set_conv_mode(self, mode: str):
         """'f16x3' (default: split-f16 MFMA, fp32-class accuracy) or 'fp32' (exact fp32 MFMA)."""
         self._chk(self._lib.wct_set_conv_mode(self._ctx, {"fp32": 0, "f16x3": 1}[mode]))
+
+    def debug_set(self, key: str, value) -> None:
+        """Experiment switches of the context ("fuse", "sp", "l1fuse", "u8fuse"): kernel formulations of the same operators."""
+        self._chk(self._lib.wct_debug_set(self._ctx, key.encode(), float(value)))
 
     def set_overlap(self, on: bool):
         self._chk(self._lib.wct_set_overlap(self._ctx, int(on)))

@@ -32,6 +32,7 @@ extern "C" {
 #define WCT_ERR_HIP (-2)     /* a HIP runtime call failed */
 #define WCT_ERR_NOMEM (-3)   /* device allocation failed */
 #define WCT_ERR_STATE (-4)   /* module for this level not loaded */
+#define WCT_ERR_RANGE (-5)   /* an activation left the f16x3 range (+-65504) and was clamped: results deviate from fp32 */
 
 #define WCT_KIND_ENC 0
 #define WCT_KIND_DEC 1
@@ -67,7 +68,22 @@ int wct_create(int device, wct_ctx** out);
 void wct_destroy(wct_ctx* ctx);
 const char* wct_last_error(const wct_ctx* ctx);
 int wct_set_stream(wct_ctx* ctx, void* hip_stream); /* hipStream_t; NULL = default stream */
+/* waits for both of the context's streams; returns WCT_ERR_RANGE when the sticky saturation flag is raised (below) */
 int wct_sync(wct_ctx* ctx);
+
+/* Range check of the f16x3 arithmetic (wct_set_conv_mode 1, the default).  The reference computes its convolutions in fp32
+ * (model/model_cd.py:724-743: plain nn.Conv2d); the split-f16 kernels represent an activation as hi + lo in f16 and clamp
+ * it to +-65504.  A clamp that actually changed a value is a deviation from the reference, so every clamp site raises a
+ * sticky per-context device counter (threads that saw |x| > 65504).  wct_saturation_count synchronises the context and
+ * returns it (count may be NULL), clearing it when reset != 0; wct_sync reports a raised flag as WCT_ERR_RANGE.  Conv
+ * mode 0 (exact fp32 MFMA) has no such limit. */
+int wct_saturation_count(wct_ctx* ctx, int reset, unsigned long long* count);
+
+/* Context-level experiment switches (tests, A/B measurements): key in {"fuse", "sp", "l1fuse", "u8fuse"}, value 0 / 1.  They select
+ * between kernel formulations of the same operators (fused full-resolution ends, SP16 intermediates, level 1 without
+ * relu1_1 in HBM); results agree to fp32 round-off or bitwise (tests/test_hip_parity.py).  Environment variables WCT_*
+ * are honoured only when WCT_DEBUG is set. */
+int wct_debug_set(wct_ctx* ctx, const char* key, double value);
 
 /* replaces SmallEncoder{L}_16x_aux(path) / SmallDecoder{L}_16x(path) / Encoder{L} / Decoder{L} construction
  * (util_wct.py:36-55; model_cd.py:712-718).  conv0_w [3*3] / conv0_b [3] (HOST): the encoder's 1x1 colour
@@ -161,9 +177,11 @@ int wct_reserve(wct_ctx* ctx, int H, int W, int Hs, int Ws);
 
 /* arithmetic of the 3x3 convolutions (all but the HBM-bound 3-channel first conv):
  *   1 (default)  split-f16 "f16x3" MFMA: x = hi + lo in f16, w.x ~ hi.hi + hi.lo + lo.hi, fp32 accumulate --
- *                fp32-class accuracy (6e-7 vs 8e-7 for exact fp32 on K = 1152 dot products) at 3/16 of the issue time
+ *                fp32-class accuracy (6e-7 vs 8e-7 for exact fp32 on K = 1152 dot products) at 3/16 of the issue time;
+ *                operands are ~22-bit (two f16 terms), the lo.lo product is dropped, accumulation is fp32, activations
+ *                beyond +-65504 are clamped and flagged (wct_saturation_count)
  *   0            exact fp32 MFMA (v_mfma_f32_16x16x4_f32)
- * env WCT_CONV_MODE=0|fp32 selects 0 at wct_create. */
+ * (env WCT_CONV_MODE=0|fp32 selects 0 at wct_create when WCT_DEBUG is set.) */
 int wct_set_conv_mode(wct_ctx* ctx, int mode);
 
 /* `--numpy` of the reference (WCT.py:34, util_wct.py:204-208): whiten_and_color_np adds the identity to the CONTENT

@@ -98,6 +98,62 @@ int oracle_conv3x3_reflect(const float* x, int C, int H, int W, const float* w, 
   return 0;
 }
 
+/* ---- fp64 arm ("truth"): the same operators with double tensors and double accumulation.  Not a restatement of
+ * anything the reference runs (its convolutions are fp32, model_cd.py) -- it is the yardstick against which the
+ * tests measure how far the fp32 reference arithmetic itself, and the HIP path, sit from the exact result
+ * (tests/test_hip_parity.py::test_error_budget_vs_fp64_truth). */
+__attribute__((target_clones("default", "avx2", "avx512f")))
+void oracle_row_fma3_f64(double* out, const double* in, double w0, double w1, double w2, int W) {
+  for (int xx = 0; xx < W; ++xx) {
+    double a = out[xx];
+    a += w0 * in[xx];
+    a += w1 * in[xx + 1];
+    a += w2 * in[xx + 2];
+    out[xx] = a;
+  }
+}
+
+int oracle_conv3x3_reflect_f64(const double* x, int C, int H, int W, const float* w, const float* b,
+                               int K, int relu, double* y) {
+  if (H < 2 || W < 2) return -1;
+  const int Wp = W + 2, Hp = H + 2;
+  double* xp = (double*)malloc((size_t)C * Hp * Wp * sizeof(double));
+  if (!xp) return -2;
+#pragma omp parallel for schedule(static)
+  for (int c = 0; c < C; ++c)
+    for (int yy = 0; yy < Hp; ++yy) {
+      const double* src = x + ((size_t)c * H + reflect(yy - 1, H)) * W;
+      double* dst = xp + ((size_t)c * Hp + yy) * Wp;
+      dst[0] = src[1];
+      memcpy(dst + 1, src, (size_t)W * sizeof(double));
+      dst[W + 1] = src[W - 2];
+    }
+  const int RB = 4;
+  const int nblk = (H + RB - 1) / RB;
+#pragma omp parallel for schedule(dynamic, 1)
+  for (int blk = 0; blk < nblk; ++blk) {
+    const int y0 = blk * RB, y1 = (y0 + RB < H) ? y0 + RB : H;
+    for (int k = 0; k < K; ++k) {
+      for (int yy = y0; yy < y1; ++yy) {
+        double* out = y + ((size_t)k * H + yy) * W;
+        const double bias = b ? (double)b[k] : 0.0;
+        for (int xx = 0; xx < W; ++xx) out[xx] = bias;
+        for (int c = 0; c < C; ++c) {
+          const float* wk = w + ((size_t)k * C + c) * 9;
+          for (int ky = 0; ky < 3; ++ky) {
+            const double* in = xp + ((size_t)c * Hp + yy + ky) * Wp;
+            oracle_row_fma3_f64(out, in, (double)wk[ky * 3 + 0], (double)wk[ky * 3 + 1], (double)wk[ky * 3 + 2], W);
+          }
+        }
+        if (relu)
+          for (int xx = 0; xx < W; ++xx) out[xx] = out[xx] > 0.0 ? out[xx] : 0.0;
+      }
+    }
+  }
+  free(xp);
+  return 0;
+}
+
 /* y[K,H,W] = bias + sum_c w[k,c] x[c]  (1x1 conv, no activation) */
 int oracle_conv1x1(const float* x, int C, int H, int W, const float* w, const float* b, int K, float* y) {
   const size_t n = (size_t)H * W;

@@ -20,8 +20,21 @@ def pytest_configure(config):
 
 
 def pytest_collection_modifyitems(config, items):
-    # `-m gpu` on a box without a GPU is a configuration error, not a skip: fail loudly there.
-    pass
+    """Plain `pytest tests` on a box without a GPU runs the CPU suite: gpu-marked tests are skipped there.  An explicit
+    `-m gpu` on such a box is a configuration error, not a skip -- those tests then fail loudly (no CPU fallback exists)."""
+    if config.getoption("-m"):
+        return
+    try:
+        import torch
+        have_gpu = torch.cuda.is_available()
+    except Exception:
+        have_gpu = False
+    if have_gpu:
+        return
+    skip = pytest.mark.skip(reason="needs the MI355X (select with -m gpu on the GPU box)")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
 
 
 @pytest.fixture(scope="session")

@@ -64,3 +64,40 @@ def test_product_does_not_import_oracle():
             if f.endswith((".py", ".hip", ".h", ".sh", ".cpp")):
                 src = open(os.path.join(root, f)).read()
                 assert not bad.search(src), os.path.join(root, f)
+
+
+def test_checkpoint_paths_never_fall_back_silently(tmp_path, weights16x):
+    """with SOME of args.e1..d5 present the reference would fail in torch.load (model_cd.py:712-718); the mirror
+    must not substitute the packaged weights for a partial / mistyped set.  No path at all (the reference snapshot's layout
+    is absent) -> the packaged 16x blob; a complete set -> exactly those tensors, aux heads dropped."""
+    import torch
+    from wct_hip.wct import WCT
+    args = types.SimpleNamespace(mode="16x")
+    for k in range(1, 6):
+        for key in ("e%d" % k, "d%d" % k):
+            sd = {n[len(key) + 1:]: torch.from_numpy(v.copy()) for n, v in weights16x.items() if n.startswith(key + ".")}
+            if key[0] == "e":
+                sd["conv%d1_aux.weight" % k] = torch.zeros(2, 2, 1, 1)
+            path = str(tmp_path / (key + ".pth"))
+            torch.save({"epoch": 20, "model": sd} if k % 2 else sd, path)
+            setattr(args, key, path)
+    w = WCT._weights_from_args(args, "16x")
+    assert sorted(w) == sorted(weights16x) and all((w[k] == weights16x[k]).all() for k in w)
+    os.remove(args.d4)
+    with pytest.raises(FileNotFoundError, match="d4"):
+        WCT._weights_from_args(args, "16x")
+    none = types.SimpleNamespace(mode="16x", e1="../trained_models/wct_se_16x_new/1SE.pth")     # WCT.py:49: path that does not exist here
+    assert sorted(WCT._weights_from_args(none, "16x")) == sorted(weights16x)
+    args.d4 = str(tmp_path / "d4.t7")
+    open(args.d4, "wb").close()
+    with pytest.raises(ValueError, match="extension"):
+        WCT._weights_from_args(args, "16x")
+
+
+def test_debug_environment_is_gated():
+    """WCT_* experiment variables must not change results unless WCT_DEBUG is set."""
+    src = ""
+    for f in os.listdir(os.path.join(REPO, "collaborative-distillation_amd", "csrc")):
+        src += open(os.path.join(REPO, "collaborative-distillation_amd", "csrc", f)).read()
+    raw = [m for m in re.findall(r'[^_a-z]getenv\("(WCT_[A-Z_0-9]+)"\)', src) if m not in ("WCT_DEBUG", "WCT_PROF_SHAPES")]
+    assert raw == [], raw

@@ -179,7 +179,7 @@ def test_unfused_reference_sequence_matches_fused(torch_cuda, wct16, golden):
         assert rel_err(fused, unfused) < 2e-5, k
 
 
-def test_fused_ends_match_unfused(torch_cuda, weights16x, monkeypatch):
+def test_fused_ends_match_unfused(torch_cuda, weights16x):
     """Fused ends vs the layer-by-layer path (odd sizes, image-border tiles).
     Decoder tail (conv12+conv11): same arithmetic and summation order as the unfused kernels -> bitwise identical.
     Encoder head (conv11+conv12+pool): conv11 runs as f16x3 there and as exact-fp32 MFMA unfused -> fp32-class
@@ -192,8 +192,8 @@ def test_fused_ends_match_unfused(torch_cuda, weights16x, monkeypatch):
     f2 = torch.rand((1, 32, 101, 166), device="cuda", generator=g)
     outs = {}
     for fuse in ("1", "0"):
-        monkeypatch.setenv("WCT_FUSE", fuse)
         w = WCT(types.SimpleNamespace(mode="16x", alpha=1.0), weights=weights16x)
+        w.debug_set("fuse", int(fuse))
         outs[fuse] = ([w.e5(c).clone(), w.e2(c).clone(), w.e3(c[..., :64, :32]).clone()], [w.d5(f5).clone(), w.d2(f2).clone()])
     for a, b in zip(outs["1"][0], outs["0"][0]):
         assert float((a - b).abs().max() / b.abs().max()) < 3e-6
@@ -201,9 +201,9 @@ def test_fused_ends_match_unfused(torch_cuda, weights16x, monkeypatch):
         assert torch.equal(a, b)
 
 
-def test_sp16_dma_path_bitwise_equals_fp32_activations(torch_cuda, weights16x, monkeypatch):
+def test_sp16_dma_path_bitwise_equals_fp32_activations(torch_cuda, weights16x):
     """SP16 intermediates + DMA-staged kernels (default) vs fp32 NHWC intermediates + register-staged kernels
-    (WCT_SP=0): the split hi/lo values and every accumulation order are the same, so whole encoders / decoders agree bit
+    (debug_set("sp", 0)): the split hi/lo values and every accumulation order are the same, so whole encoders / decoders agree bit
     for bit -- on odd sizes (partial tiles, odd pooling, image-border reflection) and in original mode (cout groups)."""
     from wct_hip import WCT
     torch = torch_cuda
@@ -215,17 +215,18 @@ def test_sp16_dma_path_bitwise_equals_fp32_activations(torch_cuda, weights16x, m
     wo = model_zoo.synth_weights("original", 7)
     res = {}
     for sp in ("1", "0"):
-        monkeypatch.setenv("WCT_SP", sp)
         w = WCT(types.SimpleNamespace(mode="16x", alpha=1.0), weights=weights16x)
+        w.debug_set("sp", int(sp))
         r = [w.e5(c).clone(), w.e4(c).clone(), w.e3(c).clone(), w.e2(c).clone(), w.d5(f5).clone(), w.d3(f3).clone()]
         w2 = WCT(types.SimpleNamespace(mode="original", alpha=1.0), weights=wo)
+        w2.debug_set("sp", int(sp))
         r += [w2.e4(co).clone(), w2.d4(w2.e4(co)).clone()]
         res[sp] = r
     for a, b in zip(res["1"], res["0"]):
         assert a.shape == b.shape and torch.equal(a, b)
 
 
-def test_level1_fused_matches_layerwise(torch_cuda, weights16x, monkeypatch):
+def test_level1_fused_matches_layerwise(torch_cuda, weights16x):
     """Level 1 without relu1_1 in HBM (level1.hip: image -> conv11 -> moments, image -> conv11 -> folded conv -> image)
     vs the layer-by-layer path (fp32-MFMA conv11, moments kernel, c16 decoder conv).  conv11 is f16x3 in the fused
     kernels and exact-fp32 MFMA layer-wise: fp32-class agreement, tolerance relative to max|y| as in the golden tests.
@@ -237,8 +238,8 @@ def test_level1_fused_matches_layerwise(torch_cuda, weights16x, monkeypatch):
     s = torch.rand((1, 3, 97, 131), device="cuda", generator=g)
     res = {}
     for fuse in ("1", "0"):
-        monkeypatch.setenv("WCT_L1FUSE", fuse)
         w = WCT(types.SimpleNamespace(mode="16x", alpha=1.0), weights=weights16x)
+        w.debug_set("l1fuse", int(fuse))
         h, wd, sm, sq = w.content_encode(1, c, 16, 240)          # windowed moments (the sharded path's call)
         res[fuse] = (w.e1(c).clone(), sm.clone(), sq.clone(), w.style_transfer_level(1, c, s).clone(),
                      w.style_transfer_level(1, c, s, 0.6).clone())
@@ -464,55 +465,7 @@ def test_errors(torch_cuda, wct16):
         wct16.transform(torch.zeros(24, 4, 4), torch.zeros(32, 4, 4))
 
 
-# --------------------------------------------------------------------------- sharded path on the real engine
-def _shard_worker(rank, world, port, H, W, out_path):
-    import os
-    import sys
-    from tests.conftest import PKG, REPO
-    for p in (REPO, PKG):
-        if p not in sys.path:
-            sys.path.insert(0, p)
-    import torch
-    import torch.distributed as dist
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)   # both ranks share the one GPU of the test box
-    try:
-        from wct_hip import WCT, model_zoo
-        from wct_hip.sharded import ShardedStylizer
-        w = model_zoo.load_npz_weights(os.path.join(PKG, "weights", "16x.npz"))
-        wct = WCT(types.SimpleNamespace(mode="16x", alpha=1.0), weights=w)
-        g = torch.Generator(device="cuda").manual_seed(11)
-        content = torch.rand((3, H, W), device="cuda", generator=g)
-        style = torch.rand((3, 300, 260), device="cuda", generator=g)
-        sh = ShardedStylizer(wct, dist, H, W, 300, 260)
-        x0, x1 = sh.input_columns()
-        strip = sh.stylize_strip(content[:, :, x0:x1].contiguous(), style)
-        parts = [None] * world
-        dist.all_gather_object(parts, (sh.own, strip.cpu().numpy()))
-        if rank == 0:
-            full = np.concatenate([p[1] for p in sorted(parts, key=lambda t: t[0][0])], axis=3)
-            ref = wct.stylize(content, style).cpu().numpy()
-            np.savez(out_path, got=full, ref=ref)
-    finally:
-        dist.destroy_process_group()
-
-
-def test_sharded_two_ranks_match_untiled(torch_cuda, tmp_path):
-    """wct_hip/sharded.py driving libwct_hip on the GPU: 2 ranks (gloo, same device) x column strips with
-    cumulative halos, all-reduced moments, broadcast (M, b) == the untiled HIP cascade."""
-    import socket
-    import torch.multiprocessing as mp
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    out = str(tmp_path / "sh.npz")
-    mp.spawn(_shard_worker, args=(2, port, 272, 1525, out), nprocs=2, join=True)
-    z = np.load(out)
-    assert z["got"].shape == z["ref"].shape == (1, 3, 272, 1520)
-    # not bitwise: the two runs' (M, b) differ by ~1e-13 (moment summation order), which flips fp32 roundings of
-    # the folded decoder weights at level 5, and the cascade amplifies that level by level (shard_diag.py)
-    assert rel_err(z["got"], z["ref"]) < 5e-4
-
-
+# --------------------------------------------------------------------------- sharding logic on the real kernels (ranks: tests/test_sharded_gpu.py)
 def test_strip_halos_exact_per_level(torch_cuda, wct16):
     """Sharding logic on the real kernels, level-isolated: with the SAME (M, b), a strip computed from
     [own - A_L, own + A_L) is BITWISE equal to the untiled level on own +- (A_L - halo_L), for edge strips and

@@ -87,7 +87,7 @@ class OracleEngine:
         return torch.from_numpy(self.m.decode(level, y))[None]
 
 
-def _worker(rank, world, port, H, W, out_path, broadcast_map=False):
+def _worker(rank, world, port, H, W, out_path, broadcast_map=False, halo_mode="recompute"):
     for p in (REPO, PKG):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -104,7 +104,8 @@ def _worker(rank, world, port, H, W, out_path, broadcast_map=False):
         rng = np.random.default_rng(5)
         content = rng.random((3, H, W), dtype=np.float32)
         style = rng.random((3, 80, 96), dtype=np.float32)
-        sh = ShardedStylizer(eng, dist, H, W, 80, 96, alpha=1.0, broadcast_map=broadcast_map)
+        sh = ShardedStylizer(eng, dist, H, W, 80, 96, alpha=1.0, broadcast_map=broadcast_map, halo_mode=halo_mode)
+        assert sh.halo_mode == halo_mode
         x0, x1 = sh.input_columns()
         strip = sh.stylize_strip(torch.from_numpy(np.ascontiguousarray(content[:, :, x0:x1])), torch.from_numpy(style))
         parts = [None] * world
@@ -124,11 +125,15 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("world,H,W,bmap", [(2, 64, 1280, False), (3, 48, 1925, False), (6, 32, 1152, False),   # 6 ranks: every level's style side on another rank, rank 5 none
-                                            (3, 48, 1925, True)])                                               # rank 0 solves and broadcasts (M, b)
-def test_sharded_equals_untiled(tmp_path, oracle, weights16x, world, H, W, bmap):
+@pytest.mark.parametrize("world,H,W,bmap,halo", [
+    (2, 64, 1280, False, "recompute"), (3, 48, 1925, False, "recompute"),
+    (6, 32, 1152, False, "recompute"),   # 6 ranks: every level's style side on another rank, rank 5 none
+    (3, 48, 1925, True, "recompute"),    # rank 0 solves and broadcasts (M, b)
+    (3, 48, 1925, False, "exchange"),    # exact per-level margins + neighbour exchange of the decoded edge columns;
+    (6, 32, 1157, True, "exchange")])    # 1157 -> 1152 columns after level 5: the last strip shrinks before it is sent
+def test_sharded_equals_untiled(tmp_path, oracle, weights16x, world, H, W, bmap, halo):
     out = str(tmp_path / "sharded.npy")
-    mp.spawn(_worker, args=(world, _free_port(), H, W, out, bmap), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), H, W, out, bmap, halo), nprocs=world, join=True)
     got = np.load(out)
     rng = np.random.default_rng(5)
     content = rng.random((3, H, W), dtype=np.float32)
@@ -160,6 +165,14 @@ def test_strip_bounds():
     assert ext_bounds((0, 1280), 10240, 272) == (0, 1552) and ext_bounds((8960, 10240), 10240, 272) == (8688, 10240)
     with pytest.raises(ValueError):
         strip_bounds(40, 4)
+    # FLOP overhead of the two halo modes: config 4 on 8 GPUs = 1280-wide strips
+    from wct_hip.sharded import ShardedStylizer, halo_flop_overhead
+    assert 0.25 < halo_flop_overhead(1280, "recompute") < 0.27 and 0.15 < halo_flop_overhead(1280, "exchange") < 0.16
+    assert ShardedStylizer(None, None, 4096, 10240, 2048, 2048, rank=3, world=8).halo_mode == "exchange"
+    assert ShardedStylizer(None, None, 2160, 3840 * 8, 2048, 2048, rank=3, world=8).halo_mode == "recompute"
+    assert ShardedStylizer(None, None, 4096, 10240, 2048, 2048, rank=3, world=8).input_columns() == (3840 - 160, 5120 + 160)
+    with pytest.raises(ValueError):
+        ShardedStylizer(None, None, 64, 400, 64, 64, rank=0, world=4, halo_mode="exchange")
 
 
 def _replica_worker(rank, world, port, out_dir):

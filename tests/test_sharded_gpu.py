@@ -1,0 +1,124 @@
+"""The N > 1 path on the real engine.  The GPU test box has ONE MI355X, so the ranks share it and talk over gloo
+(WCT_DIST_BACKEND=gloo; RCCL needs one device per rank): what runs is the product's sharding code (wct_hip/sharded.py),
+libwct_hip's split-level C ABI and bench.py's multi-rank branches -- everything but the RCCL transport itself."""
+import json
+import os
+import socket
+import subprocess
+import sys
+import types
+
+import numpy as np
+import pytest
+
+from tests.conftest import PKG, REPO, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _shard_worker(rank, world, port, H, W, halo_mode, bmap, out_path):
+    for p in (REPO, PKG):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)   # the ranks share the one GPU of the test box
+    try:
+        from wct_hip import WCT, model_zoo
+        from wct_hip.sharded import ShardedStylizer
+        w = model_zoo.load_npz_weights(os.path.join(PKG, "weights", "16x.npz"))
+        wct = WCT(types.SimpleNamespace(mode="16x", alpha=1.0), weights=w)
+        g = torch.Generator(device="cuda").manual_seed(11)
+        content = torch.rand((3, H, W), device="cuda", generator=g)
+        style = torch.rand((3, 300, 260), device="cuda", generator=g)
+        sh = ShardedStylizer(wct, dist, H, W, 300, 260, halo_mode=halo_mode, broadcast_map=bmap)
+        x0, x1 = sh.input_columns()
+        strip = sh.stylize_strip(content[:, :, x0:x1].contiguous(), style)
+        wct.sync()
+        parts = [None] * world
+        dist.all_gather_object(parts, (sh.own, sh.halo_mode, strip.cpu().numpy()))
+        if rank == 0:
+            full = np.concatenate([p[2] for p in sorted(parts, key=lambda t: t[0][0])], axis=3)
+            ref = wct.stylize(content, style).cpu().numpy()
+            np.savez(out_path, got=full, ref=ref, modes=np.array([p[1] for p in parts]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,H,W,halo_mode,bmap", [(2, 272, 1525, "recompute", False), (2, 272, 1525, "exchange", False),
+                                                      (3, 144, 1168, "exchange", True), (2, 272, 1525, "auto", True)])
+def test_sharded_ranks_match_untiled(tmp_path, world, H, W, halo_mode, bmap):
+    """wct_hip/sharded.py driving libwct_hip on the GPU: column strips (cumulative halos, or exact per-level margins + the
+    neighbour exchange of decoded edge columns), all-reduced fp64 moments, replicated solve or broadcast (M, b)  ==  the
+    untiled HIP cascade.  Not bitwise: the runs' (M, b) differ by ~1e-13 (moment summation order), which flips fp32 roundings
+    of the folded decoder weights at level 5, and the cascade amplifies that level by level (tools/debug/shard_diag.py); the
+    strips themselves are bit-exact given the same (M, b) (test_strip_halos_exact_per_level)."""
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "sh.npz")
+    mp.spawn(_shard_worker, args=(world, _free_port(), H, W, halo_mode, bmap, out), nprocs=world, join=True)
+    z = np.load(out)
+    assert z["got"].shape == z["ref"].shape == (1, 3, H // 16 * 16, W // 16 * 16)
+    assert all(m == ("exchange" if halo_mode == "auto" else halo_mode) for m in z["modes"])
+    assert rel_err(z["got"], z["ref"]) < 5e-4
+
+
+@pytest.mark.parametrize("extra,name", [([], "cfg2x2"), (["--config", "cfg4", "--halo-mode", "exchange"], "cfg4")])
+def test_bench_two_ranks_on_one_gpu(extra, name):
+    """bench.py's N = 2 code path exactly as the driver launches it (torch.distributed.run, one process per rank), ranks
+    sharing the one GPU over gloo: the JSON contract of the multi-rank line, both workloads."""
+    env = dict(os.environ, WCT_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"] + extra
+    r = subprocess.run(cmd, env=env, cwd=REPO, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]                      # rank 0 prints ONE line
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 2 and line["unit"] == "MP/s" and line["config"]["name"] == name
+    assert line["value"] > 0 and line["parity_ok"] is None and line["config"]["dist_backend"] == "gloo"
+    if name == "cfg4":
+        assert line["scaling"] == "strong" and line["config"]["content_total"] == "10240x4096"
+        assert "halo: exchange" in line["config"]["workload"]
+        assert abs(line["value"] - 41.94304 / line["ms_per_step"] * 1e3) < 0.02 * line["value"]
+    else:
+        assert line["scaling"] == "weak" and line["config"]["content_total"] == "7680x2160"
+        s4 = line["passes"]["cfg4_strong"]                       # ONE 10240x4096 frame in 2 strips beside the weak-scaling number
+        assert s4["scaling"] == "strong" and s4["MPs"] > 0 and "10240x4096" in s4["workload"]
+    assert line["roofline"]["frac"] > 0
+
+
+def test_strip_halos_exact_with_level_margins(tmp_path):
+    """halo_mode "exchange" relies on: a strip fed own +- LEVEL_HALO[L] columns reproduces the untiled level BITWISE on its
+    owned columns (same (M, b)) -- edge strips, an interior strip, and a width that floor pooling shrinks (2005 -> 2000)."""
+    import torch
+    from wct_hip import WCT, model_zoo
+    from wct_hip.sharded import LEVEL_HALO, ext_bounds, strip_bounds
+    wct = WCT(types.SimpleNamespace(mode="16x", alpha=1.0), weights=model_zoo.load_npz_weights(os.path.join(PKG, "weights", "16x.npz")))
+    H, W, world = 176, 2005, 3
+    g = torch.Generator(device="cuda").manual_seed(3)
+    content = torch.rand((1, 3, H, W), device="cuda", generator=g)
+    style = torch.rand((3, 200, 180), device="cuda", generator=g)
+    for L in (5, 4, 3, 2, 1):
+        sh = L - 1
+        sF = wct.encode(L, style, layout="nhwc")
+        cF = wct.encode(L, content, layout="nhwc")
+        nc, sc, ssc = wct.moments(cF)
+        M, b = wct.solve(nc, sc, ssc, *wct.moments(sF))
+        full = wct.decode_affine(L, cF, M, b)
+        Wn = (W >> sh) << sh
+        for own in strip_bounds(W, world):
+            lo, hi = ext_bounds(own, W, LEVEL_HALO[L])
+            f = wct.encode(L, content[..., lo:hi].contiguous(), layout="nhwc")
+            o = wct.decode_affine(L, f, M, b)
+            a, e = own[0], min(Wn, own[1])
+            assert torch.equal(o[..., a - lo:e - lo], full[..., a:e]), (L, own)

@@ -4,7 +4,8 @@
 Runs only in the build container (needs /root/reference and torch-CPU).  Nothing of the
 reference's source travels: the outputs are *data* --
   collaborative-distillation_amd/weights/16x.npz   the ten 16x checkpoints, aux heads dropped
-  tests/golden/*.npz                               inputs + expected outputs (G1..G7)
+  tests/golden/*.npz                               inputs + expected outputs (G1..G11)
+  tests/golden/g11_*.jpg                           the reference's UHD sample content + 2048x2048 sample style (data files)
 
 The reference is imported unmodified with the two shims of SURVEY 8c:
   * torch.utils.serialization.load_lua (removed in torch>=1.0) is injected as a stub;
@@ -356,8 +357,45 @@ def gen_g10():
     np.savez_compressed(os.path.join(GOLD, "g10_numpy_variant.npz"), **g)
 
 
+def gen_g11():
+    """G11: the reference's own UHD sample pair at BASELINE config-2 size -- content/UHD_content/green_park-wallpaper-
+    3840x2160.jpg (README.md:41-44 `--UHD`) with style/in1.jpg (2048x2048) standing in for the absent UHD styles
+    (.MISSING_LARGE_BLOBS).  The two JPEG files are DATA of the reference and are copied byte for byte as fixtures; the
+    expected output is the reference itself (util_wct.WCT with the real 16x checkpoints, torch CPU, WCT.py:120-125 restated),
+    stored as: a 16x box-downsampled version of the final image, four 96x96 crops, global mean / std / max.  ~5 min here."""
+    import shutil
+    import time
+    torch.set_num_threads(8)
+    util_wct = import_reference()
+    wct = util_wct.WCT(ref_args("16x", 1.0))
+    cpath = os.path.join(REF, "PytorchWCT/content/UHD_content/green_park-wallpaper-3840x2160.jpg")
+    spath = os.path.join(REF, "PytorchWCT/style/in1.jpg")
+    shutil.copyfile(cpath, os.path.join(GOLD, "g11_uhd_content_3840x2160.jpg"))
+    shutil.copyfile(spath, os.path.join(GOLD, "g11_style_2048x2048.jpg"))
+    c, s = load_rgb(cpath), load_rgb(spath)
+    assert c.shape == (3, 2160, 3840) and s.shape == (3, 2048, 2048)
+    t0 = time.time()
+    img = t(c[None])
+    for k in (5, 4, 3, 2, 1):
+        img = ref_style_transfer(wct, getattr(wct, "e%d" % k), getattr(wct, "d%d" % k), img, t(s[None]), 1.0)
+        print("G11: level %d done, %.0f s" % (k, time.time() - t0), flush=True)
+    y = img.squeeze(0).numpy()
+    assert y.shape == (3, 2160, 3840)
+    g = {"shape": np.array(y.shape), "mean": np.float64(y.mean(dtype=np.float64)), "std": np.float64(y.std(dtype=np.float64)),
+         "max": np.float32(y.max()), "min": np.float32(y.min()),
+         "down16": y.reshape(3, 135, 16, 240, 16).mean(axis=(2, 4), dtype=np.float64).astype(np.float32)}
+    for i, (y0, x0) in enumerate(((0, 0), (1032, 1872), (2064, 3744), (500, 3000))):
+        g["crop%d.origin" % i] = np.array([y0, x0])
+        g["crop%d" % i] = y[:, y0:y0 + 96, x0:x0 + 96].copy()
+    np.savez_compressed(os.path.join(GOLD, "g11_uhd_pair.npz"), **g)
+    print("G11: mean %.6f std %.6f max %.4f" % (g["mean"], g["std"], g["max"]))
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 2 and sys.argv[1] == "--only" and sys.argv[2] == "g10":
+    if len(sys.argv) > 2 and sys.argv[1] == "--only" and sys.argv[2] == "g11":
+        os.makedirs(GOLD, exist_ok=True)
+        gen_g11()
+    elif len(sys.argv) > 2 and sys.argv[1] == "--only" and sys.argv[2] == "g10":
         os.makedirs(GOLD, exist_ok=True)
         gen_g10()
     elif len(sys.argv) > 2 and sys.argv[1] == "--only" and sys.argv[2] == "g9":
@@ -367,3 +405,4 @@ if __name__ == "__main__":
         main()
         gen_g9()
         gen_g10()
+        gen_g11()
