@@ -156,6 +156,7 @@ def main():
                     help="cfg2: 3840x2160 content per GPU (N > 1: weak scaling over an N x 3840 wide frame); "
                          "cfg4: ONE 10240x4096 content in N column strips (strong scaling)")
     ap.add_argument("--halo-mode", choices=["auto", "recompute", "exchange"], default="auto")
+    ap.add_argument("--debug-set", action="append", default=[], metavar="KEY=VALUE", help="wct_debug_set switches for A/B runs")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle run (and with it the parity gate)")
     ap.add_argument("--steps-only", action="store_true",
                     help="skip the extra passes (relu4_1 encode, cached style, frames in flight): every launch then belongs to a "
@@ -186,6 +187,8 @@ def main():
     from wct_hip import WCT, model_zoo
     weights = model_zoo.load_npz_weights(os.path.join(PKG, "weights", "16x.npz"))
     wct = WCT(types.SimpleNamespace(mode="16x", alpha=1.0), weights=weights)
+    for kv in args.debug_set:
+        wct.debug_set(kv.split("=")[0], float(kv.split("=")[1]))
 
     def noise(seed, h, w):   # uniform noise, no zeros (zero-filled inputs clock higher), seeded
         return torch.rand((3, h, w), device="cuda", generator=torch.Generator(device="cuda").manual_seed(seed))

@@ -711,7 +711,19 @@ int wct_debug_set(wct_ctx* ctx, const char* key, double value) {
   else if (!strcmp(key, "sp")) ctx->sp = v;
   else if (!strcmp(key, "l1fuse")) ctx->l1fuse = v;
   else if (!strcmp(key, "u8fuse")) ctx->u8fuse = v;
-  else return fail(ctx, WCT_ERR_INVALID, "debug_set: unknown key '%s' (fuse, sp, l1fuse, u8fuse)", key);
+  else if (!strcmp(key, "side_priority")) {
+    // priority of the style-side stream relative to the default: 0 = default, 1 = lowest (style kernels only fill the
+    // content cascade's gaps), -1 = highest
+    int lo = 0, hi = 0;
+    HIPCHK(ctx, hipDeviceGetStreamPriorityRange(&lo, &hi));   // lo = least priority (numerically largest)
+    HIPCHK(ctx, hipStreamSynchronize(ctx->side.stream));
+    hipStream_t ns = nullptr;
+    HIPCHK(ctx, hipStreamCreateWithPriority(&ns, hipStreamNonBlocking, value > 0 ? lo : (value < 0 ? hi : 0)));
+    (void)hipStreamDestroy(ctx->side.stream);
+    ctx->side.stream = ns;
+    return WCT_OK;
+  }
+  else return fail(ctx, WCT_ERR_INVALID, "debug_set: unknown key '%s' (fuse, sp, l1fuse, u8fuse, side_priority)", key);
   HIPCHK(ctx, hipStreamSynchronize(ctx->side.stream));
   return WCT_OK;
 }

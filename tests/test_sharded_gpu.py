@@ -24,7 +24,7 @@ def _free_port():
     return p
 
 
-def _shard_worker(rank, world, port, H, W, halo_mode, bmap, out_path):
+def _shard_worker(rank, world, port, H, W, halo_mode, bmap, out_path, style_hw=(300, 260)):
     for p in (REPO, PKG):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -40,8 +40,8 @@ def _shard_worker(rank, world, port, H, W, halo_mode, bmap, out_path):
         wct = WCT(types.SimpleNamespace(mode="16x", alpha=1.0), weights=w)
         g = torch.Generator(device="cuda").manual_seed(11)
         content = torch.rand((3, H, W), device="cuda", generator=g)
-        style = torch.rand((3, 300, 260), device="cuda", generator=g)
-        sh = ShardedStylizer(wct, dist, H, W, 300, 260, halo_mode=halo_mode, broadcast_map=bmap)
+        style = torch.rand((3,) + tuple(style_hw), device="cuda", generator=g)
+        sh = ShardedStylizer(wct, dist, H, W, style_hw[0], style_hw[1], halo_mode=halo_mode, broadcast_map=bmap)
         x0, x1 = sh.input_columns()
         strip = sh.stylize_strip(content[:, :, x0:x1].contiguous(), style)
         wct.sync()
@@ -70,6 +70,41 @@ def test_sharded_ranks_match_untiled(tmp_path, world, H, W, halo_mode, bmap):
     assert z["got"].shape == z["ref"].shape == (1, 3, H // 16 * 16, W // 16 * 16)
     assert all(m == ("exchange" if halo_mode == "auto" else halo_mode) for m in z["modes"])
     assert rel_err(z["got"], z["ref"]) < 5e-4
+
+
+def test_config4_eight_strips_match_untiled(tmp_path):
+    """BASELINE configs[3] as specified: ONE 10240x4096 content (2048x2048 style) in EIGHT column strips of 1280 -- eight
+    ranks (here sharing the one GPU over gloo; on the 8-GPU node: RCCL), halo mode "auto" = neighbour exchange at this strip
+    width, style statistics computed once per node and broadcast, all-reduced moments -- against the untiled single-GPU
+    cascade of the same frame."""
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "sh8.npz")
+    mp.spawn(_shard_worker, args=(8, _free_port(), 4096, 10240, "auto", False, out, (2048, 2048)), nprocs=8, join=True)
+    z = np.load(out)
+    assert z["got"].shape == z["ref"].shape == (1, 3, 4096, 10240)
+    assert all(m == "exchange" for m in z["modes"])
+    e = rel_err(z["got"], z["ref"])
+    print("\n[cfg4 8 strips vs untiled] rel_err=%.3e" % e)
+    assert np.isfinite(z["got"]).all() and e < 1e-3
+
+
+def test_rccl_first_contact_single_rank():
+    """The GPU test box has one device, so RCCL cannot carry a 2-rank job here; this at least executes the calls bench.py and
+    wct_hip/sharded.py make -- init_process_group("nccl", device_id=...), all_reduce(SUM) of fp64 moments, broadcast, a
+    MAX all-reduce, barrier -- on a 1-rank RCCL communicator, in a fresh process."""
+    code = (
+        "import os, torch, torch.distributed as dist\n"
+        "os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='%d', RANK='0', WORLD_SIZE='1')\n"
+        "torch.cuda.set_device(0)\n"
+        "dist.init_process_group('nccl', device_id=torch.device('cuda', 0))\n"
+        "x = torch.arange(128 * 128 + 128, dtype=torch.float64, device='cuda'); y = x.clone()\n"
+        "dist.all_reduce(x); dist.broadcast(x, src=0)\n"
+        "t = torch.tensor([1.5], device='cuda', dtype=torch.float64); dist.all_reduce(t, op=dist.ReduceOp.MAX)\n"
+        "dist.barrier(); torch.cuda.synchronize()\n"
+        "assert torch.equal(x, y) and float(t) == 1.5 and dist.get_backend() == 'nccl'\n"
+        "dist.destroy_process_group(); print('RCCL_OK')\n" % _free_port())
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert r.returncode == 0 and "RCCL_OK" in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])
 
 
 @pytest.mark.parametrize("extra,name", [([], "cfg2x2"), (["--config", "cfg4", "--halo-mode", "exchange"], "cfg4")])

@@ -3,7 +3,8 @@
 SQ_VALU_MFMA_BUSY_CYCLES counts, summed over the chip, the cycles a SIMD's matrix core is busy (MI355X_MICROARCH.md: 32 per
 32x32x16 f16 MFMA).  Utilisation = busy cycles / (1024 SIMDs x the kernel's duration in shader cycles); the duration in cycles is
 GRBM_GUI_ACTIVE when that counter is in the pass (per-XCD values are summed by rocprofv3 -> / 8), else avg_us x --ghz.
-usage: tools/mfma_summary.py <counter_collection.csv> [out.txt] [--ghz 2.0]"""
+usage: tools/mfma_summary.py <counter_collection.csv> [out.txt] [--ghz 2.0] [--per-dispatch]
+--per-dispatch: one row per launch, in launch order (micro-benchmarks that launch one template with different arguments)"""
 import csv
 import re
 import sys
@@ -18,11 +19,14 @@ def main():
     if "--ghz" in sys.argv:
         ghz = float(sys.argv[sys.argv.index("--ghz") + 1])
         args = [a for a in args if a != str(ghz) and a != sys.argv[sys.argv.index("--ghz") + 1]]
+    per = "--per-dispatch" in sys.argv
     agg = defaultdict(lambda: defaultdict(float))
     calls = defaultdict(set)
     dur = defaultdict(float)
     for r in csv.DictReader(open(args[0])):
         k = re.sub(r"\(anonymous namespace\)::", "", r["Kernel_Name"])
+        if per:
+            k = "#%04d %s" % (int(r["Dispatch_Id"]), k)
         agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
         if r["Dispatch_Id"] not in calls[k]:
             calls[k].add(r["Dispatch_Id"])
@@ -37,7 +41,7 @@ def main():
         us = dur[k] / n
         cyc = gui / XCDS if gui else us * 1e3 * ghz
         rows.append((dur[k], k, n, us, busy, gui, (cyc / (us * 1e3)) if us else 0.0, 100.0 * busy / (SIMDS * cyc) if cyc else 0.0))
-    for _, k, n, us, busy, gui, eff, util in sorted(rows, reverse=True):
+    for _, k, n, us, busy, gui, eff, util in (sorted(rows, key=lambda t: t[1]) if per else sorted(rows, reverse=True)):
         if k.startswith(("void at::", "__amd")):
             continue
         lines.append("%-64s %6d %9.1f %16.0f %14.0f %9.2f %8.1f" % (k[:64], n, us, busy, gui, eff, util))
