@@ -557,7 +557,7 @@ __global__ __launch_bounds__(256, 3) void enc_head_kernel(HeadArgs a) {
 struct TailArgs {   // conv12 (16->16 on the nearest-x2 upsampled input) + ReLU -> conv11 (16->3) + ReLU -> planar image
   const float* in; float* out;
   const u32x4* w12; const float* b12; float inv12; const float* inv12_ptr;
-  const u32x4* w11; const float* b11; float inv11;
+  const u32x4* w11; const float* b11; float inv11;   // w11: phase-packed (c3_phase_compute), PH_WSLOTS slots
   int H, W, inW, up_in, tiles_x, tiles_y;
   int in_sp;
   unsigned* sat;
@@ -615,16 +615,17 @@ __device__ __forceinline__ void tail_commit(const TailRegs& r, u32x4* act0, int 
 // that touch the image border recompute their reflected coordinates.
 __global__ __launch_bounds__(256, 2) void dec_tail_kernel(TailArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int NPP = npp(8), NPH = nph(8), NG = 6;
+  constexpr int NPH = nph(8), NG = 6;
   u32x4* act0 = reinterpret_cast<u32x4*>(smem);   // [4][432]  input of conv12 (two halo rings)
   u32x4* wg12 = act0 + 4 * NPI2;                  // [640]
-  u32x4* wg11 = wg12 + 640;                       // [640]
-  u32x4* act1 = wg11 + 640;                       // [4][NPP]  conv12 output on the 34 x 10 halo
+  u32x4* wg11 = wg12 + 640;                       // [PH_WSLOTS]  phase-packed 16 -> 3 weights
+  u32x4* act1 = wg11 + PH_WSLOTS;                 // [4][PH_NPX]  conv12 output on the 34 x 10 halo, pair-major slots (ph_slot)
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, kq = lane >> 4, kh = kq & 1, ts = kq >> 1;
   const int ntiles = a.tiles_x * a.tiles_y;
   const unsigned txm = tile_div_magic(a.tiles_x);   // once per workgroup; tile_rc() then stays on the scalar unit
-  for (int e = tid; e < 640; e += 256) { wg12[e] = a.w12[e]; wg11[e] = a.w11[e]; }
+  for (int e = tid; e < 640; e += 256) wg12[e] = a.w12[e];
+  for (int e = tid; e < PH_WSLOTS; e += 256) wg11[e] = a.w11[e];
   const float inv12 = a.inv12_ptr ? *a.inv12_ptr : a.inv12;
   const f32x4 bias12 = *reinterpret_cast<const f32x4*>(a.b12 + 4 * kq);
   const f32x4 bias11 = *reinterpret_cast<const f32x4*>(a.b11);
@@ -639,7 +640,7 @@ __global__ __launch_bounds__(256, 2) void dec_tail_kernel(TailArgs a) {
     soff[k] = ((py >> a.up_in) * a.inW + (px >> a.up_in)) * 16 + (e & 1) * 8;
   }
   // the wave's six 16-pixel groups of the 34 x 10 halo (group 5 exists for waves 0 and 1 only: 22 groups)
-  int gpix[NG], gpy[NG], gpx[NG];
+  int gpix[NG], gpy[NG], gpx[NG], gslot[NG];
   bool gok[NG];
 #pragma unroll
   for (int u = 0; u < NG; ++u) {
@@ -648,6 +649,7 @@ __global__ __launch_bounds__(256, 2) void dec_tail_kernel(TailArgs a) {
     gpix[u] = gok[u] ? pixr : NPH - 1;
     gpy[u] = gpix[u] / FHW;
     gpx[u] = gpix[u] - gpy[u] * FHW;
+    gslot[u] = ph_slot(gpy[u], gpx[u]);
   }
 
   TailRegs tr;
@@ -708,30 +710,27 @@ __global__ __launch_bounds__(256, 2) void dec_tail_kernel(TailArgs a) {
         f32x4 x;
 #pragma unroll
         for (int r = 0; r < 4; ++r) x[r] = fmaxf(acc[u][r] * inv12 + bias12[r], 0.f);
-        if (gok[u]) store_split4(act1, NPP, gpix[u], kq, x, sat);
+        if (gok[u]) store_split4(act1, PH_NPX, gslot[u], kq, x, sat);
       }
     }
     __syncthreads();
-    // ---- conv11 (16 -> 3) + ReLU -> planar output (the arithmetic of conv3x3_f16_c16_kernel<OUT3>)
+    // ---- conv11 (16 -> 3) + ReLU -> planar output, phase-packed (conv_f16_dev.h): lanes kq in {0, 2} hold pixel 2 li + (kq >> 1)
     f32x4 acc[2][2];
 #pragma unroll
     for (int r = 0; r < 2; ++r)
 #pragma unroll
       for (int h = 0; h < 2; ++h) acc[r][h] = f32x4{0.f, 0.f, 0.f, 0.f};
-    c16_compute(act1, wg11, wave, li, kq, acc);
-    if (kq == 0) {
+    c3_phase_compute(act1, wg11, wave, li, kq, acc);
+    if (!(kq & 1)) {
+      const int gx = tx0 + 2 * li + (kq >> 1);
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int gx = tx0 + h * 16 + li;
-#pragma unroll
-        for (int r2 = 0; r2 < 2; ++r2) {
-          const int gy = ty0 + wave * 2 + r2;
-          if (gy < a.H && gx < a.W) {
-            const size_t off = (size_t)gy * a.W + gx;
-            a.out[off] = fmaxf(acc[r2][h][0] * a.inv11 + bias11[0], 0.f);
-            a.out[plane + off] = fmaxf(acc[r2][h][1] * a.inv11 + bias11[1], 0.f);
-            a.out[2 * plane + off] = fmaxf(acc[r2][h][2] * a.inv11 + bias11[2], 0.f);
-          }
+      for (int r2 = 0; r2 < 2; ++r2) {
+        const int gy = ty0 + wave * 2 + r2;
+        if (gy < a.H && gx < a.W) {
+          const size_t off = (size_t)gy * a.W + gx;
+          a.out[off] = fmaxf((acc[r2][0][0] + acc[r2][1][0]) * a.inv11 + bias11[0], 0.f);
+          a.out[plane + off] = fmaxf((acc[r2][0][1] + acc[r2][1][1]) * a.inv11 + bias11[1], 0.f);
+          a.out[2 * plane + off] = fmaxf((acc[r2][0][2] + acc[r2][1][2]) * a.inv11 + bias11[2], 0.f);
         }
       }
     }
@@ -791,6 +790,36 @@ __global__ void split_pack_kernel(const float* wpk32, int chunks, int cout_pad, 
   out[e] = __builtin_bit_cast(u32x4, v);
 }
 
+// the phase-packed form (conv_f16_dev.h c3_phase_compute) of a cout_pad-16 layer with 3 real couts, same scale as above
+__global__ void split_pack_phase_kernel(const float* wpk32, int chunks, const unsigned* maxbits, u32x4* out) {
+  const float mx = __uint_as_float(*maxbits);
+  int ex = 0;
+  if (mx > 0.f && mx < 3.0e38f) { (void)frexpf(mx, &ex); ex = 9 - ex; }
+  ex = ex > 100 ? 100 : (ex < -100 ? -100 : ex);
+  const float scale = ldexpf(1.f, ex);
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (long)chunks * PH_WSLOTS) return;
+  long t = e;
+  const int m = (int)(t & 15); t >>= 4;
+  const int kq = (int)(t & 3); t >>= 2;
+  const int hl = (int)(t & 1); t >>= 1;
+  const int ks = (int)(t % 6);
+  const int chunk = (int)(t / 6);
+  const int phase = m >> 3, co = m & 7, dy = ks >> 1, dxr = 2 * (ks & 1) + (kq >> 1) - phase;
+  f16x8 v;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    float x = 0.f;
+    if (co < 3 && dxr >= 0 && dxr <= 2) {
+      const int ci = (kq & 1) * 8 + j, tap = dy * 3 + dxr;   // fp32 layout [chunk][tap][kq = ci / 4][cout_pad = 16][ci % 4]
+      x = wpk32[((((size_t)chunk * 9 + tap) * 4 + (ci >> 2)) * 16 + co) * 4 + (ci & 3)] * scale;
+    }
+    const _Float16 h = (_Float16)x;
+    v[j] = hl ? (_Float16)(x - (float)h) : h;
+  }
+  out[e] = __builtin_bit_cast(u32x4, v);
+}
+
 }  // namespace
 
 
@@ -802,7 +831,7 @@ bool conv_fusable_head(const ConvDesc& d0, const ConvDesc& d1) {
 
 bool conv_fusable_tail(const ConvDesc& d0, const ConvDesc& d1) {
   return d0.cin == 16 && d0.cout == 16 && d0.cout_pad == 16 && !(d0.flags & (CONV_POOL_OUT | CONV_NO_RELU | CONV_IN_NCHW3 | CONV_OUT_NCHW3)) &&
-         d0.wpk16 && (d1.flags & CONV_OUT_NCHW3) && d1.cin == 16 && d1.cout == 3 && d1.cout_pad == 16 && d1.wpk16 &&
+         d0.wpk16 && (d1.flags & CONV_OUT_NCHW3) && d1.cin == 16 && d1.cout == 3 && d1.cout_pad == 16 && d1.wpk16 && d1.wph16 &&
          !(d1.flags & (CONV_UP_IN | CONV_NO_RELU)) && !d1.inv_scale_ptr;
 }
 
@@ -827,15 +856,15 @@ hipError_t launch_dec_tail(const ConvDesc& d0, const ConvDesc& d1, const float* 
   TailArgs a;
   a.in = in; a.out = out;
   a.w12 = reinterpret_cast<const u32x4*>(d0.wpk16); a.b12 = d0.bias; a.inv12 = d0.inv_scale; a.inv12_ptr = d0.inv_scale_ptr;
-  a.w11 = reinterpret_cast<const u32x4*>(d1.wpk16); a.b11 = d1.bias; a.inv11 = d1.inv_scale;
+  a.w11 = reinterpret_cast<const u32x4*>(d1.wph16); a.b11 = d1.bias; a.inv11 = d1.inv_scale;
   a.H = H; a.W = W; a.up_in = (d0.flags & CONV_UP_IN) ? 1 : 0; a.inW = a.up_in ? W / 2 : W;
   a.in_sp = (d0.flags & CONV_IN_SP16) ? 1 : 0;
   a.sat = d1.sat;
   a.tiles_x = (W + FTW - 1) / FTW; a.tiles_y = (H + 7) / 8;
-  const size_t lds = ((size_t)4 * NPI2 + 640 + (size_t)4 * npp(8) + 640) * 16;
+  const size_t lds = ((size_t)4 * NPI2 + 640 + PH_WSLOTS + (size_t)4 * PH_NPX) * 16;   // 73.7 KB: 2 per CU
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(dec_tail_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  const int ntiles = a.tiles_x * a.tiles_y, grid = ntiles < 2 * num_cus() ? ntiles : 2 * num_cus();   // 70.6 KB: 2 per CU
+  const int ntiles = a.tiles_x * a.tiles_y, grid = ntiles < 2 * num_cus() ? ntiles : 2 * num_cus();
   hipLaunchKernelGGL(dec_tail_kernel, dim3(grid), dim3(256), lds, s, a);
   return hipGetLastError();
 }
@@ -856,6 +885,16 @@ hipError_t launch_split_pack(const float* wpk32, int cin, int cout_pad, int taps
   const long total = (long)chunks * taps * 4 * cout_pad;
   hipLaunchKernelGGL(split_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, wpk32, chunks, cout_pad, taps,
                      maxbits_dev, reinterpret_cast<u32x4*>(out), inv_scale_out);
+  return hipGetLastError();
+}
+
+size_t conv_phase_weight_bytes(int cin) { return (size_t)((cin + 15) / 16) * PH_WSLOTS * 16; }
+
+hipError_t launch_split_pack_phase(const float* wpk32, int cin, const unsigned* maxbits_dev, void* out, hipStream_t s) {
+  const int chunks = (cin + 15) / 16;
+  const long total = (long)chunks * PH_WSLOTS;
+  hipLaunchKernelGGL(split_pack_phase_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, wpk32, chunks, maxbits_dev,
+                     reinterpret_cast<u32x4*>(out));
   return hipGetLastError();
 }
 

@@ -18,7 +18,7 @@ namespace {
 struct L1DecArgs {
   const float* img; float* out;
   L1Conv c;                                  // conv11 of the encoder (f16x3 slot layout, 2 cout tiles)
-  const u32x4* w2; const float* b2;          // folded decoder conv: [2 chunks][10 taps][hl][kh][16] x 16 B, bias [16]
+  const u32x4* w2; const float* b2;          // folded decoder conv, phase-packed (c3_phase_compute): [2 chunks][PH_WSLOTS] x 16 B, bias [16]
   const float* inv2_ptr; float inv2;
   int H, W, tiles_x, tiles_y;
   unsigned* sat;
@@ -88,16 +88,16 @@ __global__ __launch_bounds__(256, 3) void l1_encode_kernel(L1EncArgs a) {
 // image -> relu1_1 on the 34 x 10 halo (LDS, split f16) -> folded decoder conv (24 -> 3) + ReLU -> planar image
 __global__ __launch_bounds__(256, 2) void l1_decode_kernel(L1DecArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int NPP = npp(8), NPH = nph(8), NG = 6;
+  constexpr int NPH = nph(8), NG = 6;
   u32x2* imgH = reinterpret_cast<u32x2*>(smem);
   u32x2* imgL = imgH + IMG_E;
-  u32x4* act = reinterpret_cast<u32x4*>(imgL + IMG_E);   // [2 chunks][4][NPP]
-  u32x4* wgt = act + 2 * 4 * NPP;                         // [2 chunks][640]
+  u32x4* act = reinterpret_cast<u32x4*>(imgL + IMG_E);   // [2 chunks][4][PH_NPX]  relu1_1 on the halo, pair-major slots (ph_slot)
+  u32x4* wgt = act + 2 * 4 * PH_NPX;                      // [2 chunks][PH_WSLOTS]
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, kq = lane >> 4;
   const int ntiles = a.tiles_x * a.tiles_y;
   const unsigned txm = tile_div_magic(a.tiles_x);   // once per workgroup; tile_rc() then stays on the scalar unit
-  for (int e = tid; e < 2 * 640; e += 256) wgt[e] = a.w2[e];
+  for (int e = tid; e < 2 * PH_WSLOTS; e += 256) wgt[e] = a.w2[e];
   if (tid < 4) { imgH[NPI2 + tid] = u32x2{0u, 0u}; imgL[NPI2 + tid] = u32x2{0u, 0u}; }
   L1Weights w;
   l1_load_weights(a.c, li, kq, w);
@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256, 2) void l1_decode_kernel(L1DecArgs a) {
     e = e < NPI2 ? e : NPI2 - 1;
     soff[k] = (e / I2W) * a.W + e % I2W;
   }
-  int gpix[NG], gpy[NG], gpx[NG];
+  int gpix[NG], gpy[NG], gpx[NG], gslot[NG];
   bool gok[NG];
 #pragma unroll
   for (int u = 0; u < NG; ++u) {
@@ -120,6 +120,7 @@ __global__ __launch_bounds__(256, 2) void l1_decode_kernel(L1DecArgs a) {
     gpix[u] = gok[u] ? pixr : NPH - 1;
     gpy[u] = gpix[u] / FHW;
     gpx[u] = gpix[u] - gpy[u] * FHW;
+    gslot[u] = ph_slot(gpy[u], gpx[u]);
   }
   float pxr[2][3];
   SatTrack sat;
@@ -150,31 +151,29 @@ __global__ __launch_bounds__(256, 2) void l1_decode_kernel(L1DecArgs a) {
 #pragma unroll
       for (int ct = 0; ct < 2; ++ct) {
         const f32x4 x = l1_conv_group(imgH, imgL, base, kq, w, ct);
-        if (gok[u]) store_split4(act + ct * 4 * NPP, NPP, gpix[u], kq, x, sat);
+        if (gok[u]) store_split4(act + ct * 4 * PH_NPX, PH_NPX, gslot[u], kq, x, sat);
       }
     }
     __syncthreads();
-    // ---- folded decoder conv on the two 16-channel chunks (the arithmetic of conv3x3_f16_c16_kernel<OUT3>)
+    // ---- folded decoder conv on the two 16-channel chunks, phase-packed (conv_f16_dev.h): lanes kq in {0, 2} hold pixel
+    //      2 li + (kq >> 1) of the wave's two rows
     f32x4 acc[2][2];
 #pragma unroll
     for (int r = 0; r < 2; ++r)
 #pragma unroll
       for (int h = 0; h < 2; ++h) acc[r][h] = f32x4{0.f, 0.f, 0.f, 0.f};
-    c16_compute(act, wgt, wave, li, kq, acc);
-    c16_compute(act + 4 * NPP, wgt + 640, wave, li, kq, acc);
-    if (kq == 0) {
+    c3_phase_compute(act, wgt, wave, li, kq, acc);
+    c3_phase_compute(act + 4 * PH_NPX, wgt + PH_WSLOTS, wave, li, kq, acc);
+    if (!(kq & 1)) {
+      const int gx = tx0 + 2 * li + (kq >> 1);
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int gx = tx0 + h * 16 + li;
-#pragma unroll
-        for (int r2 = 0; r2 < 2; ++r2) {
-          const int gy = ty0 + wave * 2 + r2;
-          if (gy < a.H && gx < a.W) {
-            const size_t off = (size_t)gy * a.W + gx;
-            a.out[off] = fmaxf(acc[r2][h][0] * inv2 + bias2[0], 0.f);
-            a.out[plane + off] = fmaxf(acc[r2][h][1] * inv2 + bias2[1], 0.f);
-            a.out[2 * plane + off] = fmaxf(acc[r2][h][2] * inv2 + bias2[2], 0.f);
-          }
+      for (int r2 = 0; r2 < 2; ++r2) {
+        const int gy = ty0 + wave * 2 + r2;
+        if (gy < a.H && gx < a.W) {
+          const size_t off = (size_t)gy * a.W + gx;
+          a.out[off] = fmaxf((acc[r2][0][0] + acc[r2][1][0]) * inv2 + bias2[0], 0.f);
+          a.out[plane + off] = fmaxf((acc[r2][0][1] + acc[r2][1][1]) * inv2 + bias2[1], 0.f);
+          a.out[2 * plane + off] = fmaxf((acc[r2][0][2] + acc[r2][1][2]) * inv2 + bias2[2], 0.f);
         }
       }
     }
@@ -204,16 +203,16 @@ hipError_t launch_l1_encode(const ConvDesc& e, const float* img, float* out, int
 
 // dec0: the decoder's only conv with the WCT map folded in (split-f16 packed, 10 taps, cout_pad 16)
 hipError_t launch_l1_decode(const ConvDesc& e, const ConvDesc& dec0, const float* img, float* out, int H, int W, hipStream_t s) {
-  if (!l1_capable(e) || H < 2 || W < 2 || !dec0.wpk16 || dec0.cout != 3 || dec0.cout_pad != 16 || dec0.cin != e.cout ||
+  if (!l1_capable(e) || H < 2 || W < 2 || !dec0.wpk16 || !dec0.wph16 || dec0.cout != 3 || dec0.cout_pad != 16 || dec0.cin != e.cout ||
       dec0.cin_chunks != 2 || !(dec0.flags & CONV_OUT_NCHW3) || (dec0.flags & (CONV_UP_IN | CONV_NO_RELU | CONV_POOL_OUT)))
     return hipErrorInvalidValue;
   L1DecArgs a;
   a.img = img; a.out = out;
   a.c.w = reinterpret_cast<const u32x4*>(e.l1w16); a.c.b = e.l1bias; a.c.inv = e.l1inv;
-  a.w2 = reinterpret_cast<const u32x4*>(dec0.wpk16); a.b2 = dec0.bias; a.inv2_ptr = dec0.inv_scale_ptr; a.inv2 = dec0.inv_scale;
+  a.w2 = reinterpret_cast<const u32x4*>(dec0.wph16); a.b2 = dec0.bias; a.inv2_ptr = dec0.inv_scale_ptr; a.inv2 = dec0.inv_scale;
   a.H = H; a.W = W; a.tiles_x = (W + FTW - 1) / FTW; a.tiles_y = (H + 7) / 8;
   a.sat = e.sat;
-  const size_t lds = (size_t)2 * IMG_E * 8 + ((size_t)2 * 4 * npp(8) + 2 * 640) * 16;   // 72.5 KB: 2 per CU
+  const size_t lds = (size_t)2 * IMG_E * 8 + ((size_t)2 * 4 * PH_NPX + 2 * PH_WSLOTS) * 16;   // 78.6 KB: 2 per CU
   hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(l1_decode_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (err != hipSuccess) return err;
   const int ntiles = a.tiles_x * a.tiles_y, grid = ntiles < 2 * num_cus() ? ntiles : 2 * num_cus();

@@ -29,6 +29,7 @@ struct LayerDev {
   float* bias = nullptr;
   void* wpk16 = nullptr;  // split-f16 weights (all but the 3-channel first conv)
   void* l1w16 = nullptr;  // 3-channel first conv with <= 32 couts: f16x3 slot packing for the level-1 kernels
+  void* wph16 = nullptr;  // last decoder conv (-> 3 couts): phase-packed split-f16 weights for the fused tails
   float* l1bias = nullptr;
 };
 
@@ -266,6 +267,32 @@ float pack_weights_f16(const float* w, int cout, int cin, int cout_pad, int taps
   return std::ldexp(1.f, -ex);
 }
 
+// the same split (same scale) of a layer with 3 real couts in the phase-packed layout of conv_f16_dev.h c3_phase_compute:
+// [chunk][6 ks][hl][kq][16 m] x 8 halfs;  K-step ks: row dy = ks >> 1, column dx' = 2 (ks & 1) + (kq >> 1), channels 8 (kq & 1) + j;
+// A[m = 8 phase + cout] = w[cout][ch][dy][dx' - phase] where 0 <= dx' - phase <= 2, else 0
+void pack_out3_phase_f16(const float* w, int cout, int cin, std::vector<_Float16>& out) {
+  float mx = 0.f;
+  for (size_t i = 0; i < (size_t)cout * cin * 9; ++i) mx = std::max(mx, std::fabs(w[i]));
+  int ex = 0;
+  if (mx > 0.f && std::isfinite(mx)) { (void)std::frexp(mx, &ex); ex = 9 - ex; }
+  const float scale = std::ldexp(1.f, ex);
+  const int chunks = (cin + 15) / 16;
+  out.assign((size_t)chunks * 6 * 2 * 4 * 16 * 8, (_Float16)0.f);
+  for (int chunk = 0; chunk < chunks; ++chunk)
+    for (int ks = 0; ks < 6; ++ks)
+      for (int kq = 0; kq < 4; ++kq)
+        for (int m = 0; m < 16; ++m)
+          for (int j = 0; j < 8; ++j) {
+            const int phase = m >> 3, co = m & 7, dy = ks >> 1, dxr = 2 * (ks & 1) + (kq >> 1) - phase, ch = chunk * 16 + (kq & 1) * 8 + j;
+            if (co >= cout || co >= 3 || ch >= cin || dxr < 0 || dxr > 2) continue;
+            const float x = w[((size_t)co * cin + ch) * 9 + dy * 3 + dxr] * scale;
+            const _Float16 h = (_Float16)x;
+            const size_t base = ((size_t)chunk * 6 + ks) * 2;
+            out[(((base + 0) * 4 + kq) * 16 + m) * 8 + j] = h;
+            out[(((base + 1) * 4 + kq) * 16 + m) * 8 + j] = (_Float16)(x - (float)h);
+          }
+}
+
 // split-f16 packing of the 3-channel first conv for the fused encoder head (conv3x3_f16.hip, enc_head_kernel):
 // K = 64 in 8-half slots, slot s = 4 kb + kq -> image row dy = s >> 1, pixels 2 (s & 1) + {0, 1}, channels RGB0;
 // layout [kb][hi/lo][kq][16 couts] x 8 halfs.  in3: the fp32 packing [tap][4][16] (conv0 already folded).  Returns 2^-e.
@@ -306,6 +333,7 @@ void free_module(Module& m) {
     if (l.wpk) (void)hipFree(l.wpk);
     if (l.wpk16) (void)hipFree(l.wpk16);
     if (l.l1w16) (void)hipFree(l.l1w16);
+    if (l.wph16) (void)hipFree(l.wph16);
     if (l.l1bias) (void)hipFree(l.l1bias);
     if (l.bias) (void)hipFree(l.bias);
   }
@@ -494,11 +522,15 @@ int fold_impl(wct_ctx* ctx, int level, const double* M, const double* b, ConvDes
   out.wpk = wpk;
   out.bias = bias;
   out.wpk16 = nullptr;
+  out.wph16 = nullptr;
   out.inv_scale_ptr = nullptr;
   if (ctx->conv_mode == 1) {
     const int taps = l.d.cout_pad == 16 ? 10 : 9;
     const size_t b16 = conv_f16_weight_bytes(l.d.cin, l.d.cout_pad, taps);
-    if (int rc = ensure(ctx, ctx->foldW16, b16 + 64)) return rc;
+    // a single-conv decoder (level 1: 24 -> 3) is also needed phase-packed, for l1_decode_kernel
+    const bool phase = (l.d.flags & CONV_OUT_NCHW3) && l.d.cout_pad == 16 && l.d.cout == 3;
+    const size_t bph = phase ? conv_phase_weight_bytes(l.d.cin) : 0;
+    if (int rc = ensure(ctx, ctx->foldW16, b16 + 64 + bph)) return rc;
     char* base = reinterpret_cast<char*>(ctx->foldW16.p);
     float* inv = reinterpret_cast<float*>(base + b16);
     unsigned* maxbits = reinterpret_cast<unsigned*>(base + b16 + 16);
@@ -506,6 +538,11 @@ int fold_impl(wct_ctx* ctx, int level, const double* M, const double* b, ConvDes
     HIPCHK(ctx, launch_split_pack(wpk, l.d.cin, l.d.cout_pad, taps, maxbits, base, inv, st, true));
     out.wpk16 = base;
     out.inv_scale_ptr = inv;
+    out.wph16 = nullptr;
+    if (phase) {
+      HIPCHK(ctx, launch_split_pack_phase(wpk, l.d.cin, maxbits, base + b16 + 64, st));
+      out.wph16 = base + b16 + 64;
+    }
   } else {
     HIPCHK(ctx, launch_fold_affine(l.w_oihw, l.bias_raw, l.d.cout, l.d.cin, l.d.cout_pad, M, b, wpk, bias, nullptr, st));
   }
@@ -791,6 +828,13 @@ int wct_load_module(wct_ctx* ctx, int kind, int level, int n_layers, const wct_l
       HIPCHK(ctx, hipMalloc(&ld.wpk16, w16.size() * sizeof(_Float16)));
       HIPCHK(ctx, hipMemcpy(ld.wpk16, w16.data(), w16.size() * sizeof(_Float16), hipMemcpyHostToDevice));
       ld.d.wpk16 = ld.wpk16;
+      if (out3 && ld.d.cout_pad == 16) {   // phase-packed form for the fused tails
+        std::vector<_Float16> wph;
+        pack_out3_phase_f16(L.weight, L.cout, L.cin, wph);
+        HIPCHK(ctx, hipMalloc(&ld.wph16, wph.size() * sizeof(_Float16)));
+        HIPCHK(ctx, hipMemcpy(ld.wph16, wph.data(), wph.size() * sizeof(_Float16), hipMemcpyHostToDevice));
+        ld.d.wph16 = ld.wph16;
+      }
     }
     if (kind == WCT_KIND_DEC && i == 0) {
       std::vector<float> raw(L.weight, L.weight + (size_t)L.cout * L.cin * 9), rb(L.bias, L.bias + L.cout);
@@ -1194,7 +1238,7 @@ int wct_reserve(wct_ctx* ctx, int H, int W, int Hs, int Ws) {
     moms = std::max(moms, moments_workspace_bytes(C, (long)hs * ws));
     const LayerDev& l0 = d.layers[0];
     if (int rc = ensure(ctx, ctx->foldW, ((size_t)l0.d.cin_chunks * 36 * l0.d.cout_pad * 4 + l0.d.cout_pad) * sizeof(float))) return rc;
-    if (int rc = ensure(ctx, ctx->foldW16, conv_f16_weight_bytes(l0.d.cin, l0.d.cout_pad, l0.d.cout_pad == 16 ? 10 : 9) + 64)) return rc;
+    if (int rc = ensure(ctx, ctx->foldW16, conv_f16_weight_bytes(l0.d.cin, l0.d.cout_pad, l0.d.cout_pad == 16 ? 10 : 9) + 64 + conv_phase_weight_bytes(l0.d.cin))) return rc;
     if (int rc = ensure(ctx, ctx->eigS[level], eig_result_bytes(C))) return rc;
   }
   if (int rc = ensure(ctx, ctx->main.actA, act)) return rc;

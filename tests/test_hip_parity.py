@@ -181,7 +181,8 @@ def test_unfused_reference_sequence_matches_fused(torch_cuda, wct16, golden):
 
 def test_fused_ends_match_unfused(torch_cuda, weights16x):
     """Fused ends vs the layer-by-layer path (odd sizes, image-border tiles).
-    Decoder tail (conv12+conv11): same arithmetic and summation order as the unfused kernels -> bitwise identical.
+    Decoder tail (conv12+conv11): conv12 has the unfused kernel's arithmetic; the final 16 -> 3 conv runs phase-packed in the
+    fused kernel (pairs of pixels per MFMA column, another summation order) -> fp32 round-off agreement.
     Encoder head (conv11+conv12+pool): conv11 runs as f16x3 there and as exact-fp32 MFMA unfused -> fp32-class
     agreement (the tolerance is relative to max|y|, as in the golden tests)."""
     from wct_hip import WCT
@@ -198,7 +199,7 @@ def test_fused_ends_match_unfused(torch_cuda, weights16x):
     for a, b in zip(outs["1"][0], outs["0"][0]):
         assert float((a - b).abs().max() / b.abs().max()) < 3e-6
     for a, b in zip(outs["1"][1], outs["0"][1]):
-        assert torch.equal(a, b)
+        assert a.shape == b.shape and float((a - b).abs().max() / b.abs().max()) < 3e-6
 
 
 def test_sp16_dma_path_bitwise_equals_fp32_activations(torch_cuda, weights16x):
