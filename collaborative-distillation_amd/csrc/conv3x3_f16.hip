@@ -503,8 +503,8 @@ __global__ __launch_bounds__(256, 3) void enc_head_kernel(HeadArgs a) {
       for (int u = 0; u < 3; ++u) {
         f32x4 x;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) x[r] = fmaxf(acc[u][r] * a.inv11 + bias11[r], 0.f);
-        if (gok[i + u]) store_split4(act, NPP, gpix[i + u], kq, x, sat);
+        for (int r = 0; r < 4; ++r) x[r] = acc[u][r] * a.inv11 + bias11[r];
+        if (gok[i + u]) store_split4<true>(act, NPP, gpix[i + u], kq, x, sat);
       }
     }
     HT_STAMP(2);
@@ -709,8 +709,8 @@ __global__ __launch_bounds__(256, 2) void dec_tail_kernel(TailArgs a) {
       for (int u = 0; u < NG; ++u) {
         f32x4 x;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) x[r] = fmaxf(acc[u][r] * inv12 + bias12[r], 0.f);
-        if (gok[u]) store_split4(act1, PH_NPX, gslot[u], kq, x, sat);
+        for (int r = 0; r < 4; ++r) x[r] = acc[u][r] * inv12 + bias12[r];
+        if (gok[u]) store_split4<true>(act1, PH_NPX, gslot[u], kq, x, sat);
       }
     }
     __syncthreads();

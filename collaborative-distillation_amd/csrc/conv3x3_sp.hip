@@ -92,7 +92,7 @@ __global__ __launch_bounds__(512) void conv3x3_sp_kernel(SpArgs a) {
   // 7..18 of them (80 -> 92 us per launch of the 64-cout layers) -- so the "|x| > 65504" lane masks are OR-ed in SCALAR
   // registers instead (v_cmp + s_or_b64 per value; the epilogue runs with all 64 lanes active)
   unsigned long long satmask = 0ull;
-  SatTrack sat_unused;
+  const float lob = a.relu ? 0.f : -65504.f;   // lower clamp bound of the SP16 epilogue: ReLU rides on the range clamp
 
   // ---- DMA of one job into a stage.  Activations: wave-instruction idx = wave + 8 i covers pixel block idx % 10 of
   // plane idx / 10; each lane's pixel offset for the wave's five blocks is recomputed when the tile changes.
@@ -155,13 +155,14 @@ __global__ __launch_bounds__(512) void conv3x3_sp_kernel(SpArgs a) {
     f32x4 x;
     int oy, ox;
     bool ok;
+    // OUTF32: x = the activation.  SP16 out: x = the PRE-activation; ReLU rides on the split's range clamp (lower bound lob)
     if constexpr (POOL) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         float t = fmaxf(r[c][0][4 * q + k], r[c][1][4 * q + k]);
         t = fmaxf(t, lane_xor1(t));
         t = t * inv + bias[k];
-        x[k] = a.relu ? fmaxf(t, 0.f) : t;
+        x[k] = (OUTF32 && a.relu) ? fmaxf(t, 0.f) : t;
       }
       oy = (ty0 + rw * 2) >> 1; ox = gx >> 1;
       ok = !(li & 1) && oy < oH && ox < oW && co < a.cout;
@@ -169,7 +170,7 @@ __global__ __launch_bounds__(512) void conv3x3_sp_kernel(SpArgs a) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         x[k] = r[c][p][4 * q + k] * inv + bias[k];
-        if (a.relu) x[k] = fmaxf(x[k], 0.f);
+        if (OUTF32 && a.relu) x[k] = fmaxf(x[k], 0.f);
       }
       oy = ty0 + rw * 2 + p; ox = gx;
       ok = oy < oH && ox < oW && co < a.cout;
@@ -178,8 +179,12 @@ __global__ __launch_bounds__(512) void conv3x3_sp_kernel(SpArgs a) {
       if (ok) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.out) + ((size_t)oy * oW + ox) * a.cout + co) = x;
     } else {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) satmask |= __ballot(fabsf(x[k]) > 65504.f);
-      const u32x4 w = sp16_pair_exchange<false>(x, sat_unused, true);
+      for (int k = 0; k < 4; ++k) satmask |= __ballot(x[k] > 65504.f);
+      if (!a.relu) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) satmask |= __ballot(x[k] < -65504.f);
+      }
+      const u32x4 w = sp16_pair_exchange_lob(x, lob);
       if (ok) *reinterpret_cast<u32x4*>(a.out + sp16_piece(sp16_plane_bytes(oH, oW), (size_t)oy * oW + ox, co >> 3, kh)) = w;
     }
   };

@@ -59,16 +59,34 @@ struct SatTrack {
   }
 };
 
+// ---- the split itself.  x (already clamped to the f16 range) -> hi = f16(x) (round to nearest even), lo = f16(x - hi), two
+// values at a time as packed pairs.  hi: one v_cvt_pk_f16_f32 per pair.  lo: ONE v_fma_mix{lo,hi}_f16 per value -- it reads hi
+// straight out of the packed register as f16, forms x - hi exactly and rounds once to f16.  (x - hi has <= 13 significant bits,
+// so the former route -- v_cvt_f32_f16, fp32 subtract, v_cvt_f16_f32: 2.5 instructions per value, the compiler does not
+// select the mix form by itself -- rounded the same exact number once: bit-identical results.)
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+struct HiLo { unsigned hi, lo; };
+__device__ __forceinline__ HiLo split2(float x0, float x1) {
+  const f16x2 h = {(_Float16)x0, (_Float16)x1};
+  HiLo r;
+  r.hi = __builtin_bit_cast(unsigned, h);
+  asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixhi_f16 %0, %1, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+      : "=&v"(r.lo) : "v"(r.hi), "v"(x0), "v"(x1));
+  return r;
+}
+__device__ __forceinline__ float clamp_pm(float x) { return __builtin_amdgcn_fmed3f(x, -65504.f, 65504.f); }
+__device__ __forceinline__ float clamp_relu(float x) { return __builtin_amdgcn_fmed3f(x, 0.f, 65504.f); }   // ReLU and the upper clamp in one
+
 __device__ __forceinline__ void split8(const f32x4& a, const f32x4& b, f16x8& hi, f16x8& lo, SatTrack& sat) {
   sat.note(a); sat.note(b);
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    float x = j < 4 ? a[j] : b[j - 4];
-    x = fminf(fmaxf(x, -65504.f), 65504.f);
-    const _Float16 h = (_Float16)x;
-    hi[j] = h;
-    lo[j] = (_Float16)(x - (float)h);
-  }
+  u32x4 h, l;
+  { const HiLo t_ = split2(clamp_pm(a[0]), clamp_pm(a[1])); h[0] = t_.hi; l[0] = t_.lo; }
+  { const HiLo t_ = split2(clamp_pm(a[2]), clamp_pm(a[3])); h[1] = t_.hi; l[1] = t_.lo; }
+  { const HiLo t_ = split2(clamp_pm(b[0]), clamp_pm(b[1])); h[2] = t_.hi; l[2] = t_.lo; }
+  { const HiLo t_ = split2(clamp_pm(b[2]), clamp_pm(b[3])); h[3] = t_.hi; l[3] = t_.lo; }
+  hi = __builtin_bit_cast(f16x8, h);
+  lo = __builtin_bit_cast(f16x8, l);
 }
 
 // ---- "SP16" activation format (intermediate activations of the f16x3 path):
@@ -89,15 +107,8 @@ __device__ __forceinline__ size_t sp16_piece(size_t plane_bytes, size_t pixel, i
 // 4 consecutive channels -> (hi, lo) as 2 + 2 dwords
 template <bool TRACK = true>
 __device__ __forceinline__ void split4(const f32x4& v, u32x2& hi, u32x2& lo, SatTrack& sat, bool nonneg) {
-  f16x4 h, l;
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const float x = fminf(fmaxf(v[r], -65504.f), 65504.f);
-    h[r] = (_Float16)x;
-    l[r] = (_Float16)(x - (float)h[r]);
-  }
-  hi = __builtin_bit_cast(u32x2, h);
-  lo = __builtin_bit_cast(u32x2, l);
+  { const HiLo t_ = split2(clamp_pm(v[0]), clamp_pm(v[1])); hi[0] = t_.hi; lo[0] = t_.lo; }
+  { const HiLo t_ = split2(clamp_pm(v[2]), clamp_pm(v[3])); hi[1] = t_.hi; lo[1] = t_.lo; }
   if constexpr (TRACK) sat.note_hi(hi[0], hi[1], nonneg);
 }
 
@@ -105,7 +116,18 @@ __device__ __forceinline__ void split4(const f32x4& v, u32x2& hi, u32x2& lo, Sat
 // v_permlane32_swap hands the low lane both hi halves and the high lane both lo halves, so each lane writes one
 // 16-byte group: returns the 16 bytes this lane stores at  record + group * 32 + (lane >> 5) * 16.
 // Must be executed by all 64 lanes (no divergence).
-// TRACK = false: the caller keeps its own saturation record (the DMA kernel: wave-wide masks in scalar registers)
+// the DMA kernel's form: `v` is the PRE-activation, `lob` the (wave-uniform) lower clamp bound -- 0 with ReLU (ReLU and the
+// range clamp are then one v_med3_f32), -65504 without; the caller keeps its own saturation record
+__device__ __forceinline__ u32x4 sp16_pair_exchange_lob(const f32x4& v, float lob) {
+  u32x2 hi, lo;
+  { const HiLo t_ = split2(__builtin_amdgcn_fmed3f(v[0], lob, 65504.f), __builtin_amdgcn_fmed3f(v[1], lob, 65504.f)); hi[0] = t_.hi; lo[0] = t_.lo; }
+  { const HiLo t_ = split2(__builtin_amdgcn_fmed3f(v[2], lob, 65504.f), __builtin_amdgcn_fmed3f(v[3], lob, 65504.f)); hi[1] = t_.hi; lo[1] = t_.lo; }
+  const auto ra = __builtin_amdgcn_permlane32_swap(hi[0], lo[0], false, false);
+  const auto rb = __builtin_amdgcn_permlane32_swap(hi[1], lo[1], false, false);
+  return u32x4{ra[0], rb[0], ra[1], rb[1]};
+}
+
+// TRACK = false: the caller keeps its own saturation record
 template <bool TRACK = true>
 __device__ __forceinline__ u32x4 sp16_pair_exchange(const f32x4& v, SatTrack& sat, bool nonneg) {
   u32x2 hi, lo;
@@ -192,34 +214,32 @@ __device__ __forceinline__ void head_commit(const float (&r)[2][3], u32x2* imgH,
     const int e = tid + 256 * k;
     sat.note3(r[k][0], r[k][1], r[k][2]);
     if (e < NPI2) {
-      f16x4 h = {0, 0, 0, 0}, l = {0, 0, 0, 0};
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        const float x = fminf(fmaxf(r[k][c], -65504.f), 65504.f);
-        h[c] = (_Float16)x;
-        l[c] = (_Float16)(x - (float)h[c]);
-      }
-      imgH[e] = __builtin_bit_cast(u32x2, h);
-      imgL[e] = __builtin_bit_cast(u32x2, l);
+      u32x2 h, l;
+      { const HiLo t_ = split2(clamp_pm(r[k][0]), clamp_pm(r[k][1])); h[0] = t_.hi; l[0] = t_.lo; }
+      { const HiLo t_ = split2(clamp_pm(r[k][2]), 0.f); h[1] = t_.hi; l[1] = t_.lo; }
+      imgH[e] = h;
+      imgL[e] = l;
     }
   }
 }
 
+// 4 consecutive channels 4kq..4kq+3 of halo pixel `pix` -> 8 bytes in the hi plane and 8 in the lo plane.  RELU: `v` is the
+// pre-activation; ReLU and the range clamp are one v_med3_f32 (the range record then looks at the positive side only)
+template <bool RELU = false>
 __device__ __forceinline__ void store_split4(u32x4* planes, int npp, int pix, int kq, const f32x4& v, SatTrack& sat) {
-  // 4 consecutive channels 4kq..4kq+3 of halo pixel `pix` -> 8 bytes in the hi plane and 8 in the lo plane
-  sat.note(v);
-  _Float16 h[4], l[4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const float x = fminf(fmaxf(v[r], -65504.f), 65504.f);
-    h[r] = (_Float16)x;
-    l[r] = (_Float16)(x - (float)h[r]);
+  u32x2 h, l;
+  if constexpr (RELU) {
+    sat.m = fmaxf(fmaxf(sat.m, v[0]), v[1]);
+    sat.m = fmaxf(fmaxf(sat.m, v[2]), v[3]);
+    { const HiLo t_ = split2(clamp_relu(v[0]), clamp_relu(v[1])); h[0] = t_.hi; l[0] = t_.lo; }
+    { const HiLo t_ = split2(clamp_relu(v[2]), clamp_relu(v[3])); h[1] = t_.hi; l[1] = t_.lo; }
+  } else {
+    sat.note(v);
+    { const HiLo t_ = split2(clamp_pm(v[0]), clamp_pm(v[1])); h[0] = t_.hi; l[0] = t_.lo; }
+    { const HiLo t_ = split2(clamp_pm(v[2]), clamp_pm(v[3])); h[1] = t_.hi; l[1] = t_.lo; }
   }
-  typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-  f16x4* ph = reinterpret_cast<f16x4*>(planes + (0 * 2 + (kq >> 1)) * npp + pix) + (kq & 1);
-  f16x4* pl = reinterpret_cast<f16x4*>(planes + (1 * 2 + (kq >> 1)) * npp + pix) + (kq & 1);
-  *ph = f16x4{h[0], h[1], h[2], h[3]};
-  *pl = f16x4{l[0], l[1], l[2], l[3]};
+  *(reinterpret_cast<u32x2*>(planes + (0 * 2 + (kq >> 1)) * npp + pix) + (kq & 1)) = h;
+  *(reinterpret_cast<u32x2*>(planes + (1 * 2 + (kq >> 1)) * npp + pix) + (kq & 1)) = l;
 }
 
 // 16->16 conv on the [4][NPP] planes of a 34 x 10 halo tile for the wave's 2 rows x 32 px (the c16 kernel's body)
@@ -311,6 +331,8 @@ __device__ __forceinline__ void l1_load_weights(const L1Conv& c, int li, int kq,
 
 // relu(conv11) of 16 pixels (lane & 15; `base` = index of the pixel's 3x3 window's top-left in the 36-wide RGB0 tile)
 // x 16 couts of tile ct:  result rows = couts ct * 16 + 4 kq + {0..3}
+// RELU = false: the pre-activation (the caller merges ReLU with the range clamp of its split: store_split4<true>)
+template <bool RELU = true>
 __device__ __forceinline__ f32x4 l1_conv_group(const u32x2* imgH, const u32x2* imgL, int base, int kq, const L1Weights& w, int ct) {
   f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -327,7 +349,10 @@ __device__ __forceinline__ f32x4 l1_conv_group(const u32x2* imgH, const u32x2* i
   }
   f32x4 x;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) x[r] = fmaxf(acc[r] * w.inv + w.bias[ct][r], 0.f);
+  for (int r = 0; r < 4; ++r) {
+    x[r] = acc[r] * w.inv + w.bias[ct][r];
+    if constexpr (RELU) x[r] = fmaxf(x[r], 0.f);
+  }
   return x;
 }
 

@@ -150,8 +150,8 @@ __global__ __launch_bounds__(256, 2) void l1_decode_kernel(L1DecArgs a) {
       }
 #pragma unroll
       for (int ct = 0; ct < 2; ++ct) {
-        const f32x4 x = l1_conv_group(imgH, imgL, base, kq, w, ct);
-        if (gok[u]) store_split4(act + ct * 4 * PH_NPX, PH_NPX, gslot[u], kq, x, sat);
+        const f32x4 x = l1_conv_group<false>(imgH, imgL, base, kq, w, ct);
+        if (gok[u]) store_split4<true>(act + ct * 4 * PH_NPX, PH_NPX, gslot[u], kq, x, sat);
       }
     }
     __syncthreads();

@@ -1,5 +1,6 @@
 // Small helper kernels: layout changes at the API boundary and weight preparation for the fused apply.
 #include "wct_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -35,15 +36,50 @@ __global__ __launch_bounds__(256) void fold_row_kernel(const float* w, const flo
   if (live) for (int e = tid; e < cin * 9; e += 256) wrow[e] = w[(size_t)o * cin * 9 + e];
   __syncthreads();
   float mx = 0.f;
-  for (int e = tid; e < 9 * ipad; e += 256) {
-    const int tap = e / ipad, i = e - tap * ipad;
-    double s = 0.;
-    if (live && i < cin)
-      for (int c = 0; c < cin; ++c) s += (double)wrow[c * 9 + tap] * M[(size_t)c * cin + i];
-    const float v = (float)s;
-    mx = fmaxf(mx, fabsf(v));
-    const int chunk = i >> 4, kq = (i >> 2) & 3, r = i & 3;
-    wpk[((((size_t)chunk * 9 + tap) * 4 + kq) * cout_pad + o) * 4 + r] = v;
+  if (ipad <= 256 && (256 % ipad) == 0) {
+    // a thread owns ONE input column i and the taps tg, tg + G, tg + 2G, ... (G = 256 / ipad column groups): one pass over c
+    // with NT = ceil(9 / G) independent accumulators and one M element per step, instead of 9 * ipad / 256 dependent passes.
+    // Every (tap, i) still sums over c in the same order: bit-identical results.
+    const int G = 256 / ipad, i = tid % ipad, tg = tid / ipad;
+    auto run = [&](auto nt_tag) {
+      constexpr int NT = decltype(nt_tag)::value;
+      double s[NT];
+      int tp[NT];
+#pragma unroll
+      for (int k = 0; k < NT; ++k) { s[k] = 0.; const int t = tg + k * G; tp[k] = t < 9 ? t : 8; }   // clamped: a surplus slot repeats tap 8
+      if (live && i < cin)
+        for (int c = 0; c < cin; ++c) {
+          const double m = M[(size_t)c * cin + i];
+#pragma unroll
+          for (int k = 0; k < NT; ++k) s[k] += (double)wrow[c * 9 + tp[k]] * m;
+        }
+      const int chunk = i >> 4, kq = (i >> 2) & 3, r = i & 3;
+#pragma unroll
+      for (int k = 0; k < NT; ++k) {
+        const int tap = tg + k * G;
+        if (tap < 9) {
+          const float v = (float)s[k];
+          mx = fmaxf(mx, fabsf(v));
+          wpk[((((size_t)chunk * 9 + tap) * 4 + kq) * cout_pad + o) * 4 + r] = v;
+        }
+      }
+    };
+    if (G == 1) run(std::integral_constant<int, 9>{});
+    else if (G == 2) run(std::integral_constant<int, 5>{});
+    else if (G == 4) run(std::integral_constant<int, 3>{});
+    else if (G == 8) run(std::integral_constant<int, 2>{});
+    else run(std::integral_constant<int, 1>{});
+  } else {
+    for (int e = tid; e < 9 * ipad; e += 256) {
+      const int tap = e / ipad, i = e - tap * ipad;
+      double s = 0.;
+      if (live && i < cin)
+        for (int c = 0; c < cin; ++c) s += (double)wrow[c * 9 + tap] * M[(size_t)c * cin + i];
+      const float v = (float)s;
+      mx = fmaxf(mx, fabsf(v));
+      const int chunk = i >> 4, kq = (i >> 2) & 3, r = i & 3;
+      wpk[((((size_t)chunk * 9 + tap) * 4 + kq) * cout_pad + o) * 4 + r] = v;
+    }
   }
   double part = 0.;
   if (live)
