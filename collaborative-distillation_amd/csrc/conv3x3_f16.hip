@@ -25,6 +25,7 @@
 //   Cout == 16 (and the 3-channel last conv, padded): 16x16x32, the 32-deep K holds TWO taps x 16 channels.
 #include "wct_common.h"
 #include "conv_f16_dev.h"
+#include <cstdlib>
 
 namespace {
 
@@ -563,28 +564,40 @@ struct TailArgs {   // conv12 (16->16 on the nearest-x2 upsampled input) + ReLU 
   unsigned* sat;
 };
 
-constexpr int TAIL_SL = (NPI2 * 2 + 255) / 256;  // 4 register slots of 8 channels per thread
-struct TailRegs { f32x4 v0[TAIL_SL], v1[TAIL_SL]; };
+// Tile geometry of the fused tail for a tile of 32 x TH output pixels (TH / 2 waves, 32 * TH threads): TH = 8 -> 4 waves, two
+// workgroups per CU; TH = 16 -> 8 waves, one workgroup per CU, conv12's halo recompute 612 / 512 = 1.20 instead of 340 / 256 = 1.33
+template <int TH>
+struct TailGeo {
+  static constexpr int NT = 32 * TH, NWV = TH / 2;
+  static constexpr int HROWS = TH + 2, NPH = FHW * HROWS, NGRP = (NPH + 15) / 16, NG = (NGRP + NWV - 1) / NWV;
+  static constexpr int I2HT = TH + 4, NPI = I2W * I2HT;                      // input window 36 x (TH + 4): 432 / 720 pixels
+  static constexpr int SL = (NPI * 2 + NT - 1) / NT;                         // register slots of 8 channels per thread: 4 / 3
+  static constexpr int NPX = (HROWS * PH_W + 15) / 16 * 16;                  // pair-major slots of the conv12 output: 368 / 656
+  static_assert(NPI % 16 == 0 && (NPI * 16) % 256 == 0 && (NPX * 16) % 256 == 0, "plane strides");
+};
+template <int TH> struct TailRegs { f32x4 v0[TailGeo<TH>::SL], v1[TailGeo<TH>::SL]; };
 
 // soff[k]: tile-independent element offset of slot k from the window origin, valid for interior tiles (the window
 // origin (ty0 - 2, tx0 - 2) is even, so the nearest-x2 shift distributes over origin + offset)
-__device__ __forceinline__ void tail_fetch(const TailArgs& a, unsigned txm, TailRegs& r, const int (&soff)[TAIL_SL], int tile, int tid) {
+template <int TH>
+__device__ __forceinline__ void tail_fetch(const TailArgs& a, unsigned txm, TailRegs<TH>& r, const int (&soff)[TailGeo<TH>::SL], int tile, int tid) {
+  using G = TailGeo<TH>;
   int trow_, tcol_;
   tile_rc(tile, a.tiles_x, txm, trow_, tcol_);
-  const int ty0 = trow_ * 8, tx0 = tcol_ * FTW;
-  if (tile_interior(ty0, tx0, a.H, a.W)) {
+  const int ty0 = trow_ * TH, tx0 = tcol_ * FTW;
+  if (tile_interior_h(ty0, tx0, a.H, a.W, TH)) {
     const float* base = a.in + ((size_t)((ty0 - 2) >> a.up_in) * a.inW + ((tx0 - 2) >> a.up_in)) * 16;
 #pragma unroll
-    for (int k = 0; k < TAIL_SL; ++k) {
+    for (int k = 0; k < G::SL; ++k) {
       r.v0[k] = *reinterpret_cast<const f32x4*>(base + soff[k]);
       r.v1[k] = *reinterpret_cast<const f32x4*>(base + soff[k] + 4);
     }
     return;
   }
 #pragma unroll
-  for (int k = 0; k < TAIL_SL; ++k) {
-    int e = tid + 256 * k;
-    e = e < NPI2 * 2 ? e : NPI2 * 2 - 1;
+  for (int k = 0; k < G::SL; ++k) {
+    int e = tid + G::NT * k;
+    e = e < G::NPI * 2 ? e : G::NPI * 2 - 1;
     const int h2 = e & 1, pix = e >> 1;
     const int py = pix / I2W, px = pix - py * I2W;
     int gy = reflect_clamp(ty0 - 2 + py, a.H), gx = reflect_clamp(tx0 - 2 + px, a.W);
@@ -595,56 +608,60 @@ __device__ __forceinline__ void tail_fetch(const TailArgs& a, unsigned txm, Tail
   }
 }
 
-__device__ __forceinline__ void tail_commit(const TailRegs& r, u32x4* act0, int tid, int in_sp, SatTrack& sat) {
+template <int TH>
+__device__ __forceinline__ void tail_commit(const TailRegs<TH>& r, u32x4* act0, int tid, int in_sp, SatTrack& sat) {
+  using G = TailGeo<TH>;
 #pragma unroll
-  for (int k = 0; k < TAIL_SL; ++k) {
-    const int e = tid + 256 * k;
-    if (e < NPI2 * 2) {
+  for (int k = 0; k < G::SL; ++k) {
+    const int e = tid + G::NT * k;
+    if (e < G::NPI * 2) {
       f16x8 hi, lo;
       if (in_sp) { hi = __builtin_bit_cast(f16x8, r.v0[k]); lo = __builtin_bit_cast(f16x8, r.v1[k]); }
       else split8(r.v0[k], r.v1[k], hi, lo, sat);
-      act0[(0 * 2 + (e & 1)) * NPI2 + (e >> 1)] = __builtin_bit_cast(u32x4, hi);
-      act0[(1 * 2 + (e & 1)) * NPI2 + (e >> 1)] = __builtin_bit_cast(u32x4, lo);
+      act0[(0 * 2 + (e & 1)) * G::NPI + (e >> 1)] = __builtin_bit_cast(u32x4, hi);
+      act0[(1 * 2 + (e & 1)) * G::NPI + (e >> 1)] = __builtin_bit_cast(u32x4, lo);
     }
   }
 }
 
-// Persistent like enc_head_kernel: both weight slabs are staged once per workgroup, the 36 x 12 x 16 input window of
+// Persistent like enc_head_kernel: both weight slabs are staged once per workgroup, the 36 x (TH + 4) x 16 input window of
 // the NEXT tile is fetched into registers while this tile is on the matrix cores and split into LDS behind conv11.
 // Everything that depends only on the thread (slot offsets, halo-group pixel indices) is computed once; only tiles
 // that touch the image border recompute their reflected coordinates.
-__global__ __launch_bounds__(256, 2) void dec_tail_kernel(TailArgs a) {
+template <int TH>
+__global__ __launch_bounds__(32 * TH, TH == 8 ? 2 : 1) void dec_tail_kernel(TailArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int NPH = nph(8), NG = 6;
-  u32x4* act0 = reinterpret_cast<u32x4*>(smem);   // [4][432]  input of conv12 (two halo rings)
-  u32x4* wg12 = act0 + 4 * NPI2;                  // [640]
+  using G = TailGeo<TH>;
+  constexpr int NT = G::NT, NWV = G::NWV, NPH = G::NPH, NG = G::NG, NPI = G::NPI, NPX = G::NPX, SL = G::SL;
+  u32x4* act0 = reinterpret_cast<u32x4*>(smem);   // [4][NPI]  input of conv12 (two halo rings)
+  u32x4* wg12 = act0 + 4 * NPI;                   // [640]
   u32x4* wg11 = wg12 + 640;                       // [PH_WSLOTS]  phase-packed 16 -> 3 weights
-  u32x4* act1 = wg11 + PH_WSLOTS;                 // [4][PH_NPX]  conv12 output on the 34 x 10 halo, pair-major slots (ph_slot)
+  u32x4* act1 = wg11 + PH_WSLOTS;                 // [4][NPX]  conv12 output on the 34 x (TH + 2) halo, pair-major slots (ph_slot)
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, kq = lane >> 4, kh = kq & 1, ts = kq >> 1;
   const int ntiles = a.tiles_x * a.tiles_y;
   const unsigned txm = tile_div_magic(a.tiles_x);   // once per workgroup; tile_rc() then stays on the scalar unit
-  for (int e = tid; e < 640; e += 256) wg12[e] = a.w12[e];
-  for (int e = tid; e < PH_WSLOTS; e += 256) wg11[e] = a.w11[e];
+  for (int e = tid; e < 640; e += NT) wg12[e] = a.w12[e];
+  for (int e = tid; e < PH_WSLOTS; e += NT) wg11[e] = a.w11[e];
   const float inv12 = a.inv12_ptr ? *a.inv12_ptr : a.inv12;
   const f32x4 bias12 = *reinterpret_cast<const f32x4*>(a.b12 + 4 * kq);
   const f32x4 bias11 = *reinterpret_cast<const f32x4*>(a.b11);
   const size_t plane = (size_t)a.H * a.W;
 
-  int soff[TAIL_SL];
+  int soff[SL];
 #pragma unroll
-  for (int k = 0; k < TAIL_SL; ++k) {
-    int e = tid + 256 * k;
-    e = e < NPI2 * 2 ? e : NPI2 * 2 - 1;
+  for (int k = 0; k < SL; ++k) {
+    int e = tid + NT * k;
+    e = e < NPI * 2 ? e : NPI * 2 - 1;
     const int pix = e >> 1, py = pix / I2W, px = pix - py * I2W;
     soff[k] = ((py >> a.up_in) * a.inW + (px >> a.up_in)) * 16 + (e & 1) * 8;
   }
-  // the wave's six 16-pixel groups of the 34 x 10 halo (group 5 exists for waves 0 and 1 only: 22 groups)
+  // the wave's NG 16-pixel groups of the 34 x (TH + 2) halo (22 groups over 4 waves / 39 over 8: the last ones may not exist)
   int gpix[NG], gpy[NG], gpx[NG], gslot[NG];
   bool gok[NG];
 #pragma unroll
   for (int u = 0; u < NG; ++u) {
-    const int pixr = (wave + 4 * u) * 16 + li;
+    const int pixr = (wave + NWV * u) * 16 + li;
     gok[u] = pixr < NPH;
     gpix[u] = gok[u] ? pixr : NPH - 1;
     gpy[u] = gpix[u] / FHW;
@@ -652,28 +669,28 @@ __global__ __launch_bounds__(256, 2) void dec_tail_kernel(TailArgs a) {
     gslot[u] = ph_slot(gpy[u], gpx[u]);
   }
 
-  TailRegs tr;
+  TailRegs<TH> tr;
   SatTrack sat;
   int v = blockIdx.x;
   if (v < ntiles) {
-    tail_fetch(a, txm, tr, soff, xcd_swizzle(v, ntiles), tid);
-    tail_commit(tr, act0, tid, a.in_sp, sat);
+    tail_fetch<TH>(a, txm, tr, soff, xcd_swizzle(v, ntiles), tid);
+    tail_commit<TH>(tr, act0, tid, a.in_sp, sat);
   }
   for (; v < ntiles; v += gridDim.x) {
     const int tile = xcd_swizzle(v, ntiles);
     int trow_, tcol_;
     tile_rc(tile, a.tiles_x, txm, trow_, tcol_);
-    const int ty0 = trow_ * 8, tx0 = tcol_ * FTW;
+    const int ty0 = trow_ * TH, tx0 = tcol_ * FTW;
     __syncthreads();   // act0 of this tile is in LDS; every wave is done with the previous tile's act1
     const int vn = v + gridDim.x;
-    if (vn < ntiles) tail_fetch(a, txm, tr, soff, xcd_swizzle(vn, ntiles), tid);
-    // ---- conv12 on the 340 halo pixels (evaluated at their reflected image coordinates), into act1.
-    //      All six groups are in flight together (tap loop outermost): the operand reads of the next tap pair overlap
+    if (vn < ntiles) tail_fetch<TH>(a, txm, tr, soff, xcd_swizzle(vn, ntiles), tid);
+    // ---- conv12 on the halo pixels (evaluated at their reflected image coordinates), into act1.
+    //      All the wave's groups are in flight together (tap loop outermost): the operand reads of the next tap pair overlap
     //      the MFMAs of this one.
     {
       f32x4 acc[NG];
       int sp0[NG];
-      if (tile_interior(ty0, tx0, a.H, a.W)) {
+      if (tile_interior_h(ty0, tx0, a.H, a.W, TH)) {
 #pragma unroll
         for (int u = 0; u < NG; ++u) sp0[u] = gpy[u] * I2W + gpx[u];
       } else {
@@ -696,8 +713,8 @@ __global__ __launch_bounds__(256, 2) void dec_tail_kernel(TailArgs a) {
 #pragma unroll
         for (int u = 0; u < NG; ++u) {
           const int sp = sp0[u] + dy * I2W + dx;
-          bh[u] = __builtin_bit_cast(f16x8, act0[(0 * 2 + kh) * NPI2 + sp]);
-          bl[u] = __builtin_bit_cast(f16x8, act0[(1 * 2 + kh) * NPI2 + sp]);
+          bh[u] = __builtin_bit_cast(f16x8, act0[(0 * 2 + kh) * NPI + sp]);
+          bl[u] = __builtin_bit_cast(f16x8, act0[(1 * 2 + kh) * NPI + sp]);
         }
 #pragma unroll
         for (int term = 0; term < 3; ++term)
@@ -710,7 +727,7 @@ __global__ __launch_bounds__(256, 2) void dec_tail_kernel(TailArgs a) {
         f32x4 x;
 #pragma unroll
         for (int r = 0; r < 4; ++r) x[r] = acc[u][r] * inv12 + bias12[r];
-        if (gok[u]) store_split4<true>(act1, PH_NPX, gslot[u], kq, x, sat);
+        if (gok[u]) store_split4<true>(act1, NPX, gslot[u], kq, x, sat);
       }
     }
     __syncthreads();
@@ -720,7 +737,7 @@ __global__ __launch_bounds__(256, 2) void dec_tail_kernel(TailArgs a) {
     for (int r = 0; r < 2; ++r)
 #pragma unroll
       for (int h = 0; h < 2; ++h) acc[r][h] = f32x4{0.f, 0.f, 0.f, 0.f};
-    c3_phase_compute(act1, wg11, wave, li, kq, acc);
+    c3_phase_compute<NPX>(act1, wg11, wave, li, kq, acc);
     if (!(kq & 1)) {
       const int gx = tx0 + 2 * li + (kq >> 1);
 #pragma unroll
@@ -734,7 +751,7 @@ __global__ __launch_bounds__(256, 2) void dec_tail_kernel(TailArgs a) {
         }
       }
     }
-    if (vn < ntiles) tail_commit(tr, act0, tid, a.in_sp, sat);   // conv12 of this tile is behind the barrier above
+    if (vn < ntiles) tail_commit<TH>(tr, act0, tid, a.in_sp, sat);   // conv12 of this tile is behind the barrier above
   }
   sat.commit(a.sat);
 }
@@ -860,13 +877,22 @@ hipError_t launch_dec_tail(const ConvDesc& d0, const ConvDesc& d1, const float* 
   a.H = H; a.W = W; a.up_in = (d0.flags & CONV_UP_IN) ? 1 : 0; a.inW = a.up_in ? W / 2 : W;
   a.in_sp = (d0.flags & CONV_IN_SP16) ? 1 : 0;
   a.sat = d1.sat;
-  a.tiles_x = (W + FTW - 1) / FTW; a.tiles_y = (H + 7) / 8;
-  const size_t lds = ((size_t)4 * NPI2 + 640 + PH_WSLOTS + (size_t)4 * PH_NPX) * 16;   // 73.7 KB: 2 per CU
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(dec_tail_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e != hipSuccess) return e;
-  const int ntiles = a.tiles_x * a.tiles_y, grid = ntiles < 2 * num_cus() ? ntiles : 2 * num_cus();
-  hipLaunchKernelGGL(dec_tail_kernel, dim3(grid), dim3(256), lds, s, a);
-  return hipGetLastError();
+  a.tiles_x = (W + FTW - 1) / FTW;
+  static const int th_env = [] { const char* e = wct_debug_env("WCT_TAIL_TH"); return e ? atoi(e) : 0; }();   // experiment: force 8 / 16
+  // 32 x 16 tiles (conv12's halo recompute 1.20 instead of 1.33: -10 % at 4K) once they still fill the chip; results do not
+  // depend on the tile shape (same arithmetic per pixel)
+  const int th = th_env ? th_env : (((H + 15) / 16) * a.tiles_x >= 2 * num_cus() ? 16 : 8);
+  auto go = [&](auto kern, auto geo, int per_cu) -> hipError_t {
+    using G = decltype(geo);
+    a.tiles_y = (H + G::HROWS - 3) / (G::HROWS - 2);
+    const size_t lds = ((size_t)4 * G::NPI + 640 + PH_WSLOTS + (size_t)4 * G::NPX) * 16;   // 73.7 KB (TH = 8: 2 per CU) / 110.6 KB (TH = 16)
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    const int ntiles = a.tiles_x * a.tiles_y, grid = ntiles < per_cu * num_cus() ? ntiles : per_cu * num_cus();
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(G::NT), lds, s, a);
+    return hipGetLastError();
+  };
+  return th == 16 ? go(dec_tail_kernel<16>, TailGeo<16>{}, 1) : go(dec_tail_kernel<8>, TailGeo<8>{}, 2);
 }
 
 size_t conv_f16_weight_bytes(int cin, int cout_pad, int taps) {

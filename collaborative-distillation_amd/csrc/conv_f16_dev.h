@@ -177,9 +177,18 @@ __device__ __forceinline__ float lane_xor1(float x) {
   return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, true));
 }
 
+// (uniform) the same for a tile of 32 x th output pixels
+__device__ __forceinline__ bool tile_interior_h(int ty0, int tx0, int H, int W, int th) {
+  return ty0 >= 2 && ty0 + th + 2 <= H && tx0 >= 2 && tx0 + 34 <= W;
+}
+
+// TH: tile height (8: 4 waves / 256 threads, the 36 x 12 window; 16: 8 waves / 512 threads, 36 x 20) -- two pixels per thread either way
+template <int TH = 8>
 __device__ __forceinline__ void head_fetch(const float* img, int H, int W, float (&r)[2][3], const int (&soff)[2], int ty0, int tx0, int tid) {
+  constexpr int NT = 32 * TH, NPI = I2W * (TH + 4);
+  static_assert(2 * NT >= NPI, "two pixels per thread cover the window");
   const size_t plane = (size_t)H * W;
-  if (tile_interior(ty0, tx0, H, W)) {
+  if (tile_interior_h(ty0, tx0, H, W, TH)) {
     // uniform base per plane + the thread's UNSIGNED 32-bit offset: global_load with an SGPR base (a signed index is widened
     // to a 64-bit VGPR pair per load)
     const float* base = img + (size_t)(ty0 - 2) * W + (tx0 - 2);
@@ -193,8 +202,8 @@ __device__ __forceinline__ void head_fetch(const float* img, int H, int W, float
   }
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
-    int e = tid + 256 * k;
-    e = e < NPI2 ? e : NPI2 - 1;
+    int e = tid + NT * k;
+    e = e < NPI ? e : NPI - 1;
     const int py = e / I2W, px = e - py * I2W;
     const size_t off = (size_t)reflect_clamp(ty0 - 2 + py, H) * W + reflect_clamp(tx0 - 2 + px, W);
 #pragma unroll
@@ -202,18 +211,21 @@ __device__ __forceinline__ void head_fetch(const float* img, int H, int W, float
   }
 }
 
+template <int TH = 8>
 __device__ __forceinline__ void head_fetch(const float* img, int H, int W, int tiles_x, unsigned tx_magic, float (&r)[2][3], const int (&soff)[2], int tile, int tid) {
   int tr, tc;
   tile_rc(tile, tiles_x, tx_magic, tr, tc);
-  head_fetch(img, H, W, r, soff, tr * 8, tc * FTW, tid);
+  head_fetch<TH>(img, H, W, r, soff, tr * TH, tc * FTW, tid);
 }
 
+template <int TH = 8>
 __device__ __forceinline__ void head_commit(const float (&r)[2][3], u32x2* imgH, u32x2* imgL, int tid, SatTrack& sat) {
+  constexpr int NT = 32 * TH, NPI = I2W * (TH + 4);
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
-    const int e = tid + 256 * k;
+    const int e = tid + NT * k;
     sat.note3(r[k][0], r[k][1], r[k][2]);
-    if (e < NPI2) {
+    if (e < NPI) {
       u32x2 h, l;
       { const HiLo t_ = split2(clamp_pm(r[k][0]), clamp_pm(r[k][1])); h[0] = t_.hi; l[0] = t_.lo; }
       { const HiLo t_ = split2(clamp_pm(r[k][2]), 0.f); h[1] = t_.hi; l[1] = t_.lo; }
@@ -287,10 +299,11 @@ constexpr int PH_W = 36, PH_NPX = ((8 + 2) * PH_W + 15) / 16 * 16;   // 368 slot
 constexpr int PH_WSLOTS = 6 * 2 * 4 * 16;                             // 768 weight slots per 16-channel chunk
 __host__ __device__ inline int ph_slot(int py, int px) { return py * PH_W + (px & 1) * 17 + (px >> 1); }
 
+template <int NPX = PH_NPX>   // slots per plane: PH_NPX for the 34 x 10 halo of a 32 x 8 tile
 __device__ __forceinline__ void c3_phase_compute(const u32x4* act, const u32x4* wgt, int wave, int li, int kq, f32x4 (&acc)[2][2]) {
   const int kh = kq & 1, p = kq >> 1;
-  const u32x4* ah_ = act + (0 * 2 + kh) * PH_NPX + p * 17 + li;   // per-lane part of the slot: column parity plane + pair index
-  const u32x4* al_ = act + (1 * 2 + kh) * PH_NPX + p * 17 + li;
+  const u32x4* ah_ = act + (0 * 2 + kh) * NPX + p * 17 + li;   // per-lane part of the slot: column parity plane + pair index
+  const u32x4* al_ = act + (1 * 2 + kh) * NPX + p * 17 + li;
 #pragma unroll
   for (int ks = 0; ks < 6; ++ks) {
     const int dy = ks >> 1, c1 = ks & 1;          // dx' = 2 c1 + p: parity p, half index c1

@@ -12,6 +12,7 @@
 // three kernels share l1_conv_group(), so their relu1_1 values are bit-identical.
 #include "wct_common.h"
 #include "conv_f16_dev.h"
+#include <cstdlib>
 
 namespace {
 
@@ -85,20 +86,30 @@ __global__ __launch_bounds__(256, 3) void l1_encode_kernel(L1EncArgs a) {
   sat.commit(a.sat);
 }
 
-// image -> relu1_1 on the 34 x 10 halo (LDS, split f16) -> folded decoder conv (24 -> 3) + ReLU -> planar image
-__global__ __launch_bounds__(256, 2) void l1_decode_kernel(L1DecArgs a) {
+// image -> relu1_1 on the 34 x (TH + 2) halo (LDS, split f16) -> folded decoder conv (24 -> 3) + ReLU -> planar image.
+// TH = 8: 4 waves, two workgroups per CU; TH = 16: 8 waves, one workgroup per CU, halo recompute 1.20 instead of 1.33.
+template <int TH>
+struct L1DecGeo {
+  static constexpr int NT = 32 * TH, NWV = TH / 2, HROWS = TH + 2, NPH = FHW * HROWS, NGRP = (NPH + 15) / 16, NG = (NGRP + NWV - 1) / NWV;
+  static constexpr int NPI = I2W * (TH + 4), IMGE = NPI + 4, NPX = (HROWS * PH_W + 15) / 16 * 16;
+  static constexpr size_t lds = (size_t)2 * IMGE * 8 + ((size_t)2 * 4 * NPX + 2 * PH_WSLOTS) * 16;   // 78.6 KB / 120.2 KB
+};
+
+template <int TH>
+__global__ __launch_bounds__(32 * TH, TH == 8 ? 2 : 1) void l1_decode_kernel(L1DecArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int NPH = nph(8), NG = 6;
+  using G = L1DecGeo<TH>;
+  constexpr int NT = G::NT, NWV = G::NWV, NPH = G::NPH, NG = G::NG, NPI = G::NPI, NPX = G::NPX;
   u32x2* imgH = reinterpret_cast<u32x2*>(smem);
-  u32x2* imgL = imgH + IMG_E;
-  u32x4* act = reinterpret_cast<u32x4*>(imgL + IMG_E);   // [2 chunks][4][PH_NPX]  relu1_1 on the halo, pair-major slots (ph_slot)
-  u32x4* wgt = act + 2 * 4 * PH_NPX;                      // [2 chunks][PH_WSLOTS]
+  u32x2* imgL = imgH + G::IMGE;
+  u32x4* act = reinterpret_cast<u32x4*>(imgL + G::IMGE);   // [2 chunks][4][NPX]  relu1_1 on the halo, pair-major slots (ph_slot)
+  u32x4* wgt = act + 2 * 4 * NPX;                          // [2 chunks][PH_WSLOTS]
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, kq = lane >> 4;
   const int ntiles = a.tiles_x * a.tiles_y;
   const unsigned txm = tile_div_magic(a.tiles_x);   // once per workgroup; tile_rc() then stays on the scalar unit
-  for (int e = tid; e < 2 * PH_WSLOTS; e += 256) wgt[e] = a.w2[e];
-  if (tid < 4) { imgH[NPI2 + tid] = u32x2{0u, 0u}; imgL[NPI2 + tid] = u32x2{0u, 0u}; }
+  for (int e = tid; e < 2 * PH_WSLOTS; e += NT) wgt[e] = a.w2[e];
+  if (tid < 4) { imgH[NPI + tid] = u32x2{0u, 0u}; imgL[NPI + tid] = u32x2{0u, 0u}; }
   L1Weights w;
   l1_load_weights(a.c, li, kq, w);
   const float inv2 = a.inv2_ptr ? *a.inv2_ptr : a.inv2;
@@ -107,15 +118,15 @@ __global__ __launch_bounds__(256, 2) void l1_decode_kernel(L1DecArgs a) {
   int soff[2];
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
-    int e = tid + 256 * k;
-    e = e < NPI2 ? e : NPI2 - 1;
+    int e = tid + NT * k;
+    e = e < NPI ? e : NPI - 1;
     soff[k] = (e / I2W) * a.W + e % I2W;
   }
   int gpix[NG], gpy[NG], gpx[NG], gslot[NG];
   bool gok[NG];
 #pragma unroll
   for (int u = 0; u < NG; ++u) {
-    const int pixr = (wave + 4 * u) * 16 + li;
+    const int pixr = (wave + NWV * u) * 16 + li;
     gok[u] = pixr < NPH;
     gpix[u] = gok[u] ? pixr : NPH - 1;
     gpy[u] = gpix[u] / FHW;
@@ -126,19 +137,19 @@ __global__ __launch_bounds__(256, 2) void l1_decode_kernel(L1DecArgs a) {
   SatTrack sat;
   int v = blockIdx.x;
   if (v < ntiles) {
-    head_fetch(a.img, a.H, a.W, a.tiles_x, txm, pxr, soff, xcd_swizzle(v, ntiles), tid);
-    head_commit(pxr, imgH, imgL, tid, sat);
+    head_fetch<TH>(a.img, a.H, a.W, a.tiles_x, txm, pxr, soff, xcd_swizzle(v, ntiles), tid);
+    head_commit<TH>(pxr, imgH, imgL, tid, sat);
   }
   for (; v < ntiles; v += gridDim.x) {
     const int tile = xcd_swizzle(v, ntiles);
     int trow_, tcol_;
     tile_rc(tile, a.tiles_x, txm, trow_, tcol_);
-    const int ty0 = trow_ * 8, tx0 = tcol_ * FTW;
+    const int ty0 = trow_ * TH, tx0 = tcol_ * FTW;
     __syncthreads();   // image window in LDS; previous tile's planes consumed
     const int vn = v + gridDim.x;
-    if (vn < ntiles) head_fetch(a.img, a.H, a.W, a.tiles_x, txm, pxr, soff, xcd_swizzle(vn, ntiles), tid);
-    const bool interior = tile_interior(ty0, tx0, a.H, a.W);
-    // ---- relu1_1 on the 340 halo pixels, each evaluated at its REFLECTED image coordinate (the decoder's own padding)
+    if (vn < ntiles) head_fetch<TH>(a.img, a.H, a.W, a.tiles_x, txm, pxr, soff, xcd_swizzle(vn, ntiles), tid);
+    const bool interior = tile_interior_h(ty0, tx0, a.H, a.W, TH);
+    // ---- relu1_1 on the halo pixels, each evaluated at its REFLECTED image coordinate (the decoder's own padding)
 #pragma unroll
     for (int u = 0; u < NG; ++u) {
       int base;
@@ -151,7 +162,7 @@ __global__ __launch_bounds__(256, 2) void l1_decode_kernel(L1DecArgs a) {
 #pragma unroll
       for (int ct = 0; ct < 2; ++ct) {
         const f32x4 x = l1_conv_group<false>(imgH, imgL, base, kq, w, ct);
-        if (gok[u]) store_split4<true>(act + ct * 4 * PH_NPX, PH_NPX, gslot[u], kq, x, sat);
+        if (gok[u]) store_split4<true>(act + ct * 4 * NPX, NPX, gslot[u], kq, x, sat);
       }
     }
     __syncthreads();
@@ -162,8 +173,8 @@ __global__ __launch_bounds__(256, 2) void l1_decode_kernel(L1DecArgs a) {
     for (int r = 0; r < 2; ++r)
 #pragma unroll
       for (int h = 0; h < 2; ++h) acc[r][h] = f32x4{0.f, 0.f, 0.f, 0.f};
-    c3_phase_compute(act, wgt, wave, li, kq, acc);
-    c3_phase_compute(act + 4 * PH_NPX, wgt + PH_WSLOTS, wave, li, kq, acc);
+    c3_phase_compute<NPX>(act, wgt, wave, li, kq, acc);
+    c3_phase_compute<NPX>(act + 4 * NPX, wgt + PH_WSLOTS, wave, li, kq, acc);
     if (!(kq & 1)) {
       const int gx = tx0 + 2 * li + (kq >> 1);
 #pragma unroll
@@ -177,7 +188,7 @@ __global__ __launch_bounds__(256, 2) void l1_decode_kernel(L1DecArgs a) {
         }
       }
     }
-    if (vn < ntiles) head_commit(pxr, imgH, imgL, tid, sat);
+    if (vn < ntiles) head_commit<TH>(pxr, imgH, imgL, tid, sat);
   }
   sat.commit(a.sat);
 }
@@ -210,12 +221,19 @@ hipError_t launch_l1_decode(const ConvDesc& e, const ConvDesc& dec0, const float
   a.img = img; a.out = out;
   a.c.w = reinterpret_cast<const u32x4*>(e.l1w16); a.c.b = e.l1bias; a.c.inv = e.l1inv;
   a.w2 = reinterpret_cast<const u32x4*>(dec0.wph16); a.b2 = dec0.bias; a.inv2_ptr = dec0.inv_scale_ptr; a.inv2 = dec0.inv_scale;
-  a.H = H; a.W = W; a.tiles_x = (W + FTW - 1) / FTW; a.tiles_y = (H + 7) / 8;
+  a.H = H; a.W = W; a.tiles_x = (W + FTW - 1) / FTW;
   a.sat = e.sat;
-  const size_t lds = (size_t)2 * IMG_E * 8 + ((size_t)2 * 4 * PH_NPX + 2 * PH_WSLOTS) * 16;   // 78.6 KB: 2 per CU
-  hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(l1_decode_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (err != hipSuccess) return err;
-  const int ntiles = a.tiles_x * a.tiles_y, grid = ntiles < 2 * num_cus() ? ntiles : 2 * num_cus();
-  hipLaunchKernelGGL(l1_decode_kernel, dim3(grid), dim3(256), lds, s, a);
-  return hipGetLastError();
+  static const int th_env = [] { const char* v = wct_debug_env("WCT_L1DEC_TH"); return v ? atoi(v) : 0; }();   // experiment: force 8 / 16
+  auto go = [&](auto kern, auto geo, int th, int per_cu) -> hipError_t {
+    using G = decltype(geo);
+    a.tiles_y = (H + th - 1) / th;
+    hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::lds);
+    if (err != hipSuccess) return err;
+    const int ntiles = a.tiles_x * a.tiles_y, grid = ntiles < per_cu * num_cus() ? ntiles : per_cu * num_cus();
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(G::NT), G::lds, s, a);
+    return hipGetLastError();
+  };
+  // 32 x 16 tiles (less halo recompute) once they still fill the chip; results do not depend on the tile shape
+  const bool tall = th_env ? th_env == 16 : ((H + 15) / 16) * a.tiles_x >= 2 * num_cus();
+  return tall ? go(l1_decode_kernel<16>, L1DecGeo<16>{}, 16, 1) : go(l1_decode_kernel<8>, L1DecGeo<8>{}, 8, 2);
 }
