@@ -255,8 +255,8 @@ __device__ __forceinline__ void store_split4(u32x4* planes, int npp, int pix, in
 }
 
 // 16->16 conv on the [4][NPP] planes of a 34 x 10 halo tile for the wave's 2 rows x 32 px (the c16 kernel's body)
+template <int NPP = npp(8)>   // plane stride: npp(tile height)
 __device__ __forceinline__ void c16_compute(const u32x4* act, const u32x4* wgt, int wave, int li, int kq, f32x4 (&acc)[2][2]) {
-  constexpr int NPP = npp(8);
   const int kh = kq & 1, ts = kq >> 1;
 #pragma unroll
   for (int s = 0; s < 5; ++s) {
