@@ -393,18 +393,32 @@ __device__ unsigned long long g_head_t[8];
 #define HT_STAMP(i)
 #endif
 
-__global__ __launch_bounds__(256, 3) void enc_head_kernel(HeadArgs a) {
+// TH: tile height.  8: 4 waves, three workgroups per CU (22 halo groups over 4 waves: 6 slots each).  24: 12 waves, one workgroup
+// per CU -- the same three waves per SIMD -- with conv11's halo recompute 884 / 768 = 1.15 instead of 340 / 256 = 1.33 and 56
+// groups over 12 waves: 5 slots each.  (12 and 16 were measured: 6-wave workgroups land unevenly on the 4 SIMDs, -36 %; 8 waves
+// are two per SIMD, -12 %.)
+template <int TH>
+struct HeadGeo {
+  static constexpr int NT = 32 * TH, NWV = TH / 2, NPH = nph(TH), NPP = npp(TH), NGRP = (NPH + 15) / 16, NG = (NGRP + NWV - 1) / NWV;
+  static constexpr int NPI = I2W * (TH + 4), IMGE = NPI + 4;
+  static constexpr int PER_CU = TH == 8 ? 3 : (TH == 12 ? 2 : 1);
+  static constexpr size_t lds = (size_t)2 * IMGE * 8 + (size_t)4 * NPP * 16 + 640 * 16;   // 39.7 KB at TH = 8, 83.8 KB at 24
+};
+
+template <int TH>
+__global__ __launch_bounds__(32 * TH, HeadGeo<TH>::PER_CU) void enc_head_kernel(HeadArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int NPP = npp(8), NPH = nph(8);
-  u32x2* imgH = reinterpret_cast<u32x2*>(smem);                // [IMG_E] RGB0 hi
-  u32x2* imgL = imgH + IMG_E;                                  // [IMG_E] RGB0 lo
-  u32x4* act = reinterpret_cast<u32x4*>(imgL + IMG_E);         // [4][NPP]
+  using G = HeadGeo<TH>;
+  constexpr int NT = G::NT, NWV = G::NWV, NPP = G::NPP, NPH = G::NPH, NG = G::NG, NPI = G::NPI, IMGE = G::IMGE;
+  u32x2* imgH = reinterpret_cast<u32x2*>(smem);                // [IMGE] RGB0 hi
+  u32x2* imgL = imgH + IMGE;                                   // [IMGE] RGB0 lo
+  u32x4* act = reinterpret_cast<u32x4*>(imgL + IMGE);          // [4][NPP]
   u32x4* wgt = act + 4 * NPP;                                  // [10][2][2][16]
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, kq = lane >> 4;
   const int ntiles = a.tiles_x * a.tiles_y;
-  for (int e = tid; e < 40 * 16; e += 256) wgt[e] = a.w12[e];
-  if (tid < 4) { imgH[NPI2 + tid] = u32x2{0u, 0u}; imgL[NPI2 + tid] = u32x2{0u, 0u}; }
+  for (int e = tid; e < 40 * 16; e += NT) wgt[e] = a.w12[e];
+  if (tid < 4) { imgH[NPI + tid] = u32x2{0u, 0u}; imgL[NPI + tid] = u32x2{0u, 0u}; }
   f16x8 a11[2][2];
 #pragma unroll
   for (int kb = 0; kb < 2; ++kb)
@@ -425,16 +439,16 @@ __global__ __launch_bounds__(256, 3) void enc_head_kernel(HeadArgs a) {
   int soff[2];
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
-    int e = tid + 256 * k;
-    e = e < NPI2 ? e : NPI2 - 1;
+    int e = tid + NT * k;
+    e = e < NPI ? e : NPI - 1;
     soff[k] = (e / I2W) * a.W + e % I2W;
   }
-  // the wave's six 16-pixel groups of the 34 x 10 halo (group 5 exists for waves 0 and 1 only: 22 groups)
-  int gpix[6], gpy[6], gpx[6];
-  bool gok[6];
+  // the wave's NG 16-pixel groups of the 34 x (TH + 2) halo (TH = 8: group 5 exists for waves 0 and 1 only, 22 groups)
+  int gpix[NG], gpy[NG], gpx[NG];
+  bool gok[NG];
 #pragma unroll
-  for (int u = 0; u < 6; ++u) {
-    const int pixr = (wave + 4 * u) * 16 + li;
+  for (int u = 0; u < NG; ++u) {
+    const int pixr = (wave + NWV * u) * 16 + li;
     gok[u] = pixr < NPH;
     gpix[u] = gok[u] ? pixr : NPH - 1;
     gpy[u] = gpix[u] / FHW;
@@ -448,9 +462,9 @@ __global__ __launch_bounds__(256, 3) void enc_head_kernel(HeadArgs a) {
   if (v < ntiles) {
     int tr, tc;
     tile_rc(xcd_swizzle(v, ntiles), a.tiles_x, a.tx_magic, tr, tc);
-    ty0 = tr * 8; tx0 = tc * FTW;
-    head_fetch(a.img, a.H, a.W, pxr, soff, ty0, tx0, tid);
-    head_commit(pxr, imgH, imgL, tid, sat);
+    ty0 = tr * TH; tx0 = tc * FTW;
+    head_fetch<TH>(a.img, a.H, a.W, pxr, soff, ty0, tx0, tid);
+    head_commit<TH>(pxr, imgH, imgL, tid, sat);
   }
   // per-lane part of the pooled output address: pixel li >> 1 of the half-tile, channels 4 kq .. 4 kq + 3
   const int out_lane = a.out_sp ? (li >> 1) * 64 + (kq >> 1) * 32 + (kq & 1) * 8 : ((li >> 1) * 16 + 4 * kq) * 4;
@@ -465,18 +479,19 @@ __global__ __launch_bounds__(256, 3) void enc_head_kernel(HeadArgs a) {
     if (vn < ntiles) {
       int tr, tc;
       tile_rc(xcd_swizzle(vn, ntiles), a.tiles_x, a.tx_magic, tr, tc);
-      nty0 = tr * 8; ntx0 = tc * FTW;
-      head_fetch(a.img, a.H, a.W, pxr, soff, nty0, ntx0, tid);
+      nty0 = tr * TH; ntx0 = tc * FTW;
+      head_fetch<TH>(a.img, a.H, a.W, pxr, soff, nty0, ntx0, tid);
     }
     HT_STAMP(1);
-    const bool interior = tile_interior(ty0, tx0, a.H, a.W);
-    // ---- conv11 on the 340 halo pixels, three 16-pixel groups in flight per wave
+    const bool interior = tile_interior_h(ty0, tx0, a.H, a.W, TH);
+    // ---- conv11 on the halo pixels, three 16-pixel groups in flight per wave
 #pragma unroll
-    for (int i = 0; i < 6; i += 3) {
+    for (int i = 0; i < NG; i += 3) {
       f32x4 acc[3];
       f16x8 bhs[3][2], bls[3][2];
 #pragma unroll
       for (int u = 0; u < 3; ++u) {
+        if (i + u >= NG) continue;
         int base;
         if (interior) {
           base = gpy[i + u] * I2W + gpx[i + u];
@@ -499,9 +514,10 @@ __global__ __launch_bounds__(256, 3) void enc_head_kernel(HeadArgs a) {
         for (int term = 0; term < 3; ++term)
 #pragma unroll
           for (int u = 0; u < 3; ++u)
-            acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a11[kb][term == 2], term == 1 ? bls[u][kb] : bhs[u][kb], acc[u], 0, 0, 0);
+            if (i + u < NG) acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a11[kb][term == 2], term == 1 ? bls[u][kb] : bhs[u][kb], acc[u], 0, 0, 0);
 #pragma unroll
       for (int u = 0; u < 3; ++u) {
+        if (i + u >= NG) continue;
         f32x4 x;
 #pragma unroll
         for (int r = 0; r < 4; ++r) x[r] = acc[u][r] * a.inv11 + bias11[r];
@@ -517,7 +533,7 @@ __global__ __launch_bounds__(256, 3) void enc_head_kernel(HeadArgs a) {
     for (int r = 0; r < 2; ++r)
 #pragma unroll
       for (int h = 0; h < 2; ++h) acc[r][h] = f32x4{0.f, 0.f, 0.f, 0.f};
-    c16_compute(act, wgt, wave, li, kq, acc);
+    c16_compute<NPP>(act, wgt, wave, li, kq, acc);
     HT_STAMP(4);
     const int oy = (ty0 >> 1) + wave;                                   // uniform
     char* orow = reinterpret_cast<char*>(a.out) + ((size_t)oy * Wp + (tx0 >> 1)) * 64;   // uniform: SALU address arithmetic
@@ -545,7 +561,7 @@ __global__ __launch_bounds__(256, 3) void enc_head_kernel(HeadArgs a) {
       }
     }
     HT_STAMP(5);
-    if (vn < ntiles) head_commit(pxr, imgH, imgL, tid, sat);   // conv11 of this tile is behind the barrier above
+    if (vn < ntiles) head_commit<TH>(pxr, imgH, imgL, tid, sat);   // conv11 of this tile is behind the barrier above
     HT_STAMP(6);
     ty0 = nty0; tx0 = ntx0;
   }
@@ -858,14 +874,27 @@ hipError_t launch_enc_head(const ConvDesc& d0, const ConvDesc& d1, const float* 
   a.img = img; a.out = out;
   a.w11 = reinterpret_cast<const u32x4*>(d0.wpk16); a.b11 = d0.bias; a.inv11 = d0.inv_scale;
   a.w12 = reinterpret_cast<const u32x4*>(d1.wpk16); a.b12 = d1.bias; a.inv12 = d1.inv_scale;
-  a.H = H; a.W = W; a.tiles_x = (W + FTW - 1) / FTW; a.tiles_y = (H + 7) / 8;
+  a.H = H; a.W = W; a.tiles_x = (W + FTW - 1) / FTW;
   a.tx_magic = tile_div_magic(a.tiles_x);
   a.out_sp = (d1.flags & CONV_OUT_SP16) ? 1 : 0;
   a.sat = d1.sat;
-  const size_t lds = (size_t)2 * IMG_E * 8 + (size_t)4 * npp(8) * 16 + 640 * 16;   // 39.7 KB: 4 workgroups per CU
-  const int ntiles = a.tiles_x * a.tiles_y, grid = ntiles < 3 * num_cus() ? ntiles : 3 * num_cus();
-  hipLaunchKernelGGL(enc_head_kernel, dim3(grid), dim3(256), lds, s, a);
-  return hipGetLastError();
+  static const int th_env = [] { const char* e = wct_debug_env("WCT_HEAD_TH"); return e ? atoi(e) : 0; }();   // experiment: force 8 / 24
+  auto go = [&](auto kern, auto geo, int th) -> hipError_t {
+    using G = decltype(geo);
+    a.tiles_y = (H + th - 1) / th;
+    if (G::lds > 48 * 1024) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::lds);
+      if (e != hipSuccess) return e;
+    }
+    const int ntiles = a.tiles_x * a.tiles_y, grid = ntiles < G::PER_CU * num_cus() ? ntiles : G::PER_CU * num_cus();
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(G::NT), G::lds, s, a);
+    return hipGetLastError();
+  };
+  // 32 x 24 tiles (12 waves, one workgroup per CU: the same three waves per SIMD, conv11's halo recompute 1.15 instead of 1.33:
+  // -2.6 %) once they still give every CU four tiles; results do not depend on the tile shape
+  const int th = th_env ? th_env : (((H + 23) / 24) * a.tiles_x >= 4 * num_cus() ? 24 : 8);
+  if (th == 24) return go(enc_head_kernel<24>, HeadGeo<24>{}, 24);
+  return go(enc_head_kernel<8>, HeadGeo<8>{}, 8);
 }
 
 hipError_t launch_dec_tail(const ConvDesc& d0, const ConvDesc& d1, const float* in, float* out, int H, int W, hipStream_t s) {
@@ -881,17 +910,19 @@ hipError_t launch_dec_tail(const ConvDesc& d0, const ConvDesc& d1, const float* 
   static const int th_env = [] { const char* e = wct_debug_env("WCT_TAIL_TH"); return e ? atoi(e) : 0; }();   // experiment: force 8 / 16
   // 32 x 16 tiles (conv12's halo recompute 1.20 instead of 1.33: -10 % at 4K) once they still fill the chip; results do not
   // depend on the tile shape (same arithmetic per pixel)
-  const int th = th_env ? th_env : (((H + 15) / 16) * a.tiles_x >= 2 * num_cus() ? 16 : 8);
+  // (32 x 24, 12 waves: three waves per SIMD instead of two and recompute 1.15: another -7 %, when every CU still gets four tiles)
+  const int th = th_env ? th_env : (((H + 23) / 24) * a.tiles_x >= 4 * num_cus() ? 24 : (((H + 15) / 16) * a.tiles_x >= 2 * num_cus() ? 16 : 8));
   auto go = [&](auto kern, auto geo, int per_cu) -> hipError_t {
     using G = decltype(geo);
     a.tiles_y = (H + G::HROWS - 3) / (G::HROWS - 2);
-    const size_t lds = ((size_t)4 * G::NPI + 640 + PH_WSLOTS + (size_t)4 * G::NPX) * 16;   // 73.7 KB (TH = 8: 2 per CU) / 110.6 KB (TH = 16)
+    const size_t lds = ((size_t)4 * G::NPI + 640 + PH_WSLOTS + (size_t)4 * G::NPX) * 16;   // 73.7 KB (TH = 8: 2 per CU) / 110.6 KB (16) / 147.5 KB (24)
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     const int ntiles = a.tiles_x * a.tiles_y, grid = ntiles < per_cu * num_cus() ? ntiles : per_cu * num_cus();
     hipLaunchKernelGGL(kern, dim3(grid), dim3(G::NT), lds, s, a);
     return hipGetLastError();
   };
+  if (th == 24) return go(dec_tail_kernel<24>, TailGeo<24>{}, 1);
   return th == 16 ? go(dec_tail_kernel<16>, TailGeo<16>{}, 1) : go(dec_tail_kernel<8>, TailGeo<8>{}, 2);
 }
 
