@@ -341,7 +341,11 @@ MomArgs plan(int C, long npix) {
   a.pw = a.pixsplit ? (a.NP <= 3 ? 3 : 6) : (a.NP <= 12 ? 3 : 6);
   a.NPG = a.pixsplit ? 1 : (a.NP + 4 * a.pw - 1) / (4 * a.pw);
   a.Cs = (a.T & 1) ? a.T * 16 : a.T * 16 + 16;  // == 16 (mod 32) dwords
-  a.MP = std::min(256, (MAXLD * 256 * 4 / C) / 16 * 16);  // MP * C / 4 <= 8 * 256 float4 slots; multiple of 16
+  // MP * C / 4 <= maxld * 256 float4 slots; multiple of 16.  Six pairs per wave (C >= 64) leave room for 6 load slots only: with 8
+  // the two-tile prefetch + 48 accumulator registers spilled 18 VGPRs into scratch inside the pixel loop
+  static const int maxld6 = [] { const char* e = wct_debug_env("WCT_MOM_MAXLD6"); return e ? atoi(e) : 6; }();
+  const int maxld = a.pw == 6 ? maxld6 : MAXLD;
+  a.MP = std::max(16, std::min(256, (maxld * 256 * 4 / C) / 16 * 16));
   const int MP = a.MP;
   a.npix = npix;
   static long npc_target = [] { const char* e = wct_debug_env("WCT_MOM_NPC"); return e ? atol(e) : 512L; }();
