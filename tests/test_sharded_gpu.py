@@ -88,6 +88,46 @@ def test_config4_eight_strips_match_untiled(tmp_path):
     assert np.isfinite(z["got"]).all() and e < 1e-3
 
 
+def _replica_worker(rank, world, port, out_dir):
+    for p in (REPO, PKG):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from wct_hip import WCT, model_zoo
+        from wct_hip.replicas import ReplicaStylizer
+        wct = WCT(types.SimpleNamespace(mode="16x", alpha=1.0), weights=model_zoo.load_npz_weights(os.path.join(PKG, "weights", "16x.npz")))
+        style = torch.rand((3, 320, 256), device="cuda", generator=torch.Generator(device="cuda").manual_seed(2))
+        content = torch.rand((3, 272 + 32 * rank, 400), device="cuda", generator=torch.Generator(device="cuda").manual_seed(10 + rank))
+        out = ReplicaStylizer(wct, dist).stylize(content, style)
+        wct.sync()
+        np.save(os.path.join(out_dir, "r%d.npy" % rank), out.cpu().numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_replicas_three_ranks_on_the_hip_engine(tmp_path):
+    """BASELINE configs[4] ("batch of distinct contents x 1 style, one per GPU"): wct_hip/replicas.py on the HIP engine, three
+    ranks (sharing the one GPU over gloo), a different content per rank, each level's style statistics computed by ONE rank
+    and broadcast -- every rank's result equals a single-engine stylisation of its content bit for bit."""
+    import torch
+    import torch.multiprocessing as mp
+    from wct_hip import WCT, model_zoo
+    world = 3
+    mp.spawn(_replica_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    wct = WCT(types.SimpleNamespace(mode="16x", alpha=1.0), weights=model_zoo.load_npz_weights(os.path.join(PKG, "weights", "16x.npz")))
+    style = torch.rand((3, 320, 256), device="cuda", generator=torch.Generator(device="cuda").manual_seed(2))
+    for rank in range(world):
+        content = torch.rand((3, 272 + 32 * rank, 400), device="cuda", generator=torch.Generator(device="cuda").manual_seed(10 + rank))
+        ref = wct.stylize(content, style).cpu().numpy()
+        got = np.load(str(tmp_path / ("r%d.npy" % rank)))
+        assert got.shape == ref.shape and np.array_equal(got, ref), rank
+
+
 def test_rccl_first_contact_single_rank():
     """The GPU test box has one device, so RCCL cannot carry a 2-rank job here; this at least executes the calls bench.py and
     wct_hip/sharded.py make -- init_process_group("nccl", device_id=...), all_reduce(SUM) of fp64 moments, broadcast, a
