@@ -150,15 +150,8 @@ __device__ __forceinline__ void sp16_store4(char* record, int kq, const f32x4& v
 // ---- shared by the fused full-resolution kernels (conv3x3_f16.hip: enc_head / dec_tail, level1.hip)
 constexpr int I2W = FTW + 4, I2H = 8 + 4;       // 36 x 12: input tile of the first conv (two halo rings)
 constexpr int NPI2 = I2W * I2H;                 // 432 (a multiple of 16)
-constexpr int NGRP = (nph(8) + 15) / 16;        // 22 groups of 16 halo pixels
 
 constexpr int IMG_E = NPI2 + 4;   // 8-byte pixels per plane; the zeroed tail absorbs the "4th pixel" over-read of the last row
-
-// (uniform) true when the 36 x 12 input window of the tile lies inside the image: no reflection anywhere
-__device__ __forceinline__ bool tile_interior(int ty0, int tx0, int H, int W) {
-  return ty0 >= 2 && ty0 + 10 <= H && tx0 >= 2 && tx0 + 34 <= W;
-}
-
 
 // next tile's 36 x 12 x 3 image window -> 6 registers per thread (unconditional, clamped).  soff[k]: tile-independent
 // offset of the thread's pixel k from the window origin, valid for interior tiles.
@@ -177,7 +170,7 @@ __device__ __forceinline__ float lane_xor1(float x) {
   return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, true));
 }
 
-// (uniform) the same for a tile of 32 x th output pixels
+// (uniform) true when the 36 x (th + 4) input window of a 32 x th tile lies inside the image: no reflection anywhere
 __device__ __forceinline__ bool tile_interior_h(int ty0, int tx0, int H, int W, int th) {
   return ty0 >= 2 && ty0 + th + 2 <= H && tx0 >= 2 && tx0 + 34 <= W;
 }
