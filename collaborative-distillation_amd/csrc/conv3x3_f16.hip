@@ -364,8 +364,9 @@ __global__ __launch_bounds__(256) void conv3x3_f16_c16_kernel(F16Args a) {
 // + pool: model_cd.py:726-728) and the last two decoder layers (conv12 16->16 after the upsample, conv11 16->3:
 // model_cd.py:291-293) run at full image resolution with only 16 channels: unfused they move 156 B per pixel
 // (the 64 B/px intermediate written and read back), fused 28 B per pixel.  The intermediate lives only in LDS,
-// already split into f16 hi/lo planes.  The tail keeps the arithmetic and summation order of the unfused kernels (bitwise
-// identical to running the two layers separately); the head's conv11 is f16x3 here and exact-fp32 MFMA unfused (3e-6).
+// already split into f16 hi/lo planes.  The tail's conv12 has the arithmetic and summation order of the unfused kernel; its
+// final 16 -> 3 conv runs phase-packed (conv_f16_dev.h c3_phase_compute: another summation order, fp32 round-off agreement
+// with the two layers run separately); the head's conv11 is f16x3 here and exact-fp32 MFMA unfused (3e-6).
 // The intermediate's own reflect padding: a halo pixel OUTSIDE the image must hold the intermediate value of its
 // mirror pixel (not the first conv evaluated outside the image), so every halo pixel is evaluated at its reflected
 // image coordinate -- whose 3x3 input window is inside the staged tile -- and stored at the halo position.
