@@ -472,6 +472,7 @@ __global__ __launch_bounds__(32 * TH, HeadGeo<TH>::PER_CU) void enc_head_kernel(
 #ifdef WCT_HEAD_TIMING
   unsigned long long ht[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tl = __builtin_amdgcn_s_memtime();
 #endif
+  settle_preloop_loads();
   for (; v < ntiles; v += gridDim.x) {
     __syncthreads();   // image window of this tile is in LDS; every wave is done with the previous tile's planes
     HT_STAMP(0);
@@ -562,7 +563,7 @@ __global__ __launch_bounds__(32 * TH, HeadGeo<TH>::PER_CU) void enc_head_kernel(
       }
     }
     HT_STAMP(5);
-    if (vn < ntiles) head_commit<TH>(pxr, imgH, imgL, tid, sat);   // conv11 of this tile is behind the barrier above
+    if (vn < ntiles) { head_pin(pxr); head_commit<TH>(pxr, imgH, imgL, tid, sat); }   // conv11 of this tile is behind the barrier above
     HT_STAMP(6);
     ty0 = nty0; tx0 = ntx0;
   }
@@ -693,6 +694,7 @@ __global__ __launch_bounds__(32 * TH, TH == 8 ? 2 : 1) void dec_tail_kernel(Tail
     tail_fetch<TH>(a, txm, tr, soff, xcd_swizzle(v, ntiles), tid);
     tail_commit<TH>(tr, act0, tid, a.in_sp, sat);
   }
+  settle_preloop_loads();
   for (; v < ntiles; v += gridDim.x) {
     const int tile = xcd_swizzle(v, ntiles);
     int trow_, tcol_;

@@ -211,6 +211,25 @@ __device__ __forceinline__ void head_fetch(const float* img, int H, int W, int t
   head_fetch<TH>(img, H, W, r, soff, tr * TH, tc * FTW, tid);
 }
 
+// Call once before a persistent tile loop that keeps weights / biases loaded from global memory in registers AND prefetches the next
+// tile with global loads inside the loop.  The compiler's wait-count insertion cannot prove at the loop header that the
+// pre-loop loads have landed, so it guards every use of those registers inside the loop with s_waitcnt vmcnt(k) -- and since
+// vmcnt retires in order, that makes the first MFMAs of every tile wait for the prefetch that was issued just before them
+// (enc_head: vmcnt(5), (4), (3), (2) in front of the conv11 MFMAs = the HBM latency of the next tile's window, every tile).  An
+// explicit, compiler-visible wait before the loop settles the scoreboard.
+__device__ __forceinline__ void settle_preloop_loads() { __builtin_amdgcn_s_waitcnt(0x0F70); }   // vmcnt(0) only (gfx9 encoding)
+
+// The prefetched window of the NEXT tile must not be touched before the end of the current tile: left to itself the scheduler
+// hoists this function's conversions (pure VALU on the loaded registers) to right behind the loads, and every wave then waits for
+// HBM inside its first MFMA phase (s_waitcnt vmcnt(5..1) in the middle of conv11).  head_pin() makes the registers opaque at the
+// point of the call -- a volatile asm with "+v" constraints, which cannot move above the barrier that precedes it.
+__device__ __forceinline__ void head_pin(float (&r)[2][3]) {
+#pragma unroll
+  for (int k = 0; k < 2; ++k)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) asm volatile("" : "+v"(r[k][c]));
+}
+
 template <int TH = 8>
 __device__ __forceinline__ void head_commit(const float (&r)[2][3], u32x2* imgH, u32x2* imgL, int tid, SatTrack& sat) {
   constexpr int NT = 32 * TH, NPI = I2W * (TH + 4);

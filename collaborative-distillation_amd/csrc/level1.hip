@@ -58,6 +58,7 @@ __global__ __launch_bounds__(256, 3) void l1_encode_kernel(L1EncArgs a) {
     head_fetch(a.img, a.H, a.W, a.tiles_x, txm, pxr, soff, xcd_swizzle(v, ntiles), tid);
     head_commit(pxr, imgH, imgL, tid, sat);
   }
+  settle_preloop_loads();
   for (; v < ntiles; v += gridDim.x) {
     const int tile = xcd_swizzle(v, ntiles);
     int trow_, tcol_;
@@ -81,7 +82,7 @@ __global__ __launch_bounds__(256, 3) void l1_encode_kernel(L1EncArgs a) {
         }
       }
     __syncthreads();
-    if (vn < ntiles) head_commit(pxr, imgH, imgL, tid, sat);
+    if (vn < ntiles) { head_pin(pxr); head_commit(pxr, imgH, imgL, tid, sat); }
   }
   sat.commit(a.sat);
 }
@@ -140,6 +141,7 @@ __global__ __launch_bounds__(32 * TH, TH == 8 ? 2 : 1) void l1_decode_kernel(L1D
     head_fetch<TH>(a.img, a.H, a.W, a.tiles_x, txm, pxr, soff, xcd_swizzle(v, ntiles), tid);
     head_commit<TH>(pxr, imgH, imgL, tid, sat);
   }
+  settle_preloop_loads();
   for (; v < ntiles; v += gridDim.x) {
     const int tile = xcd_swizzle(v, ntiles);
     int trow_, tcol_;
@@ -188,7 +190,7 @@ __global__ __launch_bounds__(32 * TH, TH == 8 ? 2 : 1) void l1_decode_kernel(L1D
         }
       }
     }
-    if (vn < ntiles) head_commit<TH>(pxr, imgH, imgL, tid, sat);
+    if (vn < ntiles) { head_pin(pxr); head_commit<TH>(pxr, imgH, imgL, tid, sat); }
   }
   sat.commit(a.sat);
 }

@@ -246,6 +246,7 @@ __global__ __launch_bounds__(256, 2) void l1_moments_kernel(L1MomArgs a) {
     head_fetch(a.img, a.H, a.W, a.tiles_x, txm, pxr, soff, xcd_swizzle(v, ntiles), tid);
     head_commit(pxr, imgH, imgL, tid, sat);
   }
+  settle_preloop_loads();
   for (; v < ntiles; v += gridDim.x) {
     const int tile = xcd_swizzle(v, ntiles);
     int trow_, tcol_;
@@ -271,7 +272,7 @@ __global__ __launch_bounds__(256, 2) void l1_moments_kernel(L1MomArgs a) {
     __syncthreads();
     const int st0 = wave * (MP / 16);
     tile_steps3(feat, a.Cs, st0, st0 + MP / 16, kq, offA, offB, acc[0], acc[1], acc[2], s[0], s[1], s[2]);
-    if (vn < ntiles) head_commit(pxr, imgH, imgL, tid, sat);
+    if (vn < ntiles) { head_pin(pxr); head_commit(pxr, imgH, imgL, tid, sat); }
   }
   sat.commit(a.sat);
   // add the four waves' partial sets through LDS, fixed order (as moments_kernel's pixel-split tail)
