@@ -2,7 +2,7 @@
 # Build libwct_hip.so for gfx950 (cross-compiles without a GPU).  In-tree so that it travels with the repo snapshot.
 set -e
 cd "$(dirname "$0")"
-SRC="csrc/conv3x3.hip csrc/conv3x3_f16.hip csrc/conv3x3_sp.hip csrc/level1.hip csrc/moments.hip csrc/solve.hip csrc/misc.hip csrc/wct_api.hip"
+SRC="csrc/conv3x3.hip csrc/conv3x3_f16.hip csrc/conv3x3_sp.hip csrc/level1.hip csrc/moments.hip csrc/solve.hip csrc/misc.hip csrc/resize.hip csrc/wct_api.hip"
 OUT=libwct_hip.so
 if [ -f "$OUT" ] && [ "$1" != "-f" ]; then
   newer=0

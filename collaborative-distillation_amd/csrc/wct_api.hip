@@ -38,6 +38,14 @@ struct Module {
   std::vector<LayerDev> layers;
 };
 
+// weight tables of one resize axis on the device (resize.hip)
+struct ResizeAxis {
+  int in_size = 0, out_size = 0, ksize = 0, first = 0, last = 0;   // [first, last): input rows / columns any output touches
+  int* bounds = nullptr;          // [2 * out]
+  int* bounds_shifted = nullptr;  // the same with `first` subtracted from every start (the vertical pass reads a cropped image)
+  int* kk = nullptr;              // [out * ksize]
+};
+
 struct ProfRec {
   hipEvent_t e0, e1;
   std::string name;
@@ -64,6 +72,8 @@ struct wct_ctx {
   DevBuf featC, featS, tmpT, wsAsm, small, foldW, foldW16, eigC, eigS[6];
   int cur_level = 0, cur_h = 0, cur_w = 0;  // content feature held in featC by wct_content_encode
   DevBuf u8c, u8s, u8o;   // fp32 planar staging of wct_stylize_u8 (content, style, result)
+  DevBuf rsz_tmp;         // wct_resize_u8: uint8 image between the horizontal and the vertical pass
+  std::vector<ResizeAxis> rsz_axes;   // weight tables per (in, out) size, built on first use
   DevBuf l1img;       // level 1 fused: copy of the content image between wct_content_encode and wct_content_decode
   int cur_H = 0, cur_W = 0;
   int numpy_variant = 0;  // 1: `--numpy` semantics (util_wct.py:143): + I on the CONTENT covariance
@@ -695,7 +705,9 @@ void wct_destroy(wct_ctx* ctx) {
     for (int l = 0; l < 6; ++l) free_module(ctx->mod[k][l]);
   for (Lane* ln : {&ctx->main, &ctx->side})
     for (DevBuf* b : {&ln->actA, &ln->actB, &ln->wsMom, &ln->wsEig, &ln->sums}) release(*b);
-  for (DevBuf* b : {&ctx->featC, &ctx->featS, &ctx->tmpT, &ctx->wsAsm, &ctx->small, &ctx->foldW, &ctx->foldW16, &ctx->eigC, &ctx->l1img, &ctx->u8c, &ctx->u8s, &ctx->u8o}) release(*b);
+  for (DevBuf* b : {&ctx->featC, &ctx->featS, &ctx->tmpT, &ctx->wsAsm, &ctx->small, &ctx->foldW, &ctx->foldW16, &ctx->eigC, &ctx->l1img, &ctx->u8c, &ctx->u8s, &ctx->u8o, &ctx->rsz_tmp}) release(*b);
+  for (ResizeAxis& a : ctx->rsz_axes) { (void)hipFree(a.bounds); (void)hipFree(a.bounds_shifted); (void)hipFree(a.kk); }
+  ctx->rsz_axes.clear();
   for (int l = 0; l < 6; ++l) {
     release(ctx->eigS[l]);
     if (ctx->ev_style[l]) (void)hipEventDestroy(ctx->ev_style[l]);
@@ -1193,6 +1205,79 @@ int wct_stylize_u8(wct_ctx* ctx, const uint8_t* content_hwc, int H, int W, const
   if (Ho) *Ho = ho;
   if (Wo) *Wo = wo;
   return WCT_OK;
+}
+
+int wct_resize_shape(int H, int W, int size, int* oH, int* oW) {
+  if (H < 1 || W < 1 || size < 0 || !oH || !oW) return WCT_ERR_INVALID;
+  *oH = H; *oW = W;
+  if (size == 0 || (W <= H && W == size) || (H <= W && H == size)) return WCT_OK;
+  // torchvision 0.2.1 functional.resize(img, int): the smaller edge becomes `size`, the other int(size * long / short)
+  // (Python float division of ints, then truncation)
+  if (W < H) { *oW = size; *oH = (int)((double)size * H / W); }
+  else { *oH = size; *oW = (int)((double)size * W / H); }
+  return (*oH >= 1 && *oW >= 1) ? WCT_OK : WCT_ERR_INVALID;
+}
+
+namespace {
+int resize_axis(wct_ctx* ctx, int in_size, int out_size, const ResizeAxis** out) {
+  for (const ResizeAxis& a : ctx->rsz_axes)
+    if (a.in_size == in_size && a.out_size == out_size) { *out = &a; return WCT_OK; }
+  if (ctx->rsz_axes.size() >= 16) {   // a bounded cache: drop everything (nothing in flight may still read the tables)
+    HIPCHK(ctx, hipStreamSynchronize(ctx->main.stream));
+    for (ResizeAxis& a : ctx->rsz_axes) { (void)hipFree(a.bounds); (void)hipFree(a.bounds_shifted); (void)hipFree(a.kk); }
+    ctx->rsz_axes.clear();
+  }
+  std::vector<int> bounds, kk;
+  ResizeAxis a;
+  a.in_size = in_size; a.out_size = out_size;
+  resize_axis_tables(in_size, out_size, a.ksize, bounds, kk);
+  a.first = bounds[0];
+  a.last = bounds[2 * (size_t)(out_size - 1)] + bounds[2 * (size_t)(out_size - 1) + 1];
+  std::vector<int> shifted(bounds);
+  for (int i = 0; i < out_size; ++i) shifted[2 * (size_t)i] -= a.first;
+  HIPCHK(ctx, hipMalloc(&a.bounds, bounds.size() * sizeof(int)));
+  HIPCHK(ctx, hipMalloc(&a.bounds_shifted, bounds.size() * sizeof(int)));
+  HIPCHK(ctx, hipMalloc(&a.kk, kk.size() * sizeof(int)));
+  HIPCHK(ctx, hipMemcpy(a.bounds, bounds.data(), bounds.size() * sizeof(int), hipMemcpyHostToDevice));
+  HIPCHK(ctx, hipMemcpy(a.bounds_shifted, shifted.data(), shifted.size() * sizeof(int), hipMemcpyHostToDevice));
+  HIPCHK(ctx, hipMemcpy(a.kk, kk.data(), kk.size() * sizeof(int), hipMemcpyHostToDevice));
+  ctx->rsz_axes.push_back(a);
+  *out = &ctx->rsz_axes.back();
+  return WCT_OK;
+}
+
+int resize_impl(wct_ctx* ctx, const uint8_t* src, int H, int W, int oH, int oW, uint8_t* dst, float* planar) {
+  if (!src || (!dst && !planar) || H < 1 || W < 1 || oH < 1 || oW < 1 || H > 65535 || oH > 65535)
+    return fail(ctx, WCT_ERR_INVALID, "resize_u8: bad arguments (%dx%d -> %dx%d)", H, W, oH, oW);
+  if ((reinterpret_cast<size_t>(src) & 3) != 0) return fail(ctx, WCT_ERR_INVALID, "resize_u8: source not 4-byte aligned");
+  const ResizeAxis *ax = nullptr, *ay = nullptr;
+  // the vector may reallocate when the second axis is added: look both up again afterwards
+  if (int rc = resize_axis(ctx, W, oW, &ax)) return rc;
+  if (int rc = resize_axis(ctx, H, oH, &ay)) return rc;
+  if (int rc = resize_axis(ctx, W, oW, &ax)) return rc;
+  const bool need_h = oW != W, need_v = oH != H;
+  const int row0 = need_v ? ay->first : 0, rows = need_v ? ay->last - ay->first : H;
+  if (need_h && (need_v || planar))
+    if (int rc = ensure(ctx, ctx->rsz_tmp, (size_t)rows * oW * 3)) return rc;
+  ProfScope ps(ctx, ctx->main.stream, "resize_u8", 0, 3.0 * H * W + 3.0 * oH * oW * (planar ? 4 : 1));
+  HIPCHK(ctx, launch_resize_u8(src, H, W, oH, oW, ax->bounds, ax->kk, ax->ksize, ay->bounds_shifted, ay->kk, ay->ksize, row0, rows,
+                               reinterpret_cast<uint8_t*>(ctx->rsz_tmp.p), dst, planar, ctx->main.stream));
+  return WCT_OK;
+}
+}  // namespace
+
+int wct_resize_u8(wct_ctx* ctx, const uint8_t* src_hwc, int H, int W, uint8_t* dst_hwc, int oH, int oW) {
+  if (!ctx) return WCT_ERR_INVALID;
+  WCT_GUARD(ctx);
+  if (!dst_hwc) return fail(ctx, WCT_ERR_INVALID, "resize_u8: bad arguments");
+  return resize_impl(ctx, src_hwc, H, W, oH, oW, dst_hwc, nullptr);
+}
+
+int wct_resize_u8_to_planar(wct_ctx* ctx, const uint8_t* src_hwc, int H, int W, float* planar, int oH, int oW) {
+  if (!ctx) return WCT_ERR_INVALID;
+  WCT_GUARD(ctx);
+  if (!planar) return fail(ctx, WCT_ERR_INVALID, "resize_u8_to_planar: bad arguments");
+  return resize_impl(ctx, src_hwc, H, W, oH, oW, nullptr, planar);
 }
 
 size_t wct_workspace_bytes(const wct_ctx* ctx, int H, int W, int Hs, int Ws) {

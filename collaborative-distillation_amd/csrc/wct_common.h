@@ -5,6 +5,7 @@
 #include <stddef.h>
 
 #include <stdlib.h>
+#include <vector>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef double f64x4 __attribute__((ext_vector_type(4)));
@@ -84,6 +85,11 @@ hipError_t launch_split_pack_phase(const float* wpk32, int cin, const unsigned* 
 // ---- image edge: uint8 HWC <-> planar fp32 (ToTensor / save_image of the reference's harness)
 hipError_t launch_u8_to_planar(const uint8_t* hwc, long npix, float* planar, hipStream_t s);
 hipError_t launch_planar_to_u8(const float* planar, long npix, uint8_t* hwc, int round_mode, hipStream_t s);
+// ---- image edge: transforms.Resize = Pillow's bilinear resampler, bit-exact (resize.hip)
+void resize_axis_tables(int in_size, int out_size, int& ksize, std::vector<int>& bounds, std::vector<int>& kk);   // host
+hipError_t launch_resize_u8(const uint8_t* in, int H, int W, int oH, int oW, const int* bounds_h, const int* kk_h, int ksize_h,
+                            const int* bounds_v_shifted, const int* kk_v, int ksize_v, int row0, int rows, uint8_t* tmp, uint8_t* out,
+                            float* planar, hipStream_t s);
 
 // ---- layout
 hipError_t launch_nhwc_to_nchw(const float* in, float* out, int C, int npix, hipStream_t s);

@@ -6,7 +6,7 @@ What the reference script does around the hot path and where it lives here:
   WCT.py:15-35      argparse flags                     -> build_parser()   (same names, defaults and choices)
   WCT.py:37-75      checkpoint paths per --mode        -> checkpoint_args()
   data_loader.py:22-36   content x style pairs filtered by --picked_*_mark, listdir order   -> list_pairs()
-  data_loader.py:50-59   PIL decode (.convert('RGB')), optional Resize, ToTensor            -> load_rgb_u8() + wct_u8_to_planar (GPU)
+  data_loader.py:50-59   PIL decode (.convert('RGB')), optional Resize, ToTensor            -> load_rgb_u8() + wct_resize_u8_to_planar / wct_u8_to_planar (GPU)
   WCT.py:120-125    the 5-level cascade, --num_run times -> wct_stylize (one C call)
   WCT.py:127-128    output name and save_image          -> out_name() + wct_planar_to_u8 (GPU) + PIL save
 A frame crosses PCIe as uint8 (3 B/px each way).  --numpy selects the reference's whiten_and_color_np semantics (+ I on the
@@ -89,8 +89,9 @@ def out_name(args, imname: str) -> str:
 
 
 def load_rgb_u8(path: str, size: int = 0):
-    """default_loader + transforms.Resize(size) of data_loader.py:18-19,52-56: RGB uint8 HWC; Resize matches the SMALLER
-    edge to `size` with bilinear interpolation (torchvision 0.2.1 semantics, done by Pillow on the host)."""
+    """default_loader of data_loader.py:18-19: RGB uint8 HWC.  With `size`, also transforms.Resize(size) of :52-56 by Pillow on the
+    host -- the CLI itself passes 0 and resizes on the GPU (WCT.resize_u8, bit-identical); this form is the host-side reference of
+    tests/test_cli.py."""
     import numpy as np
     from PIL import Image
     img = Image.open(path).convert("RGB")
@@ -137,26 +138,29 @@ def main(argv: Optional[List[str]] = None) -> int:
     for i, (cfile, sfile) in enumerate(pairs):
         imname = pair_name(cfile, sfile)
         logprinter("\n" + "*" * 30 + ' #%s: Transferring "%s"' % (i, imname))
-        c_u8 = torch.from_numpy(load_rgb_u8(os.path.join(content_dir, cfile), args.content_size)).pin_memory().cuda(non_blocking=True)
+        # decoded uint8 frames cross PCIe as they are (3 B/px, pinned); Resize and ToTensor run on the GPU
+        def to_tensor(u8, size):
+            return wct.resize_u8(u8, size, to_tensor=True) if size else wct.to_tensor_u8(u8)
+        c_u8 = torch.from_numpy(load_rgb_u8(os.path.join(content_dir, cfile))).pin_memory().cuda(non_blocking=True)
         s_u8 = None
         if sfile not in style_cache:
-            s_u8 = torch.from_numpy(load_rgb_u8(os.path.join(style_dir, sfile), args.style_size)).pin_memory().cuda(non_blocking=True)
+            s_u8 = torch.from_numpy(load_rgb_u8(os.path.join(style_dir, sfile))).pin_memory().cuda(non_blocking=True)
         t0 = time.time()
         if s_u8 is not None:
-            wct.style_prepare(wct.to_tensor_u8(s_u8))
+            wct.style_prepare(to_tensor(s_u8, args.style_size))
             style_cache[sfile] = {L: wct.style_export(L) for L in (5, 4, 3, 2, 1)}
         else:
             for L, stats in style_cache[sfile].items():
                 wct.style_import(L, stats)
-        c_f32 = wct.to_tensor_u8(c_u8)
+        c_f32 = to_tensor(c_u8, args.content_size)
         res = wct.stylize_prepared(c_f32, args.alpha, args.num_run)
         if wct.saturation_count(reset=True):
             # an activation left the f16x3 range (+-65504) and was clamped: a deviation from the fp32 reference -- never
             # silent.  Recompute this pair with the exact-fp32 convolutions (style statistics included).
             logprinter("WARNING: f16x3 range exceeded for this pair -> recomputing it with exact-fp32 convolutions")
             wct.set_conv_mode("fp32")
-            style_img = wct.to_tensor_u8(s_u8 if s_u8 is not None else
-                                         torch.from_numpy(load_rgb_u8(os.path.join(style_dir, sfile), args.style_size)).cuda())
+            style_img = to_tensor(s_u8 if s_u8 is not None else torch.from_numpy(load_rgb_u8(os.path.join(style_dir, sfile))).cuda(),
+                                  args.style_size)
             res = wct.stylize(c_f32, style_img, args.alpha, args.num_run)
             wct.sync()
             wct.set_conv_mode("f16x3")

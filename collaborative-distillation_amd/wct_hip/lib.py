@@ -23,7 +23,7 @@ SYMBOLS = [
     "wct_apply", "wct_transform", "wct_decode_affine", "wct_style_transfer_level", "wct_stylize",
     "wct_style_prepare", "wct_content_encode", "wct_content_solve", "wct_content_decode",
     "wct_style_prepare_levels", "wct_style_stats_count", "wct_style_export", "wct_style_import", "wct_stylize_prepared",
-    "wct_u8_to_planar", "wct_planar_to_u8", "wct_stylize_u8",
+    "wct_u8_to_planar", "wct_planar_to_u8", "wct_stylize_u8", "wct_resize_shape", "wct_resize_u8", "wct_resize_u8_to_planar",
     "wct_workspace_bytes", "wct_reserve", "wct_set_conv_mode", "wct_set_numpy_variant", "wct_set_overlap", "wct_profile_enable", "wct_profile_reset", "wct_profile_read",
 ]
 
@@ -95,6 +95,9 @@ def load() -> ctypes.CDLL:
     lib.wct_u8_to_planar.argtypes = [c_void_p, vp, c_int, c_int, vp]
     lib.wct_planar_to_u8.argtypes = [c_void_p, vp, c_int, c_int, vp, c_int]
     lib.wct_stylize_u8.argtypes = [c_void_p, vp, c_int, c_int, vp, c_int, c_int, c_float, c_int, vp, ip, ip, c_int]
+    lib.wct_resize_shape.argtypes = [c_int, c_int, c_int, ip, ip]
+    lib.wct_resize_u8.argtypes = [c_void_p, vp, c_int, c_int, vp, c_int, c_int]
+    lib.wct_resize_u8_to_planar.argtypes = [c_void_p, vp, c_int, c_int, vp, c_int, c_int]
     lib.wct_workspace_bytes.argtypes = [c_void_p, c_int, c_int, c_int, c_int]
     lib.wct_workspace_bytes.restype = c_size_t
     lib.wct_reserve.argtypes = [c_void_p, c_int, c_int, c_int, c_int]

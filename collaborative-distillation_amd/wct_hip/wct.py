@@ -390,6 +390,30 @@ class WCT:
         self._chk(self._lib.wct_u8_to_planar(self._ctx, x.data_ptr(), H, W, out.data_ptr()))
         return out
 
+    def resize_shape(self, H: int, W: int, size: int):
+        """Output (H, W) of transforms.Resize(size) (torchvision 0.2.1: the smaller edge becomes `size`; 0 = no resize)."""
+        oh, ow = c_int(), c_int()
+        if self._lib.wct_resize_shape(int(H), int(W), int(size), byref(oh), byref(ow)) != 0:
+            raise ValueError("resize_shape: bad arguments %s x %s -> %s" % (H, W, size))
+        return oh.value, ow.value
+
+    @torch.no_grad()
+    def resize_u8(self, img_u8: torch.Tensor, size, to_tensor: bool = False) -> torch.Tensor:
+        """transforms.Resize(size) of data_loader.py:52-56 on the GPU, bit-exact with Pillow's bilinear Image.resize: `size` is an
+        int (smaller edge, torchvision's rule) or an (oH, oW) pair.  to_tensor=True returns ToTensor()'s fp32 1x3xoHxoW instead of
+        uint8 HWC (one pass less)."""
+        x = self._u8(img_u8)
+        H, W = int(x.shape[0]), int(x.shape[1])
+        oH, oW = self.resize_shape(H, W, size) if isinstance(size, int) else (int(size[0]), int(size[1]))
+        self._stream()
+        if to_tensor:
+            out = torch.empty((1, 3, oH, oW), device=x.device, dtype=torch.float32)
+            self._chk(self._lib.wct_resize_u8_to_planar(self._ctx, x.data_ptr(), H, W, out.data_ptr(), oH, oW))
+        else:
+            out = torch.empty((oH, oW, 3), device=x.device, dtype=torch.uint8)
+            self._chk(self._lib.wct_resize_u8(self._ctx, x.data_ptr(), H, W, out.data_ptr(), oH, oW))
+        return out
+
     @torch.no_grad()
     def to_u8(self, img: torch.Tensor, round_mode: int = 0) -> torch.Tensor:
         """save_image's conversion (WCT.py:128; torchvision 0.2.1: mul(255).clamp(0,255).byte()) on the GPU: fp32 CHW -> uint8 HWC."""

@@ -171,6 +171,18 @@ int wct_planar_to_u8(wct_ctx* ctx, const float* planar, int H, int W, uint8_t* h
 int wct_stylize_u8(wct_ctx* ctx, const uint8_t* content_hwc, int H, int W, const uint8_t* style_hwc, int Hs, int Ws,
                    float alpha, int num_run, uint8_t* out_hwc, int* Ho, int* Wo, int round_mode);
 
+/* transforms.Resize(size) of the reference harness (PytorchWCT/data_loader.py:52-56: torchvision 0.2.1 functional.resize ->
+ * PIL Image.resize((ow, oh), Image.BILINEAR)) on the device, bit-exact with Pillow's resampler (requirements.txt: Pillow==8.2.0;
+ * libImaging/Resample.c: separable, horizontal pass first, antialiased triangle filter, 22-bit fixed-point weights).
+ *   wct_resize_shape         torchvision's size rule: the smaller edge becomes `size` (0 or already equal: unchanged)
+ *   wct_resize_u8            uint8 HWC -> uint8 HWC of oH x oW (any target size; equal sizes copy)
+ *   wct_resize_u8_to_planar  the same followed by ToTensor (data_loader.py:57: planar fp32 / 255) without a uint8 round trip
+ * Pointers are device pointers; the source must be 4-byte aligned.  Weight tables per (input, output) size are built on
+ * the host on first use (O(W + H)) and cached in the context. */
+int wct_resize_shape(int H, int W, int size, int* oH, int* oW);
+int wct_resize_u8(wct_ctx* ctx, const uint8_t* src_hwc, int H, int W, uint8_t* dst_hwc, int oH, int oW);
+int wct_resize_u8_to_planar(wct_ctx* ctx, const uint8_t* src_hwc, int H, int W, float* planar, int oH, int oW);
+
 /* bytes of internal workspace a wct_stylize of this size will hold; wct_reserve allocates it up front */
 size_t wct_workspace_bytes(const wct_ctx* ctx, int H, int W, int Hs, int Ws);
 int wct_reserve(wct_ctx* ctx, int H, int W, int Hs, int Ws);

@@ -80,3 +80,28 @@ def test_cli_end_to_end(tmp_path):
         assert np.abs(got.astype(np.int32) - ref.astype(np.int32)).mean() < 12
     log = (o / "log_T_16x.txt").read_text()
     assert "Number of content-style pairs: 2" in log and "Processed 2 images." in log
+
+
+@pytest.mark.gpu
+def test_cli_resizes_on_the_device(tmp_path):
+    """--content_size / --style_size (data_loader.py:52-56): the CLI resizes on the GPU; the result equals the cascade run on the
+    images Pillow resizes on the host (load_rgb_u8(path, size))."""
+    import types
+    import torch
+    Image = pytest.importorskip("PIL.Image")
+    from wct_hip import WCT
+    rng = np.random.default_rng(4)
+    c, s, o = tmp_path / "content", tmp_path / "style", tmp_path / "out"
+    c.mkdir(); s.mkdir()
+    Image.fromarray(rng.integers(0, 256, size=(150, 230, 3), dtype=np.uint8)).save(c / "c.png")
+    Image.fromarray(rng.integers(0, 256, size=(90, 70, 3), dtype=np.uint8)).save(s / "st.png")
+    assert cli.main(["--mode", "16x", "--contentPath", str(c), "--stylePath", str(s), "--outf", str(o), "--log_mark", "R",
+                     "--content_size", "64", "--style_size", "96"]) == 0
+    w = WCT(types.SimpleNamespace(mode="16x", alpha=1.0))
+    ch, sh = cli.load_rgb_u8(str(c / "c.png"), 64), cli.load_rgb_u8(str(s / "st.png"), 96)
+    assert ch.shape == (64, 98, 3) and sh.shape == (123, 96, 3)
+    assert np.array_equal(w.resize_u8(torch.from_numpy(cli.load_rgb_u8(str(c / "c.png"))), 64).cpu().numpy(), ch)
+    got = np.asarray(Image.open(o / "R_mode=16x_alpha=1_c+st.jpg").convert("RGB"))
+    ref = w.stylize_u8(torch.from_numpy(ch), torch.from_numpy(sh)).cpu().numpy()
+    assert got.shape == ref.shape == (64, 96, 3)
+    assert np.abs(got.astype(np.int32) - ref.astype(np.int32)).mean() < 12

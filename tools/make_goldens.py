@@ -391,8 +391,47 @@ def gen_g11():
     print("G11: mean %.6f std %.6f max %.4f" % (g["mean"], g["std"], g["max"]))
 
 
+def gen_g12():
+    """G12 Resize.  PytorchWCT/data_loader.py:52-56 calls transforms.Resize(size) (torchvision==0.2.1, absent from the snapshot and
+    this image); its published body for a PIL image and an int size is restated here with the Pillow call it makes:
+        (w, h) = img.size; unchanged if the smaller edge == size; else smaller edge -> size, other -> int(size * long / short);
+        img.resize((ow, oh), Image.BILINEAR)
+    The pixels come from Pillow itself (this image: the version printed below; requirements.txt pins 8.2.0 -- the 8-bit resampler's
+    arithmetic is the same).  Inputs: a crop of the reference's content/in4.jpg (natural data) and seeded noise, portrait and
+    landscape; shrinking (antialiased), enlarging, one edge unchanged, no-op."""
+    import PIL
+    from PIL import Image
+
+    def tv_resize(img, size):
+        w, h = img.size
+        if (w <= h and w == size) or (h <= w and h == size):
+            return img
+        if w < h:
+            ow, oh = size, int(size * h / w)
+        else:
+            oh, ow = size, int(size * w / h)
+        return img.resize((ow, oh), Image.BILINEAR)
+
+    r = np.random.default_rng(12)
+    nat = np.asarray(Image.open(os.path.join(REF, "PytorchWCT", "content", "in4.jpg")).convert("RGB"))[100:260, 80:320].copy()   # 160 x 240
+    noise_p = r.integers(0, 256, size=(131, 97, 3), dtype=np.uint8)       # portrait
+    noise_l = r.integers(0, 256, size=(45, 200, 3), dtype=np.uint8)       # landscape, strongly non-square
+    g = {"nat": nat, "noise_p": noise_p, "noise_l": noise_l, "pillow": np.array(PIL.__version__)}
+    for name, img in (("nat", nat), ("noise_p", noise_p), ("noise_l", noise_l)):
+        for size in (64, 77, 30, 7, 300 if name == "nat" else 150, min(img.shape[:2])):
+            g["%s.resize%d" % (name, size)] = np.asarray(tv_resize(Image.fromarray(img), size))
+    # explicit (oh, ow) targets: one edge unchanged, single row / column outputs
+    for (oh, ow) in ((160, 100), (50, 240), (1, 1), (333, 17)):
+        g["nat.to%dx%d" % (oh, ow)] = np.asarray(Image.fromarray(nat).resize((ow, oh), Image.BILINEAR))
+    np.savez_compressed(os.path.join(GOLD, "g12_resize.npz"), **g)
+    print("G12: Pillow %s, %d arrays" % (PIL.__version__, len(g)))
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 2 and sys.argv[1] == "--only" and sys.argv[2] == "g11":
+    if len(sys.argv) > 2 and sys.argv[1] == "--only" and sys.argv[2] == "g12":
+        os.makedirs(GOLD, exist_ok=True)
+        gen_g12()
+    elif len(sys.argv) > 2 and sys.argv[1] == "--only" and sys.argv[2] == "g11":
         os.makedirs(GOLD, exist_ok=True)
         gen_g11()
     elif len(sys.argv) > 2 and sys.argv[1] == "--only" and sys.argv[2] == "g10":
@@ -406,3 +445,4 @@ if __name__ == "__main__":
         gen_g9()
         gen_g10()
         gen_g11()
+        gen_g12()
