@@ -65,9 +65,13 @@ def pmc_traffic(family):
         return None
     co, pool, out3, dma = int(m.group(1)), bool(m.group(2)), bool(m.group(3)), bool(m.group(4))
     tf = lambda b: "true" if b else "false"
-    if dma:     # <CT, POOL, OUTF32, GROUPS>: both output formats of the family
-        pre = "void conv3x3_sp_kernel<%d, %s, " % (1 if co == 32 else 2, tf(pool))
-        rows = [v for k, v in ks.items() if k.startswith(pre) and k.endswith(", %s>(SpArgs)" % tf(co >= 128))]
+    if dma:     # <CT, POOL, OUTF32, GROUPS[, DEEP]>: both output formats (and both pipeline depths) of the family
+        rx = re.compile(r"void conv3x3_sp_kernel<(\d), (true|false), (true|false), (true|false)(?:, (true|false))?>\(SpArgs\)")
+        rows = []
+        for k, v in ks.items():
+            mm = rx.match(k)
+            if mm and int(mm.group(1)) == (1 if co == 32 else 2) and mm.group(2) == tf(pool) and mm.group(4) == tf(co >= 128):
+                rows.append(v)
         if not rows:
             return None
         n = sum(r["calls"] for r in rows)
