@@ -283,7 +283,9 @@ def main():
             roof = {"kernel": d["name"], "bound": "mfma", "achieved": round(tf, 2), "peak": round(peak_tf, 1), "unit": "TFLOP/s",
                     "frac": round(tf / peak_tf, 4), "traffic": None,
                     "peak_note": "2.5 PF dense f16 MFMA / 3 split terms" if f16 else "fp32 MFMA"}
-        roof["traffic"] = pmc_traffic(d["name"])
+        pmc = pmc_traffic(d["name"])     # HBM bytes per launch from the committed rocprofv3 PMC passes (a number, or null)
+        roof["traffic"] = pmc["hbm_bytes_per_launch"] if pmc else None
+        roof["traffic_source"] = ({"file": pmc["source"], "pmc_avg_launch_us": pmc["pmc_avg_launch_us"]} if pmc else None)
         roof.update({"avg_launch_ms": round(d["ms"] / d["launches"], 4), "share_of_kernel_time": round(d["ms"] / tot, 3),
                      "algo_flop_per_launch": d["flops"] / d["launches"], "algo_bytes_per_launch": d["bytes"] / d["launches"]})
     del step

@@ -987,6 +987,12 @@ hipError_t launch_conv3x3_f16(const ConvDesc& d, const float* in, float* out, in
     if (d.cout_pad % 128) return hipErrorInvalidValue;
     groups = d.cout_pad / 128; ct = 4;
   }
+  // small maps (level 5's first decoder conv: 135 x 240 x 128 -> 72 tiles of 32 x 16 on 256 CUs): 32 x 8 tiles and cout groups of
+  // 64 instead -- four times the workgroups, the same arithmetic per output (bit-identical)
+  static const int small_env = [] { const char* e = wct_debug_env("WCT_F16_SMALL"); return e ? atoi(e) : 1; }();
+  if (ct == 4 && small_env && a.tiles_x * ((H + 15) / 16) * groups < num_cus()) {
+    ct = 2; groups = d.cout_pad / 64;
+  }
   if (ct == 4) {  // 128 couts: 32 x 16 pixel tile, 8 waves (2 per SIMD), the 74 KB weight slab serves 512 pixels
     a.tiles_y = (H + 15) / 16;
     const size_t lds16 = (size_t)4 * npp(16) * 16 + (size_t)36 * 128 * 16;
