@@ -580,6 +580,7 @@ struct TailArgs {   // conv12 (16->16 on the nearest-x2 upsampled input) + ReLU 
   int H, W, inW, up_in, tiles_x, tiles_y;
   int in_sp;
   unsigned* sat;
+  const u32x4* w12u; float inv12u;   // conv12 behind the upsample as per-parity 2x2 weights (ConvDesc::wup16), dec_tail_up_kernel
 };
 
 // Tile geometry of the fused tail for a tile of 32 x TH output pixels (TH / 2 waves, 32 * TH threads): TH = 8 -> 4 waves, two
@@ -775,6 +776,176 @@ __global__ __launch_bounds__(32 * TH, TH == 8 ? 2 : 1) void dec_tail_kernel(Tail
   sat.commit(a.sat);
 }
 
+// ---- the same tail with conv12 evaluated on the LOW-RESOLUTION input (up_in = 1 only).
+// conv12 runs behind the nearest-x2 upsample, so each output parity (a, b) is a 2x2 convolution of the low-resolution map with summed
+// taps (wct_api.hip pack_up_phase_f16): K = 2 x 2 x 16 = 64 = two 16x16x32 K-steps (tap row i; kq -> column j = kq >> 1, channels
+// 8 (kq & 1) ..) = 6 MFMAs and 4 operand reads per 16 halo pixels instead of 15 and 10, and the staged window is the 18 x (TH / 2 + 2)
+// low-resolution pixels the tile touches instead of their 36 x (TH + 4) fourfold copies (16 KB instead of 64.5 KB at TH = 24).
+// A 16-pixel group must share its parity: the 34 x (TH + 2) halo is cut into row groups g = 2 row + c (pixels x = 2 li + 1 - c: every
+// second column) plus four groups for the two leftover columns (33 - c, rows 2 li + r); with g dealt to wave g mod NWV (NWV and the
+// number of row groups are multiples of 4) ALL groups of a wave have the parity a = ((wave >> 1) & 1) ^ 1, b = wave & 1, so the
+// wave keeps its phase's weights in 16 registers and conv12 reads no weights from LDS at all.  Reflect padding of the upsampled
+// map = clamping of the low-resolution coordinates; a halo pixel outside the image is evaluated at its reflected coordinate,
+// which has the same parity.  Sums of taps are formed in double on the host: fp32 round-off agreement with the 9-tap form.
+template <int TH>
+struct TailUpGeo {
+  static constexpr int NT = 32 * TH, NWV = TH / 2;
+  static constexpr int HROWS = TH + 2, NROWG = 2 * HROWS, NGRP = NROWG + 4, NG = (NGRP + NWV - 1) / NWV;
+  static constexpr int LW = FTW / 2 + 2, LH = TH / 2 + 2, NPL = (LW * LH + 15) / 16 * 16;     // low-resolution window 18 x (TH / 2 + 2): 256 / 192 / 112 slots
+  static constexpr int NPX = (HROWS * PH_W + 15) / 16 * 16;
+  static_assert(NWV % 4 == 0 && NROWG % 4 == 0 && 2 * LW * LH <= NT, "phase-uniform waves; one (pixel, channel half) slot per thread");
+  static constexpr size_t lds = ((size_t)4 * NPL + PH_WSLOTS + (size_t)4 * NPX) * 16;           // 89.1 / 62.5 / 43.0 KB
+};
+
+template <int TH>
+__global__ __launch_bounds__(32 * TH, TH == 8 ? 2 : 1) void dec_tail_up_kernel(TailArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  using G = TailUpGeo<TH>;
+  constexpr int NT = G::NT, NWV = G::NWV, NG = G::NG, NPL = G::NPL, NPX = G::NPX, LW = G::LW, LH = G::LH;
+  u32x4* act0 = reinterpret_cast<u32x4*>(smem);   // [4][NPL]  low-resolution input window, planes (hl, channel half)
+  u32x4* wg11 = act0 + 4 * NPL;                   // [PH_WSLOTS]  phase-packed 16 -> 3 weights
+  u32x4* act1 = wg11 + PH_WSLOTS;                 // [4][NPX]  conv12 output on the 34 x (TH + 2) halo, pair-major slots (ph_slot)
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, kq = lane >> 4, kh = kq & 1, ts = kq >> 1;
+  const int ntiles = a.tiles_x * a.tiles_y;
+  const unsigned txm = tile_div_magic(a.tiles_x);
+  for (int e = tid; e < PH_WSLOTS; e += NT) wg11[e] = a.w11[e];
+  const int pa = ((wave >> 1) & 1) ^ 1, pb = wave & 1;          // the parity of every halo group of this wave
+  f16x8 wq[2][2];                                                // [tap row][hi / lo] of this phase
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int hl = 0; hl < 2; ++hl) wq[i][hl] = __builtin_bit_cast(f16x8, a.w12u[((((pa * 2 + pb) * 2 + i) * 2 + hl) * 4 + kq) * 16 + li]);
+  const f32x4 bias12 = *reinterpret_cast<const f32x4*>(a.b12 + 4 * kq);
+  const f32x4 bias11 = *reinterpret_cast<const f32x4*>(a.b11);
+  const size_t plane = (size_t)a.H * a.W;
+  const int inH = a.H >> 1;
+
+  // this thread's slot of the low-resolution window: pixel e >> 1, channel half e & 1
+  const int fe = tid < 2 * LW * LH ? tid : 2 * LW * LH - 1;
+  const int fpix = fe >> 1, fpy = fpix / LW, fpx = fpix - fpy * LW, fh = fe & 1;
+  const int soff = (fpy * a.inW + fpx) * 16 + fh * 8;
+  // the wave's halo groups
+  int gpy[NG], gpx[NG], gslot[NG], gbase[NG];
+  bool gok[NG];
+#pragma unroll
+  for (int u = 0; u < NG; ++u) {
+    const int g = wave + NWV * u;
+    if (g < G::NROWG) { gpy[u] = g >> 1; gpx[u] = 2 * li + 1 - (g & 1); gok[u] = true; }
+    else { const int h = g - G::NROWG; gpx[u] = 33 - (h & 1); gpy[u] = 2 * li + (h >> 1); gok[u] = g < G::NGRP && gpy[u] < G::HROWS; }
+    if (!gok[u]) { gpy[u] = 1; gpx[u] = 1; }   // never stored; any in-window patch
+    gslot[u] = ph_slot(gpy[u], gpx[u]);
+    // interior tiles: window slot of the 2x2 patch's top-left = ((q >> 1) + parity) per axis, q = halo coordinate - 1
+    gbase[u] = (((gpy[u] - 1) >> 1) + pa) * LW + ((gpx[u] - 1) >> 1) + pb;
+  }
+
+  f32x4 r0, r1;
+  SatTrack sat;
+  auto fetch = [&](int tile) {
+    int trow_, tcol_;
+    tile_rc(tile, a.tiles_x, txm, trow_, tcol_);
+    const int ty0 = trow_ * TH, tx0 = tcol_ * FTW;
+    const float* src;
+    if (tile_interior_h(ty0, tx0, a.H, a.W, TH)) {
+      src = a.in + ((size_t)((ty0 >> 1) - 1) * a.inW + ((tx0 >> 1) - 1)) * 16 + (unsigned)soff;
+    } else {
+      int gy = (ty0 >> 1) - 1 + fpy, gx = (tx0 >> 1) - 1 + fpx;
+      gy = gy < 0 ? 0 : (gy >= inH ? inH - 1 : gy);
+      gx = gx < 0 ? 0 : (gx >= a.inW ? a.inW - 1 : gx);
+      src = a.in + ((size_t)gy * a.inW + gx) * 16 + fh * 8;
+    }
+    r0 = *reinterpret_cast<const f32x4*>(src);
+    r1 = *reinterpret_cast<const f32x4*>(src + 4);
+  };
+  auto commit = [&]() {
+    if (tid < 2 * LW * LH) {
+      f16x8 hi, lo;
+      if (a.in_sp) { hi = __builtin_bit_cast(f16x8, r0); lo = __builtin_bit_cast(f16x8, r1); }
+      else split8(r0, r1, hi, lo, sat);
+      act0[(0 * 2 + fh) * NPL + fpix] = __builtin_bit_cast(u32x4, hi);
+      act0[(1 * 2 + fh) * NPL + fpix] = __builtin_bit_cast(u32x4, lo);
+    }
+  };
+  int v = blockIdx.x;
+  if (v < ntiles) { fetch(xcd_swizzle(v, ntiles)); commit(); }
+  settle_preloop_loads();
+  for (; v < ntiles; v += gridDim.x) {
+    const int tile = xcd_swizzle(v, ntiles);
+    int trow_, tcol_;
+    tile_rc(tile, a.tiles_x, txm, trow_, tcol_);
+    const int ty0 = trow_ * TH, tx0 = tcol_ * FTW;
+    __syncthreads();   // the window of this tile is in LDS; every wave is done with the previous tile's act1
+    const int vn = v + gridDim.x;
+    if (vn < ntiles) fetch(xcd_swizzle(vn, ntiles));
+    // ---- conv12 on the halo pixels, from the low-resolution window
+    {
+      f32x4 acc[NG];
+      int sp0[NG];
+      if (tile_interior_h(ty0, tx0, a.H, a.W, TH)) {
+#pragma unroll
+        for (int u = 0; u < NG; ++u) sp0[u] = gbase[u];
+      } else {
+#pragma unroll
+        for (int u = 0; u < NG; ++u) {
+          // evaluated at the reflected image coordinate (same parity); rows / columns clamped into the staged window
+          const int ey = reflect_clamp(ty0 - 1 + gpy[u], a.H), ex = reflect_clamp(tx0 - 1 + gpx[u], a.W);
+          int wr = (ey >> 1) - (ty0 >> 1) + pa, wc = (ex >> 1) - (tx0 >> 1) + pb;
+          wr = wr < 0 ? 0 : (wr > LH - 2 ? LH - 2 : wr);
+          wc = wc < 0 ? 0 : (wc > LW - 2 ? LW - 2 : wc);
+          sp0[u] = wr * LW + wc;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < NG; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        f16x8 bh[NG], bl[NG];
+#pragma unroll
+        for (int u = 0; u < NG; ++u) {
+          const int sp = sp0[u] + i * LW + ts;
+          bh[u] = __builtin_bit_cast(f16x8, act0[(0 * 2 + kh) * NPL + sp]);
+          bl[u] = __builtin_bit_cast(f16x8, act0[(1 * 2 + kh) * NPL + sp]);
+        }
+#pragma unroll
+        for (int term = 0; term < 3; ++term)
+#pragma unroll
+          for (int u = 0; u < NG; ++u)
+            acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wq[i][term == 2], term == 1 ? bl[u] : bh[u], acc[u], 0, 0, 0);
+      }
+#pragma unroll
+      for (int u = 0; u < NG; ++u) {
+        f32x4 x;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) x[r] = acc[u][r] * a.inv12u + bias12[r];
+        if (gok[u]) store_split4<true>(act1, NPX, gslot[u], kq, x, sat);
+      }
+    }
+    __syncthreads();
+    // ---- conv11 (16 -> 3) + ReLU -> planar output, phase-packed (conv_f16_dev.h): lanes kq in {0, 2} hold pixel 2 li + (kq >> 1)
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) acc[r][h] = f32x4{0.f, 0.f, 0.f, 0.f};
+    c3_phase_compute<NPX>(act1, wg11, wave, li, kq, acc);
+    if (!(kq & 1)) {
+      const int gx = tx0 + 2 * li + (kq >> 1);
+#pragma unroll
+      for (int r2 = 0; r2 < 2; ++r2) {
+        const int gy = ty0 + wave * 2 + r2;
+        if (gy < a.H && gx < a.W) {
+          const size_t off = (size_t)gy * a.W + gx;
+          a.out[off] = fmaxf((acc[r2][0][0] + acc[r2][1][0]) * a.inv11 + bias11[0], 0.f);
+          a.out[plane + off] = fmaxf((acc[r2][0][1] + acc[r2][1][1]) * a.inv11 + bias11[1], 0.f);
+          a.out[2 * plane + off] = fmaxf((acc[r2][0][2] + acc[r2][1][2]) * a.inv11 + bias11[2], 0.f);
+        }
+      }
+    }
+    if (vn < ntiles) commit();   // conv12 of this tile is behind the barrier above
+  }
+  sat.commit(a.sat);
+}
+
 template <typename K>
 hipError_t launch_k(K k, const F16Args& a, size_t lds, int groups, hipStream_t s, int threads = 256) {
   if (lds > 48 * 1024) {
@@ -909,12 +1080,29 @@ hipError_t launch_dec_tail(const ConvDesc& d0, const ConvDesc& d1, const float* 
   a.H = H; a.W = W; a.up_in = (d0.flags & CONV_UP_IN) ? 1 : 0; a.inW = a.up_in ? W / 2 : W;
   a.in_sp = (d0.flags & CONV_IN_SP16) ? 1 : 0;
   a.sat = d1.sat;
+  a.w12u = nullptr; a.inv12u = 1.f;
   a.tiles_x = (W + FTW - 1) / FTW;
   static const int th_env = [] { const char* e = wct_debug_env("WCT_TAIL_TH"); return e ? atoi(e) : 0; }();   // experiment: force 8 / 16
   // 32 x 16 tiles (conv12's halo recompute 1.20 instead of 1.33: -10 % at 4K) once they still fill the chip; results do not
   // depend on the tile shape (same arithmetic per pixel)
   // (32 x 24, 12 waves: three waves per SIMD instead of two and recompute 1.15: another -7 %, when every CU still gets four tiles)
   const int th = th_env ? th_env : (((H + 23) / 24) * a.tiles_x >= 4 * num_cus() ? 24 : (((H + 15) / 16) * a.tiles_x >= 2 * num_cus() ? 16 : 8));
+  // conv12 on the low-resolution input with per-parity 2x2 weights (dec_tail_up_kernel) whenever the layer sits behind an upsample
+  static const int up_env = [] { const char* e = wct_debug_env("WCT_TAIL_UP"); return e ? atoi(e) : 1; }();
+  if (up_env && a.up_in && d0.wup16 && !(H & 1) && !(W & 1)) {
+    a.w12u = reinterpret_cast<const u32x4*>(d0.wup16); a.inv12u = d0.inv_scale_up;
+    auto gou = [&](auto kern, auto geo, int per_cu) -> hipError_t {
+      using G = decltype(geo);
+      a.tiles_y = (H + G::HROWS - 3) / (G::HROWS - 2);
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::lds);
+      if (e != hipSuccess) return e;
+      const int ntiles = a.tiles_x * a.tiles_y, grid = ntiles < per_cu * num_cus() ? ntiles : per_cu * num_cus();
+      hipLaunchKernelGGL(kern, dim3(grid), dim3(G::NT), G::lds, s, a);
+      return hipGetLastError();
+    };
+    if (th == 24) return gou(dec_tail_up_kernel<24>, TailUpGeo<24>{}, 1);
+    return th == 16 ? gou(dec_tail_up_kernel<16>, TailUpGeo<16>{}, 1) : gou(dec_tail_up_kernel<8>, TailUpGeo<8>{}, 2);
+  }
   auto go = [&](auto kern, auto geo, int per_cu) -> hipError_t {
     using G = decltype(geo);
     a.tiles_y = (H + G::HROWS - 3) / (G::HROWS - 2);

@@ -30,6 +30,7 @@ struct LayerDev {
   void* wpk16 = nullptr;  // split-f16 weights (all but the 3-channel first conv)
   void* l1w16 = nullptr;  // 3-channel first conv with <= 32 couts: f16x3 slot packing for the level-1 kernels
   void* wph16 = nullptr;  // last decoder conv (-> 3 couts): phase-packed split-f16 weights for the fused tails
+  void* wup16 = nullptr;  // 16 -> 16 conv behind an upsample: per-parity 2x2 weights (ConvDesc::wup16)
   float* l1bias = nullptr;
 };
 
@@ -303,6 +304,49 @@ void pack_out3_phase_f16(const float* w, int cout, int cin, std::vector<_Float16
           }
 }
 
+// A 3x3 convolution (reflect padding) of a nearest-x2 upsampled map U[y][x] = X[y >> 1][x >> 1]:  an output row y = 2Y + a reads
+// U rows y - 1, y, y + 1 = X rows (Y - 1, Y, Y) for a = 0 and (Y, Y, Y + 1) for a = 1 -- two distinct rows, the taps that fall on
+// the same row summed; columns alike.  So each output parity (a, b) is a 2x2 convolution of X with window origin
+// (Y - 1 + a, X - 1 + b) and weights  Wab[i][j] = SUM_{dy in R(a,i)} SUM_{dx in R(b,j)} w[dy][dx],  R(0,0) = {0}, R(0,1) = {1,2},
+// R(1,0) = {0,1}, R(1,1) = {2}: 4 instead of 9 products per output and channel pair.  (U's reflect padding maps to CLAMPING X's
+// coordinates: U[-1] = U[1] = X[0], U[H] = U[H - 2] = X[H/2 - 1].)  Sums in double, then the usual scaled hi/lo split.
+// Layout for 16 -> 16: [phase 2a + b][i][hl][kq][16 couts] x 8 halfs; K = 32 per tap row: kq -> column j = kq >> 1, channels
+// 8 (kq & 1) + e.  Returns 2^-e of its own scale.
+float pack_up_phase_f16(const float* w, int cout, int cin, std::vector<_Float16>& out) {
+  static const int R0[2][2] = {{0, 1}, {0, 2}}, R1[2][2] = {{0, 2}, {1, 2}};   // [a][i] -> first / last tap of the run R(a, i)
+  std::vector<double> comb((size_t)4 * 2 * 2 * 16 * 16, 0.0);   // [p][i][j][co][ch]
+  double mx = 0.0;
+  for (int pa = 0; pa < 2; ++pa)
+    for (int pb = 0; pb < 2; ++pb)
+      for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 2; ++j)
+          for (int co = 0; co < cout && co < 16; ++co)
+            for (int ch = 0; ch < cin && ch < 16; ++ch) {
+              double sum = 0.0;
+              for (int dy = R0[pa][i]; dy <= R1[pa][i]; ++dy)
+                for (int dx = R0[pb][j]; dx <= R1[pb][j]; ++dx) sum += (double)w[((size_t)co * cin + ch) * 9 + dy * 3 + dx];
+              comb[(((((size_t)(pa * 2 + pb) * 2 + i) * 2 + j) * 16 + co) * 16) + ch] = sum;
+              mx = std::max(mx, std::fabs(sum));
+            }
+  int ex = 0;
+  if (mx > 0.0 && std::isfinite(mx)) { (void)std::frexp((float)mx, &ex); ex = 9 - ex; }
+  const float scale = std::ldexp(1.f, ex);
+  out.assign((size_t)4 * 2 * 2 * 4 * 16 * 8, (_Float16)0.f);
+  for (int p = 0; p < 4; ++p)
+    for (int i = 0; i < 2; ++i)
+      for (int kq = 0; kq < 4; ++kq)
+        for (int co = 0; co < 16; ++co)
+          for (int e = 0; e < 8; ++e) {
+            const int j = kq >> 1, ch = 8 * (kq & 1) + e;
+            const float x = (float)(comb[(((((size_t)p * 2 + i) * 2 + j) * 16 + co) * 16) + ch] * (double)scale);
+            const _Float16 h = (_Float16)x;
+            const size_t base = ((size_t)p * 2 + i) * 2;
+            out[(((base + 0) * 4 + kq) * 16 + co) * 8 + e] = h;
+            out[(((base + 1) * 4 + kq) * 16 + co) * 8 + e] = (_Float16)(x - (float)h);
+          }
+  return std::ldexp(1.f, -ex);
+}
+
 // split-f16 packing of the 3-channel first conv for the fused encoder head (conv3x3_f16.hip, enc_head_kernel):
 // K = 64 in 8-half slots, slot s = 4 kb + kq -> image row dy = s >> 1, pixels 2 (s & 1) + {0, 1}, channels RGB0;
 // layout [kb][hi/lo][kq][16 couts] x 8 halfs.  in3: the fp32 packing [tap][4][16] (conv0 already folded).  Returns 2^-e.
@@ -344,6 +388,7 @@ void free_module(Module& m) {
     if (l.wpk16) (void)hipFree(l.wpk16);
     if (l.l1w16) (void)hipFree(l.l1w16);
     if (l.wph16) (void)hipFree(l.wph16);
+    if (l.wup16) (void)hipFree(l.wup16);
     if (l.l1bias) (void)hipFree(l.l1bias);
     if (l.bias) (void)hipFree(l.bias);
   }
@@ -840,6 +885,13 @@ int wct_load_module(wct_ctx* ctx, int kind, int level, int n_layers, const wct_l
       HIPCHK(ctx, hipMalloc(&ld.wpk16, w16.size() * sizeof(_Float16)));
       HIPCHK(ctx, hipMemcpy(ld.wpk16, w16.data(), w16.size() * sizeof(_Float16), hipMemcpyHostToDevice));
       ld.d.wpk16 = ld.wpk16;
+      if ((ld.d.flags & CONV_UP_IN) && L.cin == 16 && L.cout == 16) {   // per-parity 2x2 form for the fused tail's first conv
+        std::vector<_Float16> wup;
+        ld.d.inv_scale_up = pack_up_phase_f16(L.weight, L.cout, L.cin, wup);
+        HIPCHK(ctx, hipMalloc(&ld.wup16, wup.size() * sizeof(_Float16)));
+        HIPCHK(ctx, hipMemcpy(ld.wup16, wup.data(), wup.size() * sizeof(_Float16), hipMemcpyHostToDevice));
+        ld.d.wup16 = ld.wup16;
+      }
       if (out3 && ld.d.cout_pad == 16) {   // phase-packed form for the fused tails
         std::vector<_Float16> wph;
         pack_out3_phase_f16(L.weight, L.cout, L.cin, wph);

@@ -48,6 +48,11 @@ struct ConvDesc {
   // last decoder conv (16-channel chunks -> 3 couts): the same split-f16 weights (same scale) in the phase-packed layout of
   // conv_f16_dev.h c3_phase_compute, [chunk][6 ks][hl][kq][16 m] x 16 B, for the fused tails
   const void* wph16 = nullptr;
+  // CONV_UP_IN layers with 16 -> 16 channels (the fused tail's first conv): the 3x3 convolution of a nearest-x2 upsampled map is,
+  // per output parity (a, b), a 2x2 convolution of the LOW-RESOLUTION map with summed taps (conv3x3_f16.hip dec_tail_kernel) --
+  // split-f16 weights [phase 2a + b][tap row][hl][kq][16 couts] x 16 B with their own power-of-two scale
+  const void* wup16 = nullptr;
+  float inv_scale_up = 1.f;
   // the context's sticky saturation counter (device): raised by the f16x3 kernels when an activation exceeded +-65504 and
   // was clamped (conv_f16_dev.h SatTrack); may be null
   unsigned* sat = nullptr;
