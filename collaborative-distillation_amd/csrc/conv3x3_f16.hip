@@ -794,6 +794,7 @@ struct TailUpGeo {
   static constexpr int LW = FTW / 2 + 2, LH = TH / 2 + 2, NPL = (LW * LH + 15) / 16 * 16;     // low-resolution window 18 x (TH / 2 + 2): 256 / 192 / 112 slots
   static constexpr int NPX = (HROWS * PH_W + 15) / 16 * 16;
   static_assert(NWV % 4 == 0 && NROWG % 4 == 0 && 2 * LW * LH <= NT, "phase-uniform waves; one (pixel, channel half) slot per thread");
+  static_assert(HROWS / 2 <= 16, "a leftover column's rows of one parity fit one 16-pixel group (32 x 32 tiles were measured with two more groups' worth missing: -7 %, not pursued)");
   static constexpr size_t lds = ((size_t)4 * NPL + PH_WSLOTS + (size_t)4 * NPX) * 16;           // 89.1 / 62.5 / 43.0 KB
 };
 

@@ -297,6 +297,186 @@ __global__ __launch_bounds__(512) void conv3x3_sp_kernel(SpArgs a) {
 #endif
 }
 
+// =====================================================================================================================
+// Layers BEHIND a nearest-x2 upsample (CONV_UP_IN), on the low-resolution grid.
+// The 3x3 convolution of the upsampled map is, per output parity (a, b), a 2x2 convolution of the low-resolution map with
+// summed taps (wct_api.hip pack_up_phase_f16): 4 instead of 9 products per output and channel pair.  The kernel above gathered
+// the upsampled 34 x 18 halo (each low-resolution pixel up to four times) and ran nine taps; this one stages the LOW-RESOLUTION
+// 34 x 18 halo of a 32 x 16 low-resolution tile (= 64 x 32 outputs) and a work unit is (tile, 32-cout group, row parity a): its
+// two accumulator sets are the column parities b = 0, 1 (the register budget of the 64-cout kernel above), its job walks the six
+// patch offsets (dy in {a, a + 1}) x (dx in {0, 1, 2}), offset dx serving (b, j) = (0, dx) and (1, dx - 1): 48 MFMAs, 24
+// activation and 16 weight reads per wave and chunk for 2 x 64 x 32 outputs, against 4 x 54 in the nine-tap form.
+// Reflect padding of the upsampled map = CLAMPING the low-resolution coordinates.  Everything else -- DMA staging, one barrier
+// per chunk, parked accumulators whose stores ride on the next job -- is the kernel above.
+// Weights: [chunk][a][(b, i, j, hl, kh) = 32][cout_pad] x 16 B with their own power-of-two scale (ConvDesc::wup16 / inv_scale_up).
+template <bool OUTF32>
+__global__ __launch_bounds__(512) void conv3x3_sp_up_kernel(SpArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int COW = 32, NWV = 8;
+  constexpr int WSL = 32 * COW;                         // weight slots per stage (1024)
+  constexpr int STAGE16 = 4 * SP_NPP + WSL;
+  constexpr int W_DMA = WSL / 64, W_PER_WAVE = W_DMA / NWV;   // 16 pieces, 2 per wave
+  constexpr int SP_ACT_PER_WAVE = (SP_ACT_DMA + NWV - 1) / NWV;
+  u32x4* lds = reinterpret_cast<u32x4*>(smem);
+  float* biasL = reinterpret_cast<float*>(lds + 2 * STAGE16);
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, kh = lane >> 5, rw = wave;
+  const int ntiles = a.tiles_x * a.tiles_y;            // low-resolution tiles
+  for (int e = tid; e < a.cout_pad; e += NWV * 64) biasL[e] = a.bias[e];
+  const float inv = a.inv_scale;
+  const size_t in_plane = sp16_plane_bytes(a.inH, a.inW);
+  unsigned long long satmask = 0ull;
+  const float lob = a.relu ? 0.f : -65504.f;
+
+  size_t poff[SP_ACT_PER_WAVE];
+  auto tile_offsets = [&](int tile) {
+    const int ty0 = (tile / a.tiles_x) * SPH, tx0 = (tile % a.tiles_x) * FTW;
+#pragma unroll
+    for (int i = 0; i < SP_ACT_PER_WAVE; ++i) {
+      int idx = wave + NWV * i;
+      idx = idx < SP_ACT_DMA ? idx : SP_ACT_DMA - 1;
+      const int slot_pix = idx * 16 + (lane >> 2);
+      const int q = (lane & 3) ^ ((slot_pix >> 2) & 3);
+      const int pix = slot_pix < SP_NPH ? slot_pix : SP_NPH - 1;
+      const int py = pix / FHW, px = pix - py * FHW;
+      int gy = ty0 - 1 + py, gx = tx0 - 1 + px;
+      gy = gy < 0 ? 0 : (gy >= a.inH ? a.inH - 1 : gy);
+      gx = gx < 0 ? 0 : (gx >= a.inW ? a.inW - 1 : gx);
+      poff[i] = ((size_t)gy * a.inW + gx) * 64 + q * 16;
+    }
+  };
+  // unit group code: g32 = grp >> 1 (32-cout group), pa = grp & 1 (row parity)
+  auto issue_slice = [&](int i, int ch, int grp, int stage) {
+    u32x4* act = lds + stage * STAGE16;
+    u32x4* wgt = act + 4 * SP_NPP;
+    {
+      int idx = wave + NWV * i;
+      idx = idx < SP_ACT_DMA ? idx : SP_ACT_DMA - 1;
+      __builtin_amdgcn_global_load_lds(a.in + (size_t)ch * in_plane + poff[i], (lds_ptr)(act + idx * 64), 16, 0, 0);
+    }
+    if (i < W_PER_WAVE) {
+      const int idx = wave + NWV * i;                   // 64 slots = two of the 32 (b, i, j, hl, kh) rows
+      const u32x4* g = a.wpk + ((size_t)((ch * 2 + (grp & 1)) * 32 + idx * 2 + (lane >> 5)) * a.cout_pad + (grp >> 1) * 32 + (lane & 31));
+      __builtin_amdgcn_global_load_lds(g, (lds_ptr)(wgt + idx * 64), 16, 0, 0);
+    }
+  };
+
+  // one piece of a finished unit's epilogue: k -> b = k & 1, q = (k >> 1) & 3, p = k >> 3; the four pieces of one iteration
+  // (b, q & 1) x fixed (q >> 1, p) complete the same 128-byte lines of the output (two neighbouring pixel records)
+  constexpr int NPIECE = 16, PPT = 4;
+  auto epilogue_piece = [&](const f32x16 (&r)[2][2], int k, int ty0, int tx0, int pgrp) {
+    const int b = k & 1, q = ((k >> 1) & 1) | (((k >> 2) & 1) << 1), p = k >> 3, pa = pgrp & 1;
+    const int co = (pgrp >> 1) * COW + 8 * q + 4 * kh;
+    const f32x4 bias = *reinterpret_cast<const f32x4*>(biasL + co);
+    f32x4 x;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      x[e] = r[b][p][4 * q + e] * inv + bias[e];
+      if (OUTF32 && a.relu) x[e] = fmaxf(x[e], 0.f);
+    }
+    const int oy = 2 * (ty0 + rw * 2 + p) + pa, ox = 2 * (tx0 + li) + b;
+    const bool ok = oy < a.H && ox < a.W && co < a.cout;
+    if constexpr (OUTF32) {
+      if (ok) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.out) + ((size_t)oy * a.W + ox) * a.cout + co) = x;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) satmask |= __ballot(x[e] > 65504.f);
+      if (!a.relu) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) satmask |= __ballot(x[e] < -65504.f);
+      }
+      const u32x4 w = sp16_pair_exchange_lob(x, lob);
+      if (ok) *reinterpret_cast<u32x4*>(a.out + sp16_piece(sp16_plane_bytes(a.H, a.W), (size_t)oy * a.W + ox, co >> 3, kh)) = w;
+    }
+  };
+
+  f32x16 acc[2][2], pend[2][2];     // [column parity b][tile row p]
+  const int xq = ntiles >> 3, xr = ntiles & 7, xcd = blockIdx.x & 7;
+  const int tbase = xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq;
+  const int ngroups = a.groups;     // 2 x (cout_pad / 32)
+  const int nunits = (xq + (xcd < xr ? 1 : 0)) * ngroups, ustep = gridDim.x >> 3;
+  int v = blockIdx.x >> 3, ch = 0, stage = 0;
+  if (v >= nunits) return;
+  int grp = v % ngroups;
+  int tile = tbase + v / ngroups;
+  int dma_tile = tile;
+  int pgrp = 0, pty0 = 0, ptx0 = 0;
+  bool have_pend = false;
+  const unsigned txm = tile_div_magic(a.tiles_x);
+  tile_offsets(tile);
+#pragma unroll
+  for (int i = 0; i < SP_ACT_PER_WAVE; ++i) issue_slice(i, 0, grp, 0);
+  while (true) {
+    int nv = v, ngrp = grp, nch = ch + 1;
+    if (nch == a.cin_chunks) { nch = 0; nv = v + ustep; ngrp = nv % ngroups; }
+    const bool more = nv < nunits;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (more) {
+      const int ntile = nv == v ? tile : tbase + nv / ngroups;
+      if (ntile != dma_tile) { tile_offsets(ntile); dma_tile = ntile; }
+    }
+    if (ch == 0) {
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[b][p][r] = 0.f;
+    }
+    const u32x4* act = lds + stage * STAGE16;
+    const u32x4* wgt = act + 4 * SP_NPP;
+    const int pa = grp & 1;
+#pragma unroll
+    for (int it = 0; it < 6; ++it) {
+      const int i = it / 3, dx = it - i * 3;          // patch row i (image row offset pa + i), column offset dx
+      f16x8 bh[2], bl[2];
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        const int pix = (rw * 2 + p + pa + i) * FHW + li + dx;
+        bh[p] = __builtin_bit_cast(f16x8, act[sp_slot(pix, 2 * kh)]);
+        bl[p] = __builtin_bit_cast(f16x8, act[sp_slot(pix, 2 * kh + 1)]);
+      }
+      if (it < SP_ACT_PER_WAVE && more) issue_slice(it, nch, ngrp, stage ^ 1);
+      if (it >= 2 && have_pend) {
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) epilogue_piece(pend, (it - 2) * PPT + k, pty0, ptx0, pgrp);
+      }
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const int j = dx - b;
+        if (j < 0 || j > 1) continue;
+        const f16x8 ah = __builtin_bit_cast(f16x8, wgt[((((b * 2 + i) * 2 + j) * 2 + 0) * 2 + kh) * COW + li]);
+        const f16x8 al = __builtin_bit_cast(f16x8, wgt[((((b * 2 + i) * 2 + j) * 2 + 1) * 2 + kh) * COW + li]);
+#pragma unroll
+        for (int term = 0; term < 3; ++term)
+#pragma unroll
+          for (int p = 0; p < 2; ++p)
+            acc[b][p] = __builtin_amdgcn_mfma_f32_32x32x16_f16(term == 2 ? al : ah, term == 1 ? bl[p] : bh[p], acc[b][p], 0, 0, 0);
+      }
+    }
+    have_pend = false;
+    if (ch + 1 == a.cin_chunks) {
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) pend[b][p] = acc[b][p];
+      int trow_, tcol_;
+      tile_rc(tile, a.tiles_x, txm, trow_, tcol_);
+      pty0 = trow_ * SPH; ptx0 = tcol_ * FTW; pgrp = grp; have_pend = true;
+    }
+    if (!more) break;
+    if (nv != v) { v = nv; tile = tbase + nv / ngroups; }
+    grp = ngrp; ch = nch; stage ^= 1;
+  }
+  if (have_pend) {
+#pragma unroll
+    for (int k = 0; k < NPIECE; ++k) epilogue_piece(pend, k, pty0, ptx0, pgrp);
+  }
+  if (satmask != 0ull && lane == 0 && a.sat) atomicAdd(a.sat, 1u);
+}
+
 template <typename K>
 hipError_t launch_sp(K k, const SpArgs& a, size_t lds, hipStream_t s, int threads) {
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -339,6 +519,16 @@ hipError_t launch_conv3x3_sp(const ConvDesc& d, const void* in, void* out, int H
   a.relu = (d.flags & CONV_NO_RELU) ? 0 : 1;
   a.sat = d.sat;
   const bool pool = d.flags & CONV_POOL_OUT, f32 = !(d.flags & CONV_OUT_SP16);
+  // behind an upsample: per-parity 2x2 convolutions on the low-resolution grid (conv3x3_sp_up_kernel)
+  static const int up_env = [] { const char* e = wct_debug_env("WCT_SP_UP"); return e ? atoi(e) : 1; }();
+  if (up_env && a.up_in && d.wup16 && !pool && !d.inv_scale_ptr && !(H & 1) && !(W & 1) && (d.cout_pad % 32) == 0) {
+    a.wpk = reinterpret_cast<const u32x4*>(d.wup16);
+    a.inv_scale = d.inv_scale_up;
+    a.tiles_x = (a.inW + FTW - 1) / FTW; a.tiles_y = (a.inH + SPH - 1) / SPH;
+    a.groups = 2 * (d.cout_pad / 32);
+    const size_t ldsu = (size_t)2 * (4 * SP_NPP + 32 * 32) * 16 + (size_t)d.cout_pad * sizeof(float);   // 114.8 KB
+    return f32 ? launch_sp(conv3x3_sp_up_kernel<true>, a, ldsu, s, 512) : launch_sp(conv3x3_sp_up_kernel<false>, a, ldsu, s, 512);
+  }
   const int ct = (d.cout_pad % 64 == 0) ? 2 : 1;
   a.groups = d.cout_pad / (ct * 32);
   const size_t lds = (size_t)2 * (4 * SP_NPP + 36 * ct * 32) * 16 + (size_t)d.cout_pad * sizeof(float);

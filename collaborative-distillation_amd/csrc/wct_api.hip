@@ -82,6 +82,7 @@ struct wct_ctx {
   int l1fuse = 1;     // 1: level 1 of the 16x cascade without materialising relu1_1 (level1.hip)
   int sp = 1;         // 1: intermediate activations of the f16x3 path in SP16 (split at the producer, DMA-staged consumers)
   int u8fuse = 1;     // 1: wct_stylize_u8 reads / writes uint8 inside the first / last kernel where one exists (reserved)
+  int upconv = 1;     // 1: decoder layers behind an upsample run as per-parity 2x2 convolutions of the low-resolution map (4/9 of the products)
   int fuse = 1;       // 1: fused conv11+conv12+pool / conv12+conv11 kernels at the full-resolution ends of the 16x networks
   int overlap = 1;    // 1: style side on the side lane (overlaps the content side); 0: everything on the caller's stream
   int conv_mode = 1;  // 0: exact-fp32 MFMA everywhere; 1: split-f16 (f16x3) MFMA for all but the first conv
@@ -347,6 +348,42 @@ float pack_up_phase_f16(const float* w, int cout, int cin, std::vector<_Float16>
   return std::ldexp(1.f, -ex);
 }
 
+// The same per-parity weights for the DMA kernel's upsample form (conv3x3_sp.hip conv3x3_sp_up_kernel), any cin % 16 == 0 and cout:
+// [chunk][a][r = (((b * 2 + i) * 2 + j) * 2 + hl) * 2 + kh][cout_pad] x 8 halfs (channels chunk * 16 + kh * 8 + e).  Returns 2^-e.
+float pack_up_sp_f16(const float* w, int cout, int cin, int cout_pad, std::vector<_Float16>& out) {
+  static const int R0[2][2] = {{0, 1}, {0, 2}}, R1[2][2] = {{0, 2}, {1, 2}};
+  const int chunks = (cin + 15) / 16;
+  auto comb = [&](int co, int ch, int pa, int pb, int i, int j) {
+    double sum = 0.0;
+    for (int dy = R0[pa][i]; dy <= R1[pa][i]; ++dy)
+      for (int dx = R0[pb][j]; dx <= R1[pb][j]; ++dx) sum += (double)w[((size_t)co * cin + ch) * 9 + dy * 3 + dx];
+    return sum;
+  };
+  double mx = 0.0;
+  for (int co = 0; co < cout; ++co)
+    for (int ch = 0; ch < cin; ++ch)
+      for (int k = 0; k < 16; ++k) mx = std::max(mx, std::fabs(comb(co, ch, k >> 3, (k >> 2) & 1, (k >> 1) & 1, k & 1)));
+  int ex = 0;
+  if (mx > 0.0 && std::isfinite(mx)) { (void)std::frexp((float)mx, &ex); ex = 9 - ex; }
+  const double scale = std::ldexp(1.0, ex);
+  out.assign((size_t)chunks * 2 * 32 * cout_pad * 8, (_Float16)0.f);
+  for (int co = 0; co < cout; ++co)
+    for (int ch = 0; ch < cin; ++ch) {
+      const int chunk = ch / 16, kh = (ch % 16) / 8, e = ch % 8;
+      for (int pa = 0; pa < 2; ++pa)
+        for (int pb = 0; pb < 2; ++pb)
+          for (int i = 0; i < 2; ++i)
+            for (int j = 0; j < 2; ++j) {
+              const float x = (float)(comb(co, ch, pa, pb, i, j) * scale);
+              const _Float16 h = (_Float16)x;
+              const size_t row = (size_t)(chunk * 2 + pa) * 32 + (size_t)((((pb * 2 + i) * 2 + j) * 2) * 2);
+              out[((row + 0 * 2 + kh) * cout_pad + co) * 8 + e] = h;
+              out[((row + 1 * 2 + kh) * cout_pad + co) * 8 + e] = (_Float16)(x - (float)h);
+            }
+    }
+  return (float)std::ldexp(1.0, -ex);
+}
+
 // split-f16 packing of the 3-channel first conv for the fused encoder head (conv3x3_f16.hip, enc_head_kernel):
 // K = 64 in 8-half slots, slot s = 4 kb + kq -> image row dy = s >> 1, pixels 2 (s & 1) + {0, 1}, channels RGB0;
 // layout [kb][hi/lo][kq][16 couts] x 8 halfs.  in3: the fp32 packing [tap][4][16] (conv0 already folded).  Returns 2^-e.
@@ -492,6 +529,7 @@ int decode_impl(wct_ctx* ctx, int level, const float* feat, int h, int w, const 
     const auto& l = m.layers[i];
     const bool last = i + 1 == n;
     ConvDesc d = (i == 0 && first) ? *first : l.d;
+    if (!ctx->upconv) d.wup16 = nullptr;     // nine-tap form behind the upsamples
     if (i > 0 && m.layers[i - 1].up_after) { ch *= 2; cw *= 2; }
     if (cur_sp) d.flags |= CONV_IN_SP16;
     if (ctx->conv_mode == 1 && ctx->fuse && i + 2 == n && conv_fusable_tail(d, m.layers[i + 1].d)) {
@@ -805,6 +843,7 @@ int wct_debug_set(wct_ctx* ctx, const char* key, double value) {
   else if (!strcmp(key, "sp")) ctx->sp = v;
   else if (!strcmp(key, "l1fuse")) ctx->l1fuse = v;
   else if (!strcmp(key, "u8fuse")) ctx->u8fuse = v;
+  else if (!strcmp(key, "upconv")) ctx->upconv = v;
   else if (!strcmp(key, "side_priority")) {
     // priority of the style-side stream relative to the default: 0 = default, 1 = lowest (style kernels only fill the
     // content cascade's gaps), -1 = highest
@@ -817,7 +856,7 @@ int wct_debug_set(wct_ctx* ctx, const char* key, double value) {
     ctx->side.stream = ns;
     return WCT_OK;
   }
-  else return fail(ctx, WCT_ERR_INVALID, "debug_set: unknown key '%s' (fuse, sp, l1fuse, u8fuse, side_priority)", key);
+  else return fail(ctx, WCT_ERR_INVALID, "debug_set: unknown key '%s' (fuse, sp, l1fuse, u8fuse, upconv, side_priority)", key);
   HIPCHK(ctx, hipStreamSynchronize(ctx->side.stream));
   return WCT_OK;
 }
@@ -885,6 +924,13 @@ int wct_load_module(wct_ctx* ctx, int kind, int level, int n_layers, const wct_l
       HIPCHK(ctx, hipMalloc(&ld.wpk16, w16.size() * sizeof(_Float16)));
       HIPCHK(ctx, hipMemcpy(ld.wpk16, w16.data(), w16.size() * sizeof(_Float16), hipMemcpyHostToDevice));
       ld.d.wpk16 = ld.wpk16;
+      if ((ld.d.flags & CONV_UP_IN) && ld.d.cout_pad >= 32 && (L.cin % 16) == 0 && !out3 && !L.pool_after) {   // ... for the DMA kernel
+        std::vector<_Float16> wup;
+        ld.d.inv_scale_up = pack_up_sp_f16(L.weight, L.cout, L.cin, ld.d.cout_pad, wup);
+        HIPCHK(ctx, hipMalloc(&ld.wup16, wup.size() * sizeof(_Float16)));
+        HIPCHK(ctx, hipMemcpy(ld.wup16, wup.data(), wup.size() * sizeof(_Float16), hipMemcpyHostToDevice));
+        ld.d.wup16 = ld.wup16;
+      }
       if ((ld.d.flags & CONV_UP_IN) && L.cin == 16 && L.cout == 16) {   // per-parity 2x2 form for the fused tail's first conv
         std::vector<_Float16> wup;
         ld.d.inv_scale_up = pack_up_phase_f16(L.weight, L.cout, L.cin, wup);

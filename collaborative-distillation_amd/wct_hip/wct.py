@@ -511,7 +511,7 @@ class WCT:
         self._chk(self._lib.wct_set_conv_mode(self._ctx, {"fp32": 0, "f16x3": 1}[mode]))
 
     def debug_set(self, key: str, value) -> None:
-        """Experiment switches of the context ("fuse", "sp", "l1fuse", "u8fuse"): kernel formulations of the same operators."""
+        """Experiment switches of the context ("fuse", "sp", "l1fuse", "u8fuse", "upconv"): kernel formulations of the same operators."""
         self._chk(self._lib.wct_debug_set(self._ctx, key.encode(), float(value)))
 
     def set_overlap(self, on: bool):

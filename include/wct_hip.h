@@ -79,7 +79,7 @@ int wct_sync(wct_ctx* ctx);
  * mode 0 (exact fp32 MFMA) has no such limit. */
 int wct_saturation_count(wct_ctx* ctx, int reset, unsigned long long* count);
 
-/* Context-level experiment switches (tests, A/B measurements): key in {"fuse", "sp", "l1fuse", "u8fuse"}, value 0 / 1.  They select
+/* Context-level experiment switches (tests, A/B measurements): key in {"fuse", "sp", "l1fuse", "u8fuse", "upconv"}, value 0 / 1.  They select
  * between kernel formulations of the same operators (fused full-resolution ends, SP16 intermediates, level 1 without
  * relu1_1 in HBM); results agree to fp32 round-off or bitwise (tests/test_hip_parity.py).  Environment variables WCT_*
  * are honoured only when WCT_DEBUG is set. */

@@ -218,13 +218,45 @@ def test_sp16_dma_path_bitwise_equals_fp32_activations(torch_cuda, weights16x):
     for sp in ("1", "0"):
         w = WCT(types.SimpleNamespace(mode="16x", alpha=1.0), weights=weights16x)
         w.debug_set("sp", int(sp))
+        w.debug_set("upconv", 0)     # the nine-tap form behind the upsamples on both sides (the 2x2 form exists only for SP16 input)
         r = [w.e5(c).clone(), w.e4(c).clone(), w.e3(c).clone(), w.e2(c).clone(), w.d5(f5).clone(), w.d3(f3).clone()]
         w2 = WCT(types.SimpleNamespace(mode="original", alpha=1.0), weights=wo)
         w2.debug_set("sp", int(sp))
+        w2.debug_set("upconv", 0)
         r += [w2.e4(co).clone(), w2.d4(w2.e4(co)).clone()]
         res[sp] = r
     for a, b in zip(res["1"], res["0"]):
         assert a.shape == b.shape and torch.equal(a, b)
+
+
+def test_upsample_layers_on_the_low_resolution_grid(torch_cuda, weights16x, oracle):
+    """Decoder layers behind a nearest-x2 upsample run as per-parity 2x2 convolutions of the low-resolution map with summed taps
+    (dec_tail_up_kernel, conv3x3_sp_up_kernel; debug_set("upconv", 0) = the nine-tap form on the gathered upsampled halo): the same
+    operator, 4/9 of the products -- fp32 round-off agreement on odd sizes (clamped borders = reflect padding of the upsampled map,
+    partial tiles, leftover columns of the parity groups) in both modes, and against the CPU checker."""
+    from wct_hip import WCT
+    torch = torch_cuda
+    g = torch.Generator(device="cuda").manual_seed(41)
+    feats = {5: [(128, 2, 2), (128, 7, 11), (128, 33, 50)], 4: [(128, 9, 5), (128, 40, 66)], 3: [(64, 17, 130), (64, 68, 49)], 2: [(32, 3, 3), (32, 133, 77)]}
+    on = WCT(types.SimpleNamespace(mode="16x", alpha=1.0), weights=weights16x)
+    off = WCT(types.SimpleNamespace(mode="16x", alpha=1.0), weights=weights16x)
+    off.debug_set("upconv", 0)
+    mods = oracle.Modules("16x", weights16x)
+    for L, shapes in feats.items():
+        for shp in shapes:
+            f = torch.rand((1,) + shp, device="cuda", generator=g)
+            a, b = getattr(on, "d%d" % L)(f).clone(), getattr(off, "d%d" % L)(f).clone()
+            assert a.shape == b.shape and float((a - b).abs().max() / b.abs().max()) < 3e-6, (L, shp)
+            if shp[1] * shp[2] <= 2000:
+                ref = mods.decode(L, f[0].cpu().numpy())
+                assert rel_err(a[0].cpu().numpy(), ref) < 2e-5, (L, shp)
+    wo = model_zoo.synth_weights("original", 7)
+    on2 = WCT(types.SimpleNamespace(mode="original", alpha=1.0), weights=wo)
+    off2 = WCT(types.SimpleNamespace(mode="original", alpha=1.0), weights=wo)
+    off2.debug_set("upconv", 0)
+    f = torch.rand((1, 512, 9, 13), device="cuda", generator=g)
+    a, b = on2.d4(f).clone(), off2.d4(f).clone()
+    assert float((a - b).abs().max() / b.abs().max()) < 5e-6
 
 
 def test_level1_fused_matches_layerwise(torch_cuda, weights16x):

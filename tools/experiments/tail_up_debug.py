@@ -1,4 +1,4 @@
-"""dec_tail_up vs dec_tail (WCT_TAIL_UP=0) on one decoder: where do they differ?  python tools/experiments/tail_up_debug.py"""
+"""Decoders with the upsample layers on the low-resolution grid vs the nine-tap form (WCT_TAIL_UP=0 WCT_SP_UP=0): where do they differ?  python tools/experiments/tail_up_debug.py"""
 import os, subprocess, sys, types
 REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 if len(sys.argv) > 2 and sys.argv[1] == "--run":
@@ -12,10 +12,13 @@ if len(sys.argv) > 2 and sys.argv[1] == "--run":
     for (h, wd) in ((24, 40), (64, 96), (540, 960)):
         f = torch.rand((1, 32, h, wd), device="cuda", generator=g)
         outs.append(wct.d2(f).cpu().numpy())
+    for (h, wd) in ((7, 11), (33, 50), (135, 240)):
+        f = torch.rand((1, 128, h, wd), device="cuda", generator=g)
+        outs.append(wct.d5(f).cpu().numpy())
     np.savez(sys.argv[2], *outs)
 else:
     import numpy as np
-    for tag, extra in (("a", {}), ("b", {"WCT_TAIL_UP": "0"})):
+    for tag, extra in (("a", {}), ("b", {"WCT_TAIL_UP": "0", "WCT_SP_UP": "0"})):
         subprocess.check_call([sys.executable, __file__, "--run", "/tmp/tu_%s.npz" % tag], env=dict(os.environ, WCT_DEBUG="1", **extra))
     a, b = np.load("/tmp/tu_a.npz"), np.load("/tmp/tu_b.npz")
     for k in a.files:
