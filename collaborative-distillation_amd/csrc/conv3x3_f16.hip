@@ -365,7 +365,7 @@ __global__ __launch_bounds__(256) void conv3x3_f16_c16_kernel(F16Args a) {
 // model_cd.py:291-293) run at full image resolution with only 16 channels: unfused they move 156 B per pixel
 // (the 64 B/px intermediate written and read back), fused 28 B per pixel.  The intermediate lives only in LDS,
 // already split into f16 hi/lo planes.  The tail's conv12 has the arithmetic and summation order of the unfused kernel; its
-// final 16 -> 3 conv runs phase-packed (conv_f16_dev.h c3_phase_compute: another summation order, fp32 round-off agreement
+// final 16 -> 3 conv runs block-packed (conv_f16_dev.h c3_block_compute: another summation order, fp32 round-off agreement
 // with the two layers run separately); the head's conv11 is f16x3 here and exact-fp32 MFMA unfused (3e-6).
 // The intermediate's own reflect padding: a halo pixel OUTSIDE the image must hold the intermediate value of its
 // mirror pixel (not the first conv evaluated outside the image), so every halo pixel is evaluated at its reflected
@@ -576,7 +576,7 @@ __global__ __launch_bounds__(32 * TH, HeadGeo<TH>::PER_CU) void enc_head_kernel(
 struct TailArgs {   // conv12 (16->16 on the nearest-x2 upsampled input) + ReLU -> conv11 (16->3) + ReLU -> planar image
   const float* in; float* out;
   const u32x4* w12; const float* b12; float inv12; const float* inv12_ptr;
-  const u32x4* w11; const float* b11; float inv11;   // w11: phase-packed (c3_phase_compute), PH_WSLOTS slots
+  const u32x4* w11; const float* b11; float inv11;   // w11: block-packed (c3_block_compute), PH_WSLOTS slots
   int H, W, inW, up_in, tiles_x, tiles_y;
   int in_sp;
   unsigned* sat;
@@ -654,7 +654,7 @@ __global__ __launch_bounds__(32 * TH, TH == 8 ? 2 : 1) void dec_tail_kernel(Tail
   constexpr int NT = G::NT, NWV = G::NWV, NPH = G::NPH, NG = G::NG, NPI = G::NPI, NPX = G::NPX, SL = G::SL;
   u32x4* act0 = reinterpret_cast<u32x4*>(smem);   // [4][NPI]  input of conv12 (two halo rings)
   u32x4* wg12 = act0 + 4 * NPI;                   // [640]
-  u32x4* wg11 = wg12 + 640;                       // [PH_WSLOTS]  phase-packed 16 -> 3 weights
+  u32x4* wg11 = wg12 + 640;                       // [PH_WSLOTS]  block-packed 16 -> 3 weights
   u32x4* act1 = wg11 + PH_WSLOTS;                 // [4][NPX]  conv12 output on the 34 x (TH + 2) halo, pair-major slots (ph_slot)
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, kq = lane >> 4, kh = kq & 1, ts = kq >> 1;
@@ -751,26 +751,12 @@ __global__ __launch_bounds__(32 * TH, TH == 8 ? 2 : 1) void dec_tail_kernel(Tail
       }
     }
     __syncthreads();
-    // ---- conv11 (16 -> 3) + ReLU -> planar output, phase-packed (conv_f16_dev.h): lanes kq in {0, 2} hold pixel 2 li + (kq >> 1)
-    f32x4 acc[2][2];
+    // ---- conv11 (16 -> 3) + ReLU -> planar output, block-packed (conv_f16_dev.h): lane (li, kq) holds pixel (2 wave + (kq >> 1), 2 li + (kq & 1))
+    f32x4 acc[4];
 #pragma unroll
-    for (int r = 0; r < 2; ++r)
-#pragma unroll
-      for (int h = 0; h < 2; ++h) acc[r][h] = f32x4{0.f, 0.f, 0.f, 0.f};
-    c3_phase_compute<NPX>(act1, wg11, wave, li, kq, acc);
-    if (!(kq & 1)) {
-      const int gx = tx0 + 2 * li + (kq >> 1);
-#pragma unroll
-      for (int r2 = 0; r2 < 2; ++r2) {
-        const int gy = ty0 + wave * 2 + r2;
-        if (gy < a.H && gx < a.W) {
-          const size_t off = (size_t)gy * a.W + gx;
-          a.out[off] = fmaxf((acc[r2][0][0] + acc[r2][1][0]) * a.inv11 + bias11[0], 0.f);
-          a.out[plane + off] = fmaxf((acc[r2][0][1] + acc[r2][1][1]) * a.inv11 + bias11[1], 0.f);
-          a.out[2 * plane + off] = fmaxf((acc[r2][0][2] + acc[r2][1][2]) * a.inv11 + bias11[2], 0.f);
-        }
-      }
-    }
+    for (int c = 0; c < 4; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    c3_block_compute<NPX>(act1, wg11, wave, li, kq, acc);
+    c3_block_store(acc, a.inv11, bias11, a.out, plane, ty0, tx0, wave, li, kq, a.H, a.W);
     if (vn < ntiles) tail_commit<TH>(tr, act0, tid, a.in_sp, sat);   // conv12 of this tile is behind the barrier above
   }
   sat.commit(a.sat);
@@ -795,7 +781,7 @@ struct TailUpGeo {
   static constexpr int NPX = (HROWS * PH_W + 15) / 16 * 16;
   static_assert(NWV % 4 == 0 && NROWG % 4 == 0 && 2 * LW * LH <= NT, "phase-uniform waves; one (pixel, channel half) slot per thread");
   static_assert(HROWS / 2 <= 16, "a leftover column's rows of one parity fit one 16-pixel group (32 x 32 tiles were measured with two more groups' worth missing: -7 %, not pursued)");
-  static constexpr size_t lds = ((size_t)4 * NPL + PH_WSLOTS + (size_t)4 * NPX) * 16;           // 89.1 / 62.5 / 43.0 KB
+  static constexpr size_t lds = ((size_t)4 * NPL + PH_WSLOTS + (size_t)4 * NPX) * 16;           // 93.2 / 66.6 / 47.1 KB
 };
 
 template <int TH>
@@ -804,7 +790,7 @@ __global__ __launch_bounds__(32 * TH, TH == 8 ? 2 : 1) void dec_tail_up_kernel(T
   using G = TailUpGeo<TH>;
   constexpr int NT = G::NT, NWV = G::NWV, NG = G::NG, NPL = G::NPL, NPX = G::NPX, LW = G::LW, LH = G::LH;
   u32x4* act0 = reinterpret_cast<u32x4*>(smem);   // [4][NPL]  low-resolution input window, planes (hl, channel half)
-  u32x4* wg11 = act0 + 4 * NPL;                   // [PH_WSLOTS]  phase-packed 16 -> 3 weights
+  u32x4* wg11 = act0 + 4 * NPL;                   // [PH_WSLOTS]  block-packed 16 -> 3 weights
   u32x4* act1 = wg11 + PH_WSLOTS;                 // [4][NPX]  conv12 output on the 34 x (TH + 2) halo, pair-major slots (ph_slot)
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, kq = lane >> 4, kh = kq & 1, ts = kq >> 1;
@@ -922,26 +908,12 @@ __global__ __launch_bounds__(32 * TH, TH == 8 ? 2 : 1) void dec_tail_up_kernel(T
       }
     }
     __syncthreads();
-    // ---- conv11 (16 -> 3) + ReLU -> planar output, phase-packed (conv_f16_dev.h): lanes kq in {0, 2} hold pixel 2 li + (kq >> 1)
-    f32x4 acc[2][2];
+    // ---- conv11 (16 -> 3) + ReLU -> planar output, block-packed (conv_f16_dev.h): lane (li, kq) holds pixel (2 wave + (kq >> 1), 2 li + (kq & 1))
+    f32x4 acc[4];
 #pragma unroll
-    for (int r = 0; r < 2; ++r)
-#pragma unroll
-      for (int h = 0; h < 2; ++h) acc[r][h] = f32x4{0.f, 0.f, 0.f, 0.f};
-    c3_phase_compute<NPX>(act1, wg11, wave, li, kq, acc);
-    if (!(kq & 1)) {
-      const int gx = tx0 + 2 * li + (kq >> 1);
-#pragma unroll
-      for (int r2 = 0; r2 < 2; ++r2) {
-        const int gy = ty0 + wave * 2 + r2;
-        if (gy < a.H && gx < a.W) {
-          const size_t off = (size_t)gy * a.W + gx;
-          a.out[off] = fmaxf((acc[r2][0][0] + acc[r2][1][0]) * a.inv11 + bias11[0], 0.f);
-          a.out[plane + off] = fmaxf((acc[r2][0][1] + acc[r2][1][1]) * a.inv11 + bias11[1], 0.f);
-          a.out[2 * plane + off] = fmaxf((acc[r2][0][2] + acc[r2][1][2]) * a.inv11 + bias11[2], 0.f);
-        }
-      }
-    }
+    for (int c = 0; c < 4; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    c3_block_compute<NPX>(act1, wg11, wave, li, kq, acc);
+    c3_block_store(acc, a.inv11, bias11, a.out, plane, ty0, tx0, wave, li, kq, a.H, a.W);
     if (vn < ntiles) commit();   // conv12 of this tile is behind the barrier above
   }
   sat.commit(a.sat);
@@ -998,7 +970,7 @@ __global__ void split_pack_kernel(const float* wpk32, int chunks, int cout_pad, 
   out[e] = __builtin_bit_cast(u32x4, v);
 }
 
-// the phase-packed form (conv_f16_dev.h c3_phase_compute) of a cout_pad-16 layer with 3 real couts, same scale as above
+// the block-packed form (conv_f16_dev.h c3_block_compute) of a cout_pad-16 layer with 3 real couts, same scale as above
 __global__ void split_pack_phase_kernel(const float* wpk32, int chunks, const unsigned* maxbits, u32x4* out) {
   const float mx = __uint_as_float(*maxbits);
   int ex = 0;
@@ -1011,14 +983,15 @@ __global__ void split_pack_phase_kernel(const float* wpk32, int chunks, const un
   const int m = (int)(t & 15); t >>= 4;
   const int kq = (int)(t & 3); t >>= 2;
   const int hl = (int)(t & 1); t >>= 1;
-  const int ks = (int)(t % 6);
-  const int chunk = (int)(t / 6);
-  const int phase = m >> 3, co = m & 7, dy = ks >> 1, dxr = 2 * (ks & 1) + (kq >> 1) - phase;
+  const int ks = (int)(t & 7);
+  const int chunk = (int)(t >> 3);
+  // block-packed layout (conv_f16_dev.h c3_block_compute): m = 4 (2 py + px) + cout, window row ks >> 1, column 2 (ks & 1) + (kq >> 1)
+  const int co = m & 3, py = m >> 3, px = (m >> 2) & 1, dy = (ks >> 1) - py, dxr = 2 * (ks & 1) + (kq >> 1) - px;
   f16x8 v;
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     float x = 0.f;
-    if (co < 3 && dxr >= 0 && dxr <= 2) {
+    if (co < 3 && dy >= 0 && dy <= 2 && dxr >= 0 && dxr <= 2) {
       const int ci = (kq & 1) * 8 + j, tap = dy * 3 + dxr;   // fp32 layout [chunk][tap][kq = ci / 4][cout_pad = 16][ci % 4]
       x = wpk32[((((size_t)chunk * 9 + tap) * 4 + (ci >> 2)) * 16 + co) * 4 + (ci & 3)] * scale;
     }
@@ -1107,7 +1080,7 @@ hipError_t launch_dec_tail(const ConvDesc& d0, const ConvDesc& d1, const float* 
   auto go = [&](auto kern, auto geo, int per_cu) -> hipError_t {
     using G = decltype(geo);
     a.tiles_y = (H + G::HROWS - 3) / (G::HROWS - 2);
-    const size_t lds = ((size_t)4 * G::NPI + 640 + PH_WSLOTS + (size_t)4 * G::NPX) * 16;   // 73.7 KB (TH = 8: 2 per CU) / 110.6 KB (16) / 147.5 KB (24)
+    const size_t lds = ((size_t)4 * G::NPI + 640 + PH_WSLOTS + (size_t)4 * G::NPX) * 16;   // 77.8 KB (TH = 8: 2 per CU) / 114.7 KB (16) / 151.6 KB (24)
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     const int ntiles = a.tiles_x * a.tiles_y, grid = ntiles < per_cu * num_cus() ? ntiles : per_cu * num_cus();

@@ -296,43 +296,50 @@ __device__ __forceinline__ void c16_compute(const u32x4* act, const u32x4* wgt, 
   }
 }
 
-// ---- "phase-packed" 16 -> 3 convolution: the LAST decoder conv inside the fused tails (dec_tail_kernel, l1_decode_kernel).
-// With 3 real couts the 16-row M dimension of a 16x16x32 MFMA is 81 % padding.  Here one N column is a PAIR of horizontally
-// adjacent output pixels and M = 8 * phase + cout (phase = which pixel of the pair).  K walks the 3 x 4 input window the pair
-// shares -- 3 rows x 4 columns x 16 channels = 192 = 6 K-steps of (2 columns x 16 channels); a weight is zero where the column
-// lies outside a phase's own three taps -- so the wave's 2 rows x 32 pixels cost 6 x 3 x 2 = 36 MFMAs instead of 60, and 36
-// operand reads instead of 50.
-//   act planes: [hl][kh][PH_NPX] 16-byte slots, slot(py, px) = py * PH_W + (px & 1) * 17 + (px >> 1) over the 34 x 10 halo: the
-//               16 pairs of a row segment at a fixed column offset are 16 CONSECUTIVE slots (conflict-free ds_read_b128)
-//   wgt:        [6 ks][hl][kq][16 m] x 16 B;  K-step ks: row dy = ks >> 1, columns dx' = 2 (ks & 1) + (kq >> 1), channels
-//               8 (kq & 1) .. + 7;  A[m = 8 phase + cout][.] = w[cout][ch][dy][dx' - phase] where 0 <= dx' - phase <= 2
-// Result: lanes with kq in {0, 2} hold pixel 2 li + (kq >> 1) of row r in acc[r][.], couts 0..2 in registers 0..2.
+// ---- "block-packed" 16 -> 3 convolution: the LAST decoder conv inside the fused tails (dec_tail kernels, l1_decode_kernel).
+// With 3 real couts the 16-row M dimension of a 16x16x32 MFMA is 81 % padding.  Here one N column is a 2 x 2 BLOCK of output
+// pixels and M = 4 * phase + cout (phase = 2 py + px: which pixel of the block; 12 of 16 rows carry results).  K walks the 4 x 4
+// input window the block shares -- 4 rows x 4 columns x 16 channels = 256 = 8 K-steps of (2 columns x 16 channels); a weight is
+// zero where a window position lies outside a phase's own 3 x 3 taps -- so the wave's 2 rows x 32 pixels (16 blocks) cost
+// 8 x 3 = 24 MFMAs and 16 operand reads: 60 / 50 with one pixel per column, 36 / 36 with pixel PAIRS (round 2's first form).
+//   act planes: [hl][kh][NPX] 16-byte slots, slot(py, px) = py * PH_W + (px & 1) * 17 + (px >> 1) over the 34 x (TH + 2) halo: the
+//               16 blocks of a row segment at a fixed window column are 16 CONSECUTIVE slots (conflict-free ds_read_b128)
+//   wgt:        [8 ks][hl][kq][16 m] x 16 B;  K-step ks: window row wy = ks >> 1, column wx = 2 (ks & 1) + (kq >> 1), channels
+//               8 (kq & 1) .. + 7;  A[m = 4 (2 py + px) + cout][.] = w[cout][ch][wy - py][wx - px] where both offsets are in 0..2
+// Result: lane (li, kq) holds the output pixel (row 2 wave + (kq >> 1), column 2 li + (kq & 1)) of the tile, couts 0..2 in
+// registers 0..2 of acc[0] + acc[1] + acc[2] + acc[3] (four independent chains) -- every lane has a pixel to store.
 constexpr int PH_W = 36, PH_NPX = ((8 + 2) * PH_W + 15) / 16 * 16;   // 368 slots per plane (5888 B == 0 mod 256)
-constexpr int PH_WSLOTS = 6 * 2 * 4 * 16;                             // 768 weight slots per 16-channel chunk
+constexpr int PH_WSLOTS = 8 * 2 * 4 * 16;                             // 1024 weight slots per 16-channel chunk
 __host__ __device__ inline int ph_slot(int py, int px) { return py * PH_W + (px & 1) * 17 + (px >> 1); }
 
 template <int NPX = PH_NPX>   // slots per plane: PH_NPX for the 34 x 10 halo of a 32 x 8 tile
-__device__ __forceinline__ void c3_phase_compute(const u32x4* act, const u32x4* wgt, int wave, int li, int kq, f32x4 (&acc)[2][2]) {
+__device__ __forceinline__ void c3_block_compute(const u32x4* act, const u32x4* wgt, int wave, int li, int kq, f32x4 (&acc)[4]) {
   const int kh = kq & 1, p = kq >> 1;
-  const u32x4* ah_ = act + (0 * 2 + kh) * NPX + p * 17 + li;   // per-lane part of the slot: column parity plane + pair index
+  const u32x4* ah_ = act + (0 * 2 + kh) * NPX + p * 17 + li;   // per-lane part of the slot: column parity plane + block index
   const u32x4* al_ = act + (1 * 2 + kh) * NPX + p * 17 + li;
 #pragma unroll
-  for (int ks = 0; ks < 6; ++ks) {
-    const int dy = ks >> 1, c1 = ks & 1;          // dx' = 2 c1 + p: parity p, half index c1
+  for (int ks = 0; ks < 8; ++ks) {
+    const int wy = ks >> 1, c1 = ks & 1;          // window column 2 c1 + p
     const f16x8 wh = __builtin_bit_cast(f16x8, wgt[((ks * 2 + 0) * 4 + kq) * 16 + li]);
     const f16x8 wl = __builtin_bit_cast(f16x8, wgt[((ks * 2 + 1) * 4 + kq) * 16 + li]);
-    f16x8 bh[2], bl[2];
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-      const int off = (wave * 2 + r + dy) * PH_W + c1;
-      bh[r] = __builtin_bit_cast(f16x8, ah_[off]);
-      bl[r] = __builtin_bit_cast(f16x8, al_[off]);
-    }
-#pragma unroll
-    for (int term = 0; term < 3; ++term)      // four independent accumulator chains: (row, K-step parity)
-#pragma unroll
-      for (int r = 0; r < 2; ++r)
-        acc[r][c1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(term == 2 ? wl : wh, term == 1 ? bl[r] : bh[r], acc[r][c1], 0, 0, 0);
+    const int off = (wave * 2 + wy) * PH_W + c1;
+    const f16x8 bh = __builtin_bit_cast(f16x8, ah_[off]);
+    const f16x8 bl = __builtin_bit_cast(f16x8, al_[off]);
+    acc[ks & 3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, bh, acc[ks & 3], 0, 0, 0);
+    acc[ks & 3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, bl, acc[ks & 3], 0, 0, 0);
+    acc[ks & 3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, bh, acc[ks & 3], 0, 0, 0);
+  }
+}
+
+// the lane's output pixel of a tile after c3_block_compute: scale, bias, ReLU, three planar stores
+__device__ __forceinline__ void c3_block_store(const f32x4 (&acc)[4], float inv, const f32x4& bias, float* out, size_t plane, int ty0,
+                                               int tx0, int wave, int li, int kq, int H, int W) {
+  const int gy = ty0 + wave * 2 + (kq >> 1), gx = tx0 + 2 * li + (kq & 1);
+  if (gy < H && gx < W) {
+    const size_t off = (size_t)gy * W + gx;
+    out[off] = fmaxf(((acc[0][0] + acc[1][0]) + (acc[2][0] + acc[3][0])) * inv + bias[0], 0.f);
+    out[plane + off] = fmaxf(((acc[0][1] + acc[1][1]) + (acc[2][1] + acc[3][1])) * inv + bias[1], 0.f);
+    out[2 * plane + off] = fmaxf(((acc[0][2] + acc[1][2]) + (acc[2][2] + acc[3][2])) * inv + bias[2], 0.f);
   }
 }
 

@@ -19,7 +19,7 @@ namespace {
 struct L1DecArgs {
   const float* img; float* out;
   L1Conv c;                                  // conv11 of the encoder (f16x3 slot layout, 2 cout tiles)
-  const u32x4* w2; const float* b2;          // folded decoder conv, phase-packed (c3_phase_compute): [2 chunks][PH_WSLOTS] x 16 B, bias [16]
+  const u32x4* w2; const float* b2;          // folded decoder conv, block-packed (c3_block_compute): [2 chunks][PH_WSLOTS] x 16 B, bias [16]
   const float* inv2_ptr; float inv2;
   int H, W, tiles_x, tiles_y;
   unsigned* sat;
@@ -93,11 +93,11 @@ template <int TH>
 struct L1DecGeo {
   static constexpr int NT = 32 * TH, NWV = TH / 2, HROWS = TH + 2, NPH = FHW * HROWS, NGRP = (NPH + 15) / 16, NG = (NGRP + NWV - 1) / NWV;
   static constexpr int NPI = I2W * (TH + 4), IMGE = NPI + 4, NPX = (HROWS * PH_W + 15) / 16 * 16;
-  static constexpr size_t lds = (size_t)2 * IMGE * 8 + ((size_t)2 * 4 * NPX + 2 * PH_WSLOTS) * 16;   // 78.6 KB / 120.2 KB
+  static constexpr size_t lds = (size_t)2 * IMGE * 8 + ((size_t)2 * 4 * NPX + 2 * PH_WSLOTS) * 16;   // 86.8 KB (TH = 8: one per CU) / 128.4 KB
 };
 
 template <int TH>
-__global__ __launch_bounds__(32 * TH, TH == 8 ? 2 : 1) void l1_decode_kernel(L1DecArgs a) {
+__global__ __launch_bounds__(32 * TH, 1) void l1_decode_kernel(L1DecArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using G = L1DecGeo<TH>;
   constexpr int NT = G::NT, NWV = G::NWV, NPH = G::NPH, NG = G::NG, NPI = G::NPI, NPX = G::NPX;
@@ -168,28 +168,13 @@ __global__ __launch_bounds__(32 * TH, TH == 8 ? 2 : 1) void l1_decode_kernel(L1D
       }
     }
     __syncthreads();
-    // ---- folded decoder conv on the two 16-channel chunks, phase-packed (conv_f16_dev.h): lanes kq in {0, 2} hold pixel
-    //      2 li + (kq >> 1) of the wave's two rows
-    f32x4 acc[2][2];
+    // ---- folded decoder conv on the two 16-channel chunks, block-packed (conv_f16_dev.h): every lane ends with one output pixel
+    f32x4 acc[4];
 #pragma unroll
-    for (int r = 0; r < 2; ++r)
-#pragma unroll
-      for (int h = 0; h < 2; ++h) acc[r][h] = f32x4{0.f, 0.f, 0.f, 0.f};
-    c3_phase_compute<NPX>(act, wgt, wave, li, kq, acc);
-    c3_phase_compute<NPX>(act + 4 * NPX, wgt + PH_WSLOTS, wave, li, kq, acc);
-    if (!(kq & 1)) {
-      const int gx = tx0 + 2 * li + (kq >> 1);
-#pragma unroll
-      for (int r2 = 0; r2 < 2; ++r2) {
-        const int gy = ty0 + wave * 2 + r2;
-        if (gy < a.H && gx < a.W) {
-          const size_t off = (size_t)gy * a.W + gx;
-          a.out[off] = fmaxf((acc[r2][0][0] + acc[r2][1][0]) * inv2 + bias2[0], 0.f);
-          a.out[plane + off] = fmaxf((acc[r2][0][1] + acc[r2][1][1]) * inv2 + bias2[1], 0.f);
-          a.out[2 * plane + off] = fmaxf((acc[r2][0][2] + acc[r2][1][2]) * inv2 + bias2[2], 0.f);
-        }
-      }
-    }
+    for (int c = 0; c < 4; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    c3_block_compute<NPX>(act, wgt, wave, li, kq, acc);
+    c3_block_compute<NPX>(act + 4 * NPX, wgt + PH_WSLOTS, wave, li, kq, acc);
+    c3_block_store(acc, inv2, bias2, a.out, plane, ty0, tx0, wave, li, kq, a.H, a.W);
     if (vn < ntiles) { head_pin(pxr); head_commit<TH>(pxr, imgH, imgL, tid, sat); }
   }
   sat.commit(a.sat);
@@ -237,5 +222,5 @@ hipError_t launch_l1_decode(const ConvDesc& e, const ConvDesc& dec0, const float
   };
   // 32 x 16 tiles (less halo recompute) once they still fill the chip; results do not depend on the tile shape
   const bool tall = th_env ? th_env == 16 : ((H + 15) / 16) * a.tiles_x >= 2 * num_cus();
-  return tall ? go(l1_decode_kernel<16>, L1DecGeo<16>{}, 16, 1) : go(l1_decode_kernel<8>, L1DecGeo<8>{}, 8, 2);
+  return tall ? go(l1_decode_kernel<16>, L1DecGeo<16>{}, 16, 1) : go(l1_decode_kernel<8>, L1DecGeo<8>{}, 8, 1);
 }

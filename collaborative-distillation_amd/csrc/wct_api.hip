@@ -29,7 +29,7 @@ struct LayerDev {
   float* bias = nullptr;
   void* wpk16 = nullptr;  // split-f16 weights (all but the 3-channel first conv)
   void* l1w16 = nullptr;  // 3-channel first conv with <= 32 couts: f16x3 slot packing for the level-1 kernels
-  void* wph16 = nullptr;  // last decoder conv (-> 3 couts): phase-packed split-f16 weights for the fused tails
+  void* wph16 = nullptr;  // last decoder conv (-> 3 couts): block-packed split-f16 weights for the fused tails
   void* wup16 = nullptr;  // 16 -> 16 conv behind an upsample: per-parity 2x2 weights (ConvDesc::wup16)
   float* l1bias = nullptr;
 };
@@ -279,9 +279,9 @@ float pack_weights_f16(const float* w, int cout, int cin, int cout_pad, int taps
   return std::ldexp(1.f, -ex);
 }
 
-// the same split (same scale) of a layer with 3 real couts in the phase-packed layout of conv_f16_dev.h c3_phase_compute:
-// [chunk][6 ks][hl][kq][16 m] x 8 halfs;  K-step ks: row dy = ks >> 1, column dx' = 2 (ks & 1) + (kq >> 1), channels 8 (kq & 1) + j;
-// A[m = 8 phase + cout] = w[cout][ch][dy][dx' - phase] where 0 <= dx' - phase <= 2, else 0
+// the same split (same scale) of a layer with 3 real couts in the block-packed layout of conv_f16_dev.h c3_block_compute:
+// [chunk][8 ks][hl][kq][16 m] x 8 halfs;  K-step ks: window row wy = ks >> 1, column wx = 2 (ks & 1) + (kq >> 1), channels 8 (kq & 1) + j;
+// A[m = 4 (2 py + px) + cout] = w[cout][ch][wy - py][wx - px] where both offsets are in 0..2, else 0
 void pack_out3_phase_f16(const float* w, int cout, int cin, std::vector<_Float16>& out) {
   float mx = 0.f;
   for (size_t i = 0; i < (size_t)cout * cin * 9; ++i) mx = std::max(mx, std::fabs(w[i]));
@@ -289,17 +289,18 @@ void pack_out3_phase_f16(const float* w, int cout, int cin, std::vector<_Float16
   if (mx > 0.f && std::isfinite(mx)) { (void)std::frexp(mx, &ex); ex = 9 - ex; }
   const float scale = std::ldexp(1.f, ex);
   const int chunks = (cin + 15) / 16;
-  out.assign((size_t)chunks * 6 * 2 * 4 * 16 * 8, (_Float16)0.f);
+  out.assign((size_t)chunks * 8 * 2 * 4 * 16 * 8, (_Float16)0.f);
   for (int chunk = 0; chunk < chunks; ++chunk)
-    for (int ks = 0; ks < 6; ++ks)
+    for (int ks = 0; ks < 8; ++ks)
       for (int kq = 0; kq < 4; ++kq)
         for (int m = 0; m < 16; ++m)
           for (int j = 0; j < 8; ++j) {
-            const int phase = m >> 3, co = m & 7, dy = ks >> 1, dxr = 2 * (ks & 1) + (kq >> 1) - phase, ch = chunk * 16 + (kq & 1) * 8 + j;
-            if (co >= cout || co >= 3 || ch >= cin || dxr < 0 || dxr > 2) continue;
+            const int co = m & 3, py = m >> 3, px = (m >> 2) & 1, dy = (ks >> 1) - py, dxr = 2 * (ks & 1) + (kq >> 1) - px;
+            const int ch = chunk * 16 + (kq & 1) * 8 + j;
+            if (co >= cout || co >= 3 || ch >= cin || dy < 0 || dy > 2 || dxr < 0 || dxr > 2) continue;
             const float x = w[((size_t)co * cin + ch) * 9 + dy * 3 + dxr] * scale;
             const _Float16 h = (_Float16)x;
-            const size_t base = ((size_t)chunk * 6 + ks) * 2;
+            const size_t base = ((size_t)chunk * 8 + ks) * 2;
             out[(((base + 0) * 4 + kq) * 16 + m) * 8 + j] = h;
             out[(((base + 1) * 4 + kq) * 16 + m) * 8 + j] = (_Float16)(x - (float)h);
           }
@@ -620,7 +621,7 @@ int fold_impl(wct_ctx* ctx, int level, const double* M, const double* b, ConvDes
   if (ctx->conv_mode == 1) {
     const int taps = l.d.cout_pad == 16 ? 10 : 9;
     const size_t b16 = conv_f16_weight_bytes(l.d.cin, l.d.cout_pad, taps);
-    // a single-conv decoder (level 1: 24 -> 3) is also needed phase-packed, for l1_decode_kernel
+    // a single-conv decoder (level 1: 24 -> 3) is also needed block-packed, for l1_decode_kernel
     const bool phase = (l.d.flags & CONV_OUT_NCHW3) && l.d.cout_pad == 16 && l.d.cout == 3;
     const size_t bph = phase ? conv_phase_weight_bytes(l.d.cin) : 0;
     if (int rc = ensure(ctx, ctx->foldW16, b16 + 64 + bph)) return rc;
@@ -938,7 +939,7 @@ int wct_load_module(wct_ctx* ctx, int kind, int level, int n_layers, const wct_l
         HIPCHK(ctx, hipMemcpy(ld.wup16, wup.data(), wup.size() * sizeof(_Float16), hipMemcpyHostToDevice));
         ld.d.wup16 = ld.wup16;
       }
-      if (out3 && ld.d.cout_pad == 16) {   // phase-packed form for the fused tails
+      if (out3 && ld.d.cout_pad == 16) {   // block-packed form for the fused tails
         std::vector<_Float16> wph;
         pack_out3_phase_f16(L.weight, L.cout, L.cin, wph);
         HIPCHK(ctx, hipMalloc(&ld.wph16, wph.size() * sizeof(_Float16)));

@@ -45,8 +45,8 @@ struct ConvDesc {
   const void* l1w16 = nullptr;
   const float* l1bias = nullptr;   // [32], zero padded
   float l1inv = 1.f;
-  // last decoder conv (16-channel chunks -> 3 couts): the same split-f16 weights (same scale) in the phase-packed layout of
-  // conv_f16_dev.h c3_phase_compute, [chunk][6 ks][hl][kq][16 m] x 16 B, for the fused tails
+  // last decoder conv (16-channel chunks -> 3 couts): the same split-f16 weights (same scale) in the block-packed layout of
+  // conv_f16_dev.h c3_block_compute, [chunk][8 ks][hl][kq][16 m] x 16 B, for the fused tails
   const void* wph16 = nullptr;
   // CONV_UP_IN layers with 16 -> 16 channels (the fused tail's first conv): the 3x3 convolution of a nearest-x2 upsampled map is,
   // per output parity (a, b), a 2x2 convolution of the LOW-RESOLUTION map with summed taps (conv3x3_f16.hip dec_tail_kernel) --
@@ -83,7 +83,7 @@ hipError_t launch_l1_moments(const ConvDesc& enc0, const float* img, int H, int 
 //   have_max: *maxbits_dev already holds max |w| (written by launch_fold_affine); otherwise it is computed here
 hipError_t launch_split_pack(const float* wpk32, int cin, int cout_pad, int taps, unsigned* maxbits_dev, void* out,
                              float* inv_scale_out, hipStream_t s, bool have_max = false);
-// the same weights (cout_pad 16, 3 real couts) in the phase-packed layout; *maxbits_dev must hold max |w| (same scale as above)
+// the same weights (cout_pad 16, 3 real couts) in the block-packed layout; *maxbits_dev must hold max |w| (same scale as above)
 size_t conv_phase_weight_bytes(int cin);
 hipError_t launch_split_pack_phase(const float* wpk32, int cin, const unsigned* maxbits_dev, void* out, hipStream_t s);
 

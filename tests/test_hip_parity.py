@@ -181,7 +181,7 @@ def test_unfused_reference_sequence_matches_fused(torch_cuda, wct16, golden):
 
 def test_fused_ends_match_unfused(torch_cuda, weights16x):
     """Fused ends vs the layer-by-layer path (odd sizes, image-border tiles).
-    Decoder tail (conv12+conv11): conv12 has the unfused kernel's arithmetic; the final 16 -> 3 conv runs phase-packed in the
+    Decoder tail (conv12+conv11): conv12 has the unfused kernel's arithmetic; the final 16 -> 3 conv runs block-packed in the
     fused kernel (pairs of pixels per MFMA column, another summation order) -> fp32 round-off agreement.
     Encoder head (conv11+conv12+pool): conv11 runs as f16x3 there and as exact-fp32 MFMA unfused -> fp32-class
     agreement (the tolerance is relative to max|y|, as in the golden tests)."""
