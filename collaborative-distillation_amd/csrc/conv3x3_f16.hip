@@ -372,7 +372,7 @@ __global__ __launch_bounds__(256) void conv3x3_f16_c16_kernel(F16Args a) {
 // image coordinate -- whose 3x3 input window is inside the staged tile -- and stored at the halo position.
 struct HeadArgs {   // conv11 (3->16, conv0 folded) + ReLU -> conv12 (16->16) + ReLU -> 2x2 max-pool, both f16x3
   const float* img; float* out;
-  const u32x4* w11; const float* b11; float inv11;   // [kb][hi/lo][kq][16 couts] x 8 halfs (K layout below)
+  const u32x4* w11; const float* b11; float inv11;   // [K-step][kq][16 couts] x 8 halfs (conv_f16_dev.h l1_conv_group's K layout)
   const u32x4* w12; const float* b12; float inv12;
   int H, W, tiles_x, tiles_y;
   int out_sp;
@@ -382,10 +382,10 @@ struct HeadArgs {   // conv11 (3->16, conv0 folded) + ReLU -> conv12 (16->16) + 
 
 // Persistent: a workgroup walks tiles v, v + grid, ...; the image window of the NEXT tile is fetched into registers
 // while the current tile is on the matrix cores and written to LDS behind conv12, conv12's weights are staged once.
-// conv11 as a 16x16x32 MFMA pair: the K = 27 (tap, channel) products are laid out as 8-half slots
-//   slot s = 4 kb + kq  ->  image row dy = s >> 1, pixels 2 (s & 1) + {0, 1}, 4 channels each (RGB0)
-// so that a lane's B operand is 16 contiguous bytes of the RGB0 f16 tile (ds_read2_b64); the 4th pixel / 4th channel /
-// 4th row slots carry zero weights.  (fp32 MFMA for this layer cost 9 x 32 issue cycles per 16 pixels, this 6 x 16.)
+// conv11 on 16x16x32 MFMAs: the 3 x 27 (split term, window position, channel) products are concatenated along K as 4-half
+// "singles" (one window pixel's RGB0, hi or lo plane) -- 27 of 32 singles = four K-steps, a lane's B operand two 8-byte LDS
+// reads at fixed per-lane offsets (conv_f16_dev.h l1_lane_offsets).  (fp32 MFMA for this layer cost 9 x 32 issue cycles per 16
+// pixels; the first f16x3 form -- the three terms kept apart, two half-empty K-steps each -- 6 x 16; this one 4 x 16.)
 #ifdef WCT_HEAD_TIMING   // tools/experiments/head_timing.sh: shader-clock cycles per phase, summed over wave 0 of every workgroup
 __device__ unsigned long long g_head_t[8];
 #define HT_STAMP(i) do { if (tid == 0) { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
@@ -420,22 +420,14 @@ __global__ __launch_bounds__(32 * TH, HeadGeo<TH>::PER_CU) void enc_head_kernel(
   const int ntiles = a.tiles_x * a.tiles_y;
   for (int e = tid; e < 40 * 16; e += NT) wgt[e] = a.w12[e];
   if (tid < 4) { imgH[NPI + tid] = u32x2{0u, 0u}; imgL[NPI + tid] = u32x2{0u, 0u}; }
-  f16x8 a11[2][2];
+  f16x8 a11[4];      // the four K-steps of conv11 (conv_f16_dev.h: 27 (term, window position) singles concatenated along K)
 #pragma unroll
-  for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-    for (int hl = 0; hl < 2; ++hl) a11[kb][hl] = __builtin_bit_cast(f16x8, a.w11[((kb * 2 + hl) * 4 + kq) * 16 + li]);
+  for (int s = 0; s < 4; ++s) a11[s] = __builtin_bit_cast(f16x8, a.w11[(s * 4 + kq) * 16 + li]);
   const f32x4 bias11 = *reinterpret_cast<const f32x4*>(a.b11 + 4 * kq);
   const f32x4 bias12 = *reinterpret_cast<const f32x4*>(a.b12 + 4 * kq);
   const int Hp = a.H >> 1, Wp = a.W >> 1;
-  // B-operand slot of this lane in the two K blocks
-  int srow[2], scol[2];
-#pragma unroll
-  for (int kb = 0; kb < 2; ++kb) {
-    const int s = kb * 4 + kq;
-    srow[kb] = (s >> 1) > 2 ? 2 : (s >> 1);
-    scol[kb] = 2 * (s & 1);
-  }
+  int boff[4][2];    // this lane's two B-operand singles per K-step: window position + plane, relative to the window's top-left
+  l1_lane_offsets(kq, IMGE, boff);
 
   int soff[2];
 #pragma unroll
@@ -490,7 +482,7 @@ __global__ __launch_bounds__(32 * TH, HeadGeo<TH>::PER_CU) void enc_head_kernel(
 #pragma unroll
     for (int i = 0; i < NG; i += 3) {
       f32x4 acc[3];
-      f16x8 bhs[3][2], bls[3][2];
+      f16x8 bs[3][4];
 #pragma unroll
       for (int u = 0; u < 3; ++u) {
         if (i + u >= NG) continue;
@@ -503,20 +495,16 @@ __global__ __launch_bounds__(32 * TH, HeadGeo<TH>::PER_CU) void enc_head_kernel(
         }
         acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-          const int e0 = base + srow[kb] * I2W + scol[kb];
-          const u32x2 h0 = imgH[e0], h1 = imgH[e0 + 1], l0 = imgL[e0], l1 = imgL[e0 + 1];
-          bhs[u][kb] = __builtin_bit_cast(f16x8, u32x4{h0[0], h0[1], h1[0], h1[1]});
-          bls[u][kb] = __builtin_bit_cast(f16x8, u32x4{l0[0], l0[1], l1[0], l1[1]});
+        for (int s = 0; s < 4; ++s) {
+          const u32x2 r0 = imgH[base + boff[s][0]], r1 = imgH[base + boff[s][1]];
+          bs[u][s] = __builtin_bit_cast(f16x8, u32x4{r0[0], r0[1], r1[0], r1[1]});
         }
       }
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
+      for (int s = 0; s < 4; ++s)
 #pragma unroll
-        for (int term = 0; term < 3; ++term)
-#pragma unroll
-          for (int u = 0; u < 3; ++u)
-            if (i + u < NG) acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a11[kb][term == 2], term == 1 ? bls[u][kb] : bhs[u][kb], acc[u], 0, 0, 0);
+        for (int u = 0; u < 3; ++u)
+          if (i + u < NG) acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a11[s], bs[u][s], acc[u], 0, 0, 0);
 #pragma unroll
       for (int u = 0; u < 3; ++u) {
         if (i + u >= NG) continue;

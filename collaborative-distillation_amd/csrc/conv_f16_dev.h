@@ -343,21 +343,34 @@ __device__ __forceinline__ void c3_block_store(const f32x4 (&acc)[4], float inv,
   }
 }
 
-// ---- conv11 of the level-1 / head encoders (3 channels in, <= 32 out) as f16x3 16x16x32 MFMA pairs.
-// K layout: 8-half slots, slot s = 4 kb + kq -> image row dy = s >> 1, pixels 2 (s & 1) + {0, 1}, channels RGB0; the 4th
-// pixel / 4th channel / 4th row slots carry zero weights.  Weights: [cout tile][kb][hi/lo][kq][16 couts] x 8 halfs.
+// ---- conv11 of the level-1 / head encoders (3 channels in, <= 32 out) as f16x3 on 16x16x32 MFMAs.
+// K layout: "singles" of 4 halfs = one window pixel's RGB0; the 27 singles t = 9 term + pos (term 0: w_hi x_hi, 1: w_hi x_lo,
+// 2: w_lo x_hi; pos = 3 dy + dx of the 3x3 window) are concatenated along K -- 27 of 32 singles = FOUR K-steps (the first form
+// kept the three terms apart, two half-empty K-steps each: six MFMAs).  Lane group kq of K-step s holds singles 8 s + 2 kq + {0, 1}:
+// two 8-byte LDS reads at per-lane offsets (window position, hi or lo plane), fixed for the kernel's lifetime.
+// Weights: [cout tile][s][kq][16 couts] x 8 halfs (wct_api.hip pack_head_f16).
 struct L1Conv { const u32x4* w; const float* b; float inv; };
-struct L1Weights { f16x8 a[2][2][2]; f32x4 bias[2]; float inv; };
+struct L1Weights { f16x8 a[2][4]; int off[4][2]; f32x4 bias[2]; float inv; };
 
-__device__ __forceinline__ void l1_load_weights(const L1Conv& c, int li, int kq, L1Weights& w) {
+// per-lane operand offsets (u32x2 units from the window's top-left pixel in the hi plane); lo_plane = imgL - imgH
+__device__ __forceinline__ void l1_lane_offsets(int kq, int lo_plane, int (&off)[4][2]) {
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int t = 8 * s + 2 * kq + u, term = t / 9, pos = t - term * 9;
+      off[s][u] = t < 27 ? (pos / 3) * I2W + pos % 3 + (term == 1 ? lo_plane : 0) : 0;   // singles 27..31 carry zero weights
+    }
+}
+
+__device__ __forceinline__ void l1_load_weights(const L1Conv& c, int li, int kq, int lo_plane, L1Weights& w) {
 #pragma unroll
   for (int ct = 0; ct < 2; ++ct) {
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int hl = 0; hl < 2; ++hl) w.a[ct][kb][hl] = __builtin_bit_cast(f16x8, c.w[(((ct * 2 + kb) * 2 + hl) * 4 + kq) * 16 + li]);
+    for (int s = 0; s < 4; ++s) w.a[ct][s] = __builtin_bit_cast(f16x8, c.w[((ct * 4 + s) * 4 + kq) * 16 + li]);
     w.bias[ct] = *reinterpret_cast<const f32x4*>(c.b + ct * 16 + 4 * kq);
   }
+  l1_lane_offsets(kq, lo_plane, w.off);
   w.inv = c.inv;
 }
 
@@ -365,19 +378,13 @@ __device__ __forceinline__ void l1_load_weights(const L1Conv& c, int li, int kq,
 // x 16 couts of tile ct:  result rows = couts ct * 16 + 4 kq + {0..3}
 // RELU = false: the pre-activation (the caller merges ReLU with the range clamp of its split: store_split4<true>)
 template <bool RELU = true>
-__device__ __forceinline__ f32x4 l1_conv_group(const u32x2* imgH, const u32x2* imgL, int base, int kq, const L1Weights& w, int ct) {
+__device__ __forceinline__ f32x4 l1_conv_group(const u32x2* imgH, int base, const L1Weights& w, int ct) {
   f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+  const u32x2* p = imgH + base;
 #pragma unroll
-  for (int kb = 0; kb < 2; ++kb) {
-    const int s = kb * 4 + kq;
-    const int row = (s >> 1) > 2 ? 2 : (s >> 1);
-    const int e0 = base + row * I2W + 2 * (s & 1);
-    const u32x2 h0 = imgH[e0], h1 = imgH[e0 + 1], l0 = imgL[e0], l1 = imgL[e0 + 1];
-    const f16x8 bh = __builtin_bit_cast(f16x8, u32x4{h0[0], h0[1], h1[0], h1[1]});
-    const f16x8 bl = __builtin_bit_cast(f16x8, u32x4{l0[0], l0[1], l1[0], l1[1]});
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w.a[ct][kb][0], bh, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w.a[ct][kb][0], bl, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w.a[ct][kb][1], bh, acc, 0, 0, 0);
+  for (int s = 0; s < 4; ++s) {
+    const u32x2 r0 = p[w.off[s][0]], r1 = p[w.off[s][1]];
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w.a[ct][s], __builtin_bit_cast(f16x8, u32x4{r0[0], r0[1], r1[0], r1[1]}), acc, 0, 0, 0);
   }
   f32x4 x;
 #pragma unroll

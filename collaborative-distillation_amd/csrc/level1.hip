@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256, 3) void l1_encode_kernel(L1EncArgs a) {
   const unsigned txm = tile_div_magic(a.tiles_x);   // once per workgroup; tile_rc() then stays on the scalar unit
   if (tid < 4) { imgH[NPI2 + tid] = u32x2{0u, 0u}; imgL[NPI2 + tid] = u32x2{0u, 0u}; }
   L1Weights w;
-  l1_load_weights(a.c, li, kq, w);
+  l1_load_weights(a.c, li, kq, IMG_E, w);
   int soff[2];
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256, 3) void l1_encode_kernel(L1EncArgs a) {
         const int gy = ty0 + py, gx = tx0 + px;
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) {
-          const f32x4 x = l1_conv_group(imgH, imgL, base, kq, w, ct);
+          const f32x4 x = l1_conv_group(imgH, base, w, ct);
           const int co = ct * 16 + 4 * kq;
           if (gy < a.H && gx < a.W && co < a.C) *reinterpret_cast<f32x4*>(a.out + ((size_t)gy * a.W + gx) * a.C + co) = x;
         }
@@ -112,7 +112,7 @@ __global__ __launch_bounds__(32 * TH, 1) void l1_decode_kernel(L1DecArgs a) {
   for (int e = tid; e < 2 * PH_WSLOTS; e += NT) wgt[e] = a.w2[e];
   if (tid < 4) { imgH[NPI + tid] = u32x2{0u, 0u}; imgL[NPI + tid] = u32x2{0u, 0u}; }
   L1Weights w;
-  l1_load_weights(a.c, li, kq, w);
+  l1_load_weights(a.c, li, kq, G::IMGE, w);
   const float inv2 = a.inv2_ptr ? *a.inv2_ptr : a.inv2;
   const f32x4 bias2 = *reinterpret_cast<const f32x4*>(a.b2);
   const size_t plane = (size_t)a.H * a.W;
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(32 * TH, 1) void l1_decode_kernel(L1DecArgs a) {
       }
 #pragma unroll
       for (int ct = 0; ct < 2; ++ct) {
-        const f32x4 x = l1_conv_group<false>(imgH, imgL, base, kq, w, ct);
+        const f32x4 x = l1_conv_group<false>(imgH, base, w, ct);
         if (gok[u]) store_split4<true>(act + ct * 4 * NPX, NPX, gslot[u], kq, x, sat);
       }
     }

@@ -224,7 +224,7 @@ __global__ __launch_bounds__(256, 2) void l1_moments_kernel(L1MomArgs a) {
   if (tid < 4) { imgH[NPI2 + tid] = u32x2{0u, 0u}; imgL[NPI2 + tid] = u32x2{0u, 0u}; }
   for (int e = tid; e < MP * a.Cs; e += 256) feat[e] = 0.f;   // columns >= 32 are never written
   L1Weights w;
-  l1_load_weights(a.c, li, kq, w);
+  l1_load_weights(a.c, li, kq, IMG_E, w);
   // the three tile pairs (0,0), (0,1), (1,1) of the 32 padded channels
   int offA[3] = {li, li, 16 + li}, offB[3] = {li, 16 + li, 16 + li};
   f64x4 acc[3];
@@ -265,7 +265,7 @@ __global__ __launch_bounds__(256, 2) void l1_moments_kernel(L1MomArgs a) {
         const bool in = gy < a.H && gx >= a.x0 && gx < xhi;
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) {
-          const f32x4 x = l1_conv_group(imgH, imgL, base, kq, w, ct);
+          const f32x4 x = l1_conv_group(imgH, base, w, ct);
           *reinterpret_cast<f32x4*>(feat + (py * 32 + px) * a.Cs + ct * 16 + 4 * kq) = in ? x : f32x4{0.f, 0.f, 0.f, 0.f};
         }
       }

@@ -385,29 +385,28 @@ float pack_up_sp_f16(const float* w, int cout, int cin, int cout_pad, std::vecto
   return (float)std::ldexp(1.0, -ex);
 }
 
-// split-f16 packing of the 3-channel first conv for the fused encoder head (conv3x3_f16.hip, enc_head_kernel):
-// K = 64 in 8-half slots, slot s = 4 kb + kq -> image row dy = s >> 1, pixels 2 (s & 1) + {0, 1}, channels RGB0;
-// layout [kb][hi/lo][kq][16 couts] x 8 halfs.  in3: the fp32 packing [tap][4][16] (conv0 already folded).  Returns 2^-e.
+// split-f16 packing of the 3-channel first conv for the fused encoder head (conv3x3_f16.hip enc_head_kernel) and the level-1
+// kernels (conv_f16_dev.h l1_conv_group): K = 4 steps of 32 halfs in "singles" of 4 (one window pixel's RGB0); single
+// t = 9 term + pos (term 0: w_hi . x_hi, 1: w_hi . x_lo, 2: w_lo . x_hi; pos = 3 dy + dx), t < 27, the rest zero; lane group kq of
+// step s holds singles 8 s + 2 kq + {0, 1}.  Layout [cout tile][s][kq][16 couts] x 8 halfs.  in3: the fp32 packing
+// [tap][4][cout_pad] (conv0 already folded).  Returns 2^-e.
 float pack_head_f16(const std::vector<float>& in3, int cout_pad, int ntile, std::vector<_Float16>& out) {
-  // in3: [tap][4][cout_pad]; out: [cout tile][kb][hi/lo][kq][16 couts] x 8 halfs (couts beyond cout_pad: zeros)
   float mx = 0.f;
   for (float x : in3) mx = std::max(mx, std::fabs(x));
   int ex = 0;
   if (mx > 0.f && std::isfinite(mx)) { (void)std::frexp(mx, &ex); ex = 9 - ex; }
   const float scale = std::ldexp(1.f, ex);
-  out.assign((size_t)ntile * 2 * 2 * 4 * 16 * 8, (_Float16)0.f);
+  out.assign((size_t)ntile * 4 * 4 * 16 * 8, (_Float16)0.f);
   for (int ct = 0; ct < ntile; ++ct)
-    for (int kb = 0; kb < 2; ++kb)
+    for (int s = 0; s < 4; ++s)
       for (int kq = 0; kq < 4; ++kq)
         for (int oo = 0; oo < 16; ++oo)
           for (int j = 0; j < 8; ++j) {
-            const int s = kb * 4 + kq, dy = s >> 1, px = 2 * (s & 1) + (j >> 2), ch = j & 3, o = ct * 16 + oo;
-            if (dy > 2 || px > 2 || ch > 2 || o >= cout_pad) continue;
-            const float x = in3[((size_t)(dy * 3 + px) * 4 + ch) * cout_pad + o] * scale;
+            const int t = 8 * s + 2 * kq + (j >> 2), term = t / 9, pos = t % 9, ch = j & 3, o = ct * 16 + oo;
+            if (t >= 27 || ch > 2 || o >= cout_pad) continue;
+            const float x = in3[((size_t)pos * 4 + ch) * cout_pad + o] * scale;
             const _Float16 h = (_Float16)x;
-            const size_t base = ((size_t)ct * 2 + kb) * 2;
-            out[(((base + 0) * 4 + kq) * 16 + oo) * 8 + j] = h;
-            out[(((base + 1) * 4 + kq) * 16 + oo) * 8 + j] = (_Float16)(x - (float)h);
+            out[((((size_t)ct * 4 + s) * 4 + kq) * 16 + oo) * 8 + j] = term == 2 ? (_Float16)(x - (float)h) : h;
           }
   return std::ldexp(1.f, -ex);
 }
