@@ -61,6 +61,27 @@ __device__ __forceinline__ void tile_steps3(const float* lds, int Cs, int st0, i
   }
 }
 
+// two pairs (l1_moments_kernel's packed tiling of 24 channels)
+__device__ __forceinline__ void tile_steps2(const float* lds, int Cs, int st0, int st1, int pk, int oa0, int ob0, int oa1, int ob1,
+                                            f64x4& c0, f64x4& c1, double& s0, double& s1) {
+  for (int st = st0; st < st1; st += 4) {
+    float av[4][2], bv[4][2];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float* row = lds + ((st + u) * 4 + pk) * Cs;
+      av[u][0] = row[oa0]; bv[u][0] = row[ob0];
+      av[u][1] = row[oa1]; bv[u][1] = row[ob1];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const double a0 = (double)av[u][0], a1 = (double)av[u][1];
+      s0 += a0; s1 += a1;
+      c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, (double)bv[u][0], c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, (double)bv[u][1], c1, 0, 0, 0);
+    }
+  }
+}
+
 // NLD: float4 load slots per thread per tile = ceil(MP * C / 4 / 256); PW: tile pairs a wave can own (3 / 6 / 9 -- sized to
 // the problem so that small-C launches do not carry 9 accumulators); DEPTH: tiles in flight towards HBM (1 or 2)
 template <int NLD, int PW, int DEPTH>
@@ -225,12 +246,17 @@ __global__ __launch_bounds__(256, 2) void l1_moments_kernel(L1MomArgs a) {
   for (int e = tid; e < MP * a.Cs; e += 256) feat[e] = 0.f;   // columns >= 32 are never written
   L1Weights w;
   l1_load_weights(a.c, li, kq, IMG_E, w);
-  // the three tile pairs (0,0), (0,1), (1,1) of the 32 padded channels
-  int offA[3] = {li, li, 16 + li}, offB[3] = {li, 16 + li, 16 + li};
-  f64x4 acc[3];
-  double s[3];
+  // 24 channels in TWO 16x16 products instead of the three tile pairs (0,0), (0,1), (1,1) of the padded 32:
+  //   product 0: rows ch 0..15 x cols ch 0..15                                   = tile (0,0)
+  //   product 1: rows ch 8..23 x cols ch (16..23, 0..7): its blocks are rows 8..15 of tile (0,1), the whole 8x8 of tile (1,1),
+  //              rows 0..7 of tile (0,1) TRANSPOSED (x_a x_b = x_b x_a: the same products in the same pixel order, bit for bit)
+  //              and a duplicate of part of tile (0,0) that is dropped
+  // -- a third less work on the fp64 matrix cores, which bound this kernel.  The partials leave in the standard three-tile format.
+  const int oa1 = 8 + li, ob1 = li < 8 ? 16 + li : li - 8;
+  f64x4 acc[2];
+  double s[2];
 #pragma unroll
-  for (int j = 0; j < 3; ++j) { acc[j] = f64x4{0., 0., 0., 0.}; s[j] = 0.; }
+  for (int j = 0; j < 2; ++j) { acc[j] = f64x4{0., 0., 0., 0.}; s[j] = 0.; }
   int soff[2];
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
@@ -271,7 +297,7 @@ __global__ __launch_bounds__(256, 2) void l1_moments_kernel(L1MomArgs a) {
       }
     __syncthreads();
     const int st0 = wave * (MP / 16);
-    tile_steps3(feat, a.Cs, st0, st0 + MP / 16, kq, offA, offB, acc[0], acc[1], acc[2], s[0], s[1], s[2]);
+    tile_steps2(feat, a.Cs, st0, st0 + MP / 16, kq, li, li, oa1, ob1, acc[0], acc[1], s[0], s[1]);
     if (vn < ntiles) { head_pin(pxr); head_commit(pxr, imgH, imgL, tid, sat); }
   }
   sat.commit(a.sat);
@@ -279,16 +305,26 @@ __global__ __launch_bounds__(256, 2) void l1_moments_kernel(L1MomArgs a) {
   __syncthreads();
   double* red = reinterpret_cast<double*>(feat);   // [4][NP][256] + [4][T*16]
   double* reds = red + (size_t)4 * NP * 256;
+  {
+    double* mine = red + (size_t)wave * NP * 256;
+    // tiles (0,1) and (1,1): zero (padding channels 24..31), then product 1's blocks scattered to their places.  One wave's LDS
+    // operations execute in order, and the regions are per wave.
+    for (int e = lane; e < 2 * 256; e += 64) mine[256 + e] = 0.;
 #pragma unroll
-  for (int j = 0; j < NP; ++j) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) red[((size_t)wave * NP + j) * 256 + (kq + 4 * r) * 16 + li] = acc[j][r];
-    if (j != 1) {   // diagonal pairs own the channel sums of their tile
-      double t = s[j];
-      t += __shfl_xor(t, 16);
-      t += __shfl_xor(t, 32);
-      if (kq == 0) reds[wave * T * 16 + offA[j]] = t;
+    for (int r = 0; r < 4; ++r) {
+      const int row = kq + 4 * r;
+      mine[row * 16 + li] = acc[0][r];                                   // tile (0,0)
+      const int ra = 8 + row, cb = ob1;                                   // channels of product 1's entry
+      if (ra < 16 && cb >= 16) mine[256 + ra * 16 + (cb - 16)] = acc[1][r];             // tile (0,1) rows 8..15
+      else if (ra >= 16 && cb >= 16) mine[512 + (ra - 16) * 16 + (cb - 16)] = acc[1][r];   // tile (1,1)
+      else if (ra >= 16) mine[256 + cb * 16 + (ra - 16)] = acc[1][r];                   // tile (0,1) rows 0..7, transposed
     }
+    // channel sums: product 0's rows are channels 0..15, product 1's rows 8..15 are channels 16..23
+    double t0 = s[0], t1 = s[1];
+    t0 += __shfl_xor(t0, 16); t0 += __shfl_xor(t0, 32);
+    t1 += __shfl_xor(t1, 16); t1 += __shfl_xor(t1, 32);
+    if (kq == 0) { reds[wave * T * 16 + li] = t0; reds[wave * T * 16 + 16 + li] = 0.; }   // channels 24..31: padding
+    if (kq == 0 && li >= 8) reds[wave * T * 16 + 8 + li] = t1;
   }
   __syncthreads();
   const int nsq = NP * 256, ns = T * 16;
