@@ -344,10 +344,11 @@ __device__ __forceinline__ void c3_block_store(const f32x4 (&acc)[4], float inv,
 }
 
 // ---- conv11 of the level-1 / head encoders (3 channels in, <= 32 out) as f16x3 on 16x16x32 MFMAs.
-// K layout: "singles" of 4 halfs = one window pixel's RGB0; the 27 singles t = 9 term + pos (term 0: w_hi x_hi, 1: w_hi x_lo,
-// 2: w_lo x_hi; pos = 3 dy + dx of the 3x3 window) are concatenated along K -- 27 of 32 singles = FOUR K-steps (the first form
-// kept the three terms apart, two half-empty K-steps each: six MFMAs).  Lane group kq of K-step s holds singles 8 s + 2 kq + {0, 1}:
-// two 8-byte LDS reads at per-lane offsets (window position, hi or lo plane), fixed for the kernel's lifetime.
+// K layout: "singles" of 4 halfs = one window pixel's RGB0; the 27 singles (term 0: w_hi x_hi, 1: w_hi x_lo, 2: w_lo x_hi; pos =
+// 3 dy + dx of the 3x3 window) are concatenated along K -- 27 of 32 singles = FOUR K-steps (the first form kept the three terms
+// apart, two half-empty K-steps each: six MFMAs).  Lane group kq of K-step s holds the singles l1_single(s, kq, 0 / 1)
+// (wct_common.h: ordered so that the reads are free of bank conflicts): two 8-byte LDS reads at per-lane offsets (window position,
+// hi or lo plane), fixed for the kernel's lifetime.
 // Weights: [cout tile][s][kq][16 couts] x 8 halfs (wct_api.hip pack_head_f16).
 struct L1Conv { const u32x4* w; const float* b; float inv; };
 struct L1Weights { f16x8 a[2][4]; int off[4][2]; f32x4 bias[2]; float inv; };
@@ -358,8 +359,8 @@ __device__ __forceinline__ void l1_lane_offsets(int kq, int lo_plane, int (&off)
   for (int s = 0; s < 4; ++s)
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      const int t = 8 * s + 2 * kq + u, term = t / 9, pos = t - term * 9;
-      off[s][u] = t < 27 ? (pos / 3) * I2W + pos % 3 + (term == 1 ? lo_plane : 0) : 0;   // singles 27..31 carry zero weights
+      const L1Single t = l1_single(s, kq, u);          // wct_common.h: which (term, window position) this lane group holds
+      off[s][u] = (t.pos / 3) * I2W + t.pos % 3 + (t.term == 1 ? lo_plane : 0);
     }
 }
 
@@ -393,6 +394,27 @@ __device__ __forceinline__ f32x4 l1_conv_group(const u32x2* imgH, int base, cons
     if constexpr (RELU) x[r] = fmaxf(x[r], 0.f);
   }
   return x;
+}
+
+// both cout tiles of conv11 from ONE set of operand reads (the callers store to LDS between the tiles, so the compiler may not
+// merge the reads of two l1_conv_group calls itself)
+template <bool RELU = true>
+__device__ __forceinline__ void l1_conv_pair(const u32x2* imgH, int base, const L1Weights& w, f32x4& x0, f32x4& x1) {
+  f32x4 a0 = f32x4{0.f, 0.f, 0.f, 0.f}, a1 = a0;
+  const u32x2* p = imgH + base;
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const u32x2 r0 = p[w.off[s][0]], r1 = p[w.off[s][1]];
+    const f16x8 b = __builtin_bit_cast(f16x8, u32x4{r0[0], r0[1], r1[0], r1[1]});
+    a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w.a[0][s], b, a0, 0, 0, 0);
+    a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w.a[1][s], b, a1, 0, 0, 0);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    x0[r] = a0[r] * w.inv + w.bias[0][r];
+    x1[r] = a1[r] * w.inv + w.bias[1][r];
+    if constexpr (RELU) { x0[r] = fmaxf(x0[r], 0.f); x1[r] = fmaxf(x1[r], 0.f); }
+  }
 }
 
 inline int num_cus() {

@@ -74,11 +74,12 @@ __global__ __launch_bounds__(256, 3) void l1_encode_kernel(L1EncArgs a) {
         const int py = wave * 2 + r, px = h * 16 + li;
         const int base = (py + 1) * I2W + px + 1;   // top-left of the 3x3 window in the 36 x 12 tile (origin -2, -2)
         const int gy = ty0 + py, gx = tx0 + px;
+        f32x4 xs[2];
+        l1_conv_pair(imgH, base, w, xs[0], xs[1]);
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) {
-          const f32x4 x = l1_conv_group(imgH, base, w, ct);
           const int co = ct * 16 + 4 * kq;
-          if (gy < a.H && gx < a.W && co < a.C) *reinterpret_cast<f32x4*>(a.out + ((size_t)gy * a.W + gx) * a.C + co) = x;
+          if (gy < a.H && gx < a.W && co < a.C) *reinterpret_cast<f32x4*>(a.out + ((size_t)gy * a.W + gx) * a.C + co) = xs[ct];
         }
       }
     __syncthreads();
@@ -161,11 +162,11 @@ __global__ __launch_bounds__(32 * TH, 1) void l1_decode_kernel(L1DecArgs a) {
         const int iy = reflect_clamp(ty0 - 1 + gpy[u], a.H) - (ty0 - 2), ix = reflect_clamp(tx0 - 1 + gpx[u], a.W) - (tx0 - 2);
         base = (iy - 1) * I2W + ix - 1;
       }
+      f32x4 xs[2];
+      l1_conv_pair<false>(imgH, base, w, xs[0], xs[1]);
 #pragma unroll
-      for (int ct = 0; ct < 2; ++ct) {
-        const f32x4 x = l1_conv_group<false>(imgH, base, w, ct);
-        if (gok[u]) store_split4<true>(act + ct * 4 * NPX, NPX, gslot[u], kq, x, sat);
-      }
+      for (int ct = 0; ct < 2; ++ct)
+        if (gok[u]) store_split4<true>(act + ct * 4 * NPX, NPX, gslot[u], kq, xs[ct], sat);
     }
     __syncthreads();
     // ---- folded decoder conv on the two 16-channel chunks, block-packed (conv_f16_dev.h): every lane ends with one output pixel

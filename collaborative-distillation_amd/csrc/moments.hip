@@ -289,11 +289,11 @@ __global__ __launch_bounds__(256, 2) void l1_moments_kernel(L1MomArgs a) {
         const int base = (py + 1) * I2W + px + 1;
         const int gy = ty0 + py, gx = tx0 + px;
         const bool in = gy < a.H && gx >= a.x0 && gx < xhi;
+        f32x4 xs[2];
+        l1_conv_pair(imgH, base, w, xs[0], xs[1]);
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct) {
-          const f32x4 x = l1_conv_group(imgH, base, w, ct);
-          *reinterpret_cast<f32x4*>(feat + (py * 32 + px) * a.Cs + ct * 16 + 4 * kq) = in ? x : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
+        for (int ct = 0; ct < 2; ++ct)
+          *reinterpret_cast<f32x4*>(feat + (py * 32 + px) * a.Cs + ct * 16 + 4 * kq) = in ? xs[ct] : f32x4{0.f, 0.f, 0.f, 0.f};
       }
     __syncthreads();
     const int st0 = wave * (MP / 16);

@@ -386,9 +386,9 @@ float pack_up_sp_f16(const float* w, int cout, int cin, int cout_pad, std::vecto
 }
 
 // split-f16 packing of the 3-channel first conv for the fused encoder head (conv3x3_f16.hip enc_head_kernel) and the level-1
-// kernels (conv_f16_dev.h l1_conv_group): K = 4 steps of 32 halfs in "singles" of 4 (one window pixel's RGB0); single
-// t = 9 term + pos (term 0: w_hi . x_hi, 1: w_hi . x_lo, 2: w_lo . x_hi; pos = 3 dy + dx), t < 27, the rest zero; lane group kq of
-// step s holds singles 8 s + 2 kq + {0, 1}.  Layout [cout tile][s][kq][16 couts] x 8 halfs.  in3: the fp32 packing
+// kernels (conv_f16_dev.h l1_conv_group): K = 4 steps of 32 halfs in "singles" of 4 (one window pixel's RGB0; term 0: w_hi . x_hi,
+// 1: w_hi . x_lo, 2: w_lo . x_hi; pos = 3 dy + dx); lane group kq of step s holds the singles l1_single(s, kq, 0 / 1) of
+// wct_common.h, 27 real ones, the rest zero.  Layout [cout tile][s][kq][16 couts] x 8 halfs.  in3: the fp32 packing
 // [tap][4][cout_pad] (conv0 already folded).  Returns 2^-e.
 float pack_head_f16(const std::vector<float>& in3, int cout_pad, int ntile, std::vector<_Float16>& out) {
   float mx = 0.f;
@@ -402,11 +402,12 @@ float pack_head_f16(const std::vector<float>& in3, int cout_pad, int ntile, std:
       for (int kq = 0; kq < 4; ++kq)
         for (int oo = 0; oo < 16; ++oo)
           for (int j = 0; j < 8; ++j) {
-            const int t = 8 * s + 2 * kq + (j >> 2), term = t / 9, pos = t % 9, ch = j & 3, o = ct * 16 + oo;
-            if (t >= 27 || ch > 2 || o >= cout_pad) continue;
-            const float x = in3[((size_t)pos * 4 + ch) * cout_pad + o] * scale;
+            const L1Single t = l1_single(s, kq, j >> 2);     // wct_common.h: the K order shared with the kernels
+            const int ch = j & 3, o = ct * 16 + oo;
+            if (t.zero || ch > 2 || o >= cout_pad) continue;
+            const float x = in3[((size_t)t.pos * 4 + ch) * cout_pad + o] * scale;
             const _Float16 h = (_Float16)x;
-            out[((((size_t)ct * 4 + s) * 4 + kq) * 16 + oo) * 8 + j] = term == 2 ? (_Float16)(x - (float)h) : h;
+            out[((((size_t)ct * 4 + s) * 4 + kq) * 16 + oo) * 8 + j] = t.term == 2 ? (_Float16)(x - (float)h) : h;
           }
   return std::ldexp(1.f, -ex);
 }

@@ -18,6 +18,24 @@ static inline const char* wct_debug_env(const char* name) {
   return getenv(name);
 }
 
+// K layout of the 3-channel first conv on 16x16x32 f16 MFMAs (conv_f16_dev.h l1_conv_group, enc_head_kernel; host packing
+// wct_api.hip pack_head_f16): 27 "singles" (split term 0: w_hi x_hi, 1: w_hi x_lo, 2: w_lo x_hi; window position pos = 3 dy + dx;
+// 4 halfs RGB0 each) in 4 K-steps x 4 lane groups x 2.  One ds_read_b64 serves 32 lanes = two lane groups: their two singles are
+// always in the SAME window row and the SAME plane (hi or lo), so the two 128-byte runs overlap on identical addresses instead of
+// landing on the same banks 288 bytes apart (the contiguous order 9 term + pos did: 25 LDS cycles per 16 reads instead of 16).
+// Pair q = 4 s + 2 u + (kq >> 1) of lane groups (2 h, 2 h + 1); five pairs per window row, the 16th is empty.
+struct L1Single { int term, pos; bool zero; };
+__host__ __device__ constexpr L1Single l1_single(int s, int kq, int u) {
+  const int q = 4 * s + 2 * u + (kq >> 1), j = kq & 1;
+  if (q == 15) return L1Single{0, 0, true};
+  const int r = q / 5, m = q - 5 * r;
+  return m == 0 ? L1Single{0, 3 * r + j, false}
+       : m == 1 ? (j == 0 ? L1Single{0, 3 * r + 2, false} : L1Single{2, 3 * r, false})
+       : m == 2 ? L1Single{2, 3 * r + 1 + j, false}
+       : m == 3 ? L1Single{1, 3 * r + j, false}
+                : L1Single{1, 3 * r + 2, j != 0};      // the partner of the row's last lo single reads the same place with zero weights
+}
+
 // ---- conv3x3 (reflect-pad + 3x3 conv + bias + ReLU, optional fused nearest-x2 input / 2x2 max-pool output)
 enum ConvFlags : int {
   CONV_IN_NCHW3 = 1,   // input is a planar 3xHxW image (first encoder conv, conv0 folded in)
