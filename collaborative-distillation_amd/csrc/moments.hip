@@ -452,12 +452,15 @@ hipError_t launch_l1_moments(const ConvDesc& e, const float* img, int H, int W, 
   a.img = img;
   a.c.w = reinterpret_cast<const u32x4*>(e.l1w16); a.c.b = e.l1bias; a.c.inv = e.l1inv;
   a.H = H; a.W = W; a.x0 = x0; a.x1 = x1; a.tiles_x = (W + FTW - 1) / FTW; a.tiles_y = (H + 7) / 8;
-  a.Cs = 48;
+  // LDS row stride of the feature tile (floats).  44: the 16-byte conv11 stores of eight neighbouring pixels fall on distinct banks (48
+  // made them 4-way conflicts: 64 LDS cycles per store pair instead of 16) at the price of 2-way conflicts on the pair loop's 4-byte
+  // reads (model: 320 vs 416 LDS cycles per wave and tile; measured -6 %)
+  a.Cs = 44;
   a.sat = e.sat;
   const int ntiles = a.tiles_x * a.tiles_y, grid = ntiles < 2 * num_cus() ? ntiles : 2 * num_cus();
   a.part_sq = reinterpret_cast<double*>(ws);
   a.part_sum = a.part_sq + (size_t)grid * 3 * 256;
-  const size_t lds = (size_t)2 * IMG_E * 8 + (size_t)256 * a.Cs * sizeof(float);   // 56 KB (the reduction needs 25 KB of it)
+  const size_t lds = (size_t)2 * IMG_E * 8 + (size_t)256 * a.Cs * sizeof(float);   // 52 KB (the reduction needs 25 KB of it)
   hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(l1_moments_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (err != hipSuccess) return err;
   hipLaunchKernelGGL(l1_moments_kernel, dim3(grid), dim3(256), lds, s, a);
