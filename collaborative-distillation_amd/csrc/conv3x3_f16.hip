@@ -446,7 +446,9 @@ __global__ __launch_bounds__(32 * TH, HeadGeo<TH>::PER_CU) void enc_head_kernel(
     gpix[u] = gok[u] ? pixr : NPH - 1;
     gpy[u] = gpix[u] / FHW;
     gpx[u] = gpix[u] - gpy[u] * FHW;
+    if (!gok[u]) gpix[u] = NPP - 1;   // store target of a lane without a pixel: a slot nobody reads, so that the stores need no exec masking
   }
+  static_assert(NPP > NPH, "a spare slot behind the halo");
 
   float pxr[2][3];
   SatTrack sat;
@@ -511,7 +513,7 @@ __global__ __launch_bounds__(32 * TH, HeadGeo<TH>::PER_CU) void enc_head_kernel(
         f32x4 x;
 #pragma unroll
         for (int r = 0; r < 4; ++r) x[r] = acc[u][r] * a.inv11 + bias11[r];
-        if (gok[i + u]) store_split4<true>(act, NPP, gpix[i + u], kq, x, sat);
+        store_split4<true>(act, NPP, gpix[i + u], kq, x, sat);
       }
     }
     HT_STAMP(2);
@@ -673,8 +675,9 @@ __global__ __launch_bounds__(32 * TH, TH == 8 ? 2 : 1) void dec_tail_kernel(Tail
     gpix[u] = gok[u] ? pixr : NPH - 1;
     gpy[u] = gpix[u] / FHW;
     gpx[u] = gpix[u] - gpy[u] * FHW;
-    gslot[u] = ph_slot(gpy[u], gpx[u]);
+    gslot[u] = gok[u] ? ph_slot(gpy[u], gpx[u]) : NPX - 1;   // lanes without a pixel store to a slot nobody reads (no exec masking)
   }
+  static_assert(NPX > G::HROWS * PH_W, "a spare slot behind the halo");
 
   TailRegs<TH> tr;
   SatTrack sat;
@@ -735,7 +738,7 @@ __global__ __launch_bounds__(32 * TH, TH == 8 ? 2 : 1) void dec_tail_kernel(Tail
         f32x4 x;
 #pragma unroll
         for (int r = 0; r < 4; ++r) x[r] = acc[u][r] * inv12 + bias12[r];
-        if (gok[u]) store_split4<true>(act1, NPX, gslot[u], kq, x, sat);
+        store_split4<true>(act1, NPX, gslot[u], kq, x, sat);
       }
     }
     __syncthreads();
@@ -809,7 +812,7 @@ __global__ __launch_bounds__(32 * TH, TH == 8 ? 2 : 1) void dec_tail_up_kernel(T
     if (g < G::NROWG) { gpy[u] = g >> 1; gpx[u] = 2 * li + 1 - (g & 1); gok[u] = true; }
     else { const int h = g - G::NROWG; gpx[u] = 33 - (h & 1); gpy[u] = 2 * li + (h >> 1); gok[u] = g < G::NGRP && gpy[u] < G::HROWS; }
     if (!gok[u]) { gpy[u] = 1; gpx[u] = 1; }   // never stored; any in-window patch
-    gslot[u] = ph_slot(gpy[u], gpx[u]);
+    gslot[u] = gok[u] ? ph_slot(gpy[u], gpx[u]) : NPX - 1;   // lanes without a pixel store to a slot nobody reads (no exec masking)
     // interior tiles: window slot of the 2x2 patch's top-left = ((q >> 1) + parity) per axis, q = halo coordinate - 1
     gbase[u] = (((gpy[u] - 1) >> 1) + pa) * LW + ((gpx[u] - 1) >> 1) + pb;
   }
@@ -892,7 +895,7 @@ __global__ __launch_bounds__(32 * TH, TH == 8 ? 2 : 1) void dec_tail_up_kernel(T
         f32x4 x;
 #pragma unroll
         for (int r = 0; r < 4; ++r) x[r] = acc[u][r] * a.inv12u + bias12[r];
-        if (gok[u]) store_split4<true>(act1, NPX, gslot[u], kq, x, sat);
+        store_split4<true>(act1, NPX, gslot[u], kq, x, sat);
       }
     }
     __syncthreads();

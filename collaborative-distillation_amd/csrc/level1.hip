@@ -133,7 +133,7 @@ __global__ __launch_bounds__(32 * TH, 1) void l1_decode_kernel(L1DecArgs a) {
     gpix[u] = gok[u] ? pixr : NPH - 1;
     gpy[u] = gpix[u] / FHW;
     gpx[u] = gpix[u] - gpy[u] * FHW;
-    gslot[u] = ph_slot(gpy[u], gpx[u]);
+    gslot[u] = gok[u] ? ph_slot(gpy[u], gpx[u]) : NPX - 1;   // lanes without a pixel store to a slot nobody reads (no exec masking)
   }
   float pxr[2][3];
   SatTrack sat;
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(32 * TH, 1) void l1_decode_kernel(L1DecArgs a) {
       l1_conv_pair<false>(imgH, base, w, xs[0], xs[1]);
 #pragma unroll
       for (int ct = 0; ct < 2; ++ct)
-        if (gok[u]) store_split4<true>(act + ct * 4 * NPX, NPX, gslot[u], kq, xs[ct], sat);
+        store_split4<true>(act + ct * 4 * NPX, NPX, gslot[u], kq, xs[ct], sat);
     }
     __syncthreads();
     // ---- folded decoder conv on the two 16-channel chunks, block-packed (conv_f16_dev.h): every lane ends with one output pixel
