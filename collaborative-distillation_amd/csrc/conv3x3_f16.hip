@@ -426,7 +426,7 @@ __global__ __launch_bounds__(32 * TH, HeadGeo<TH>::PER_CU) void enc_head_kernel(
   const f32x4 bias11 = *reinterpret_cast<const f32x4*>(a.b11 + 4 * kq);
   const f32x4 bias12 = *reinterpret_cast<const f32x4*>(a.b12 + 4 * kq);
   const int Hp = a.H >> 1, Wp = a.W >> 1;
-  int boff[4][2];    // this lane's two B-operand singles per K-step: window position + plane, relative to the window's top-left
+  int boff[4][2];    // this lane's two B-operand singles per K-step: window position + plane, BYTES relative to the window's top-left
   l1_lane_offsets(kq, IMGE, boff);
 
   int soff[2];
@@ -496,9 +496,10 @@ __global__ __launch_bounds__(32 * TH, HeadGeo<TH>::PER_CU) void enc_head_kernel(
           base = (iy - 1) * I2W + ix - 1;
         }
         acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const char* bp = reinterpret_cast<const char*>(imgH) + base * 8;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-          const u32x2 r0 = imgH[base + boff[s][0]], r1 = imgH[base + boff[s][1]];
+          const u32x2 r0 = *reinterpret_cast<const u32x2*>(bp + boff[s][0]), r1 = *reinterpret_cast<const u32x2*>(bp + boff[s][1]);
           bs[u][s] = __builtin_bit_cast(f16x8, u32x4{r0[0], r0[1], r1[0], r1[1]});
         }
       }

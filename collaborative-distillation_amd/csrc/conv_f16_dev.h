@@ -353,14 +353,15 @@ __device__ __forceinline__ void c3_block_store(const f32x4 (&acc)[4], float inv,
 struct L1Conv { const u32x4* w; const float* b; float inv; };
 struct L1Weights { f16x8 a[2][4]; int off[4][2]; f32x4 bias[2]; float inv; };
 
-// per-lane operand offsets (u32x2 units from the window's top-left pixel in the hi plane); lo_plane = imgL - imgH
+// per-lane operand offsets in BYTES from the window's top-left pixel in the hi plane (an operand address is then one add);
+// lo_plane = imgL - imgH in 8-byte pixels
 __device__ __forceinline__ void l1_lane_offsets(int kq, int lo_plane, int (&off)[4][2]) {
 #pragma unroll
   for (int s = 0; s < 4; ++s)
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const L1Single t = l1_single(s, kq, u);          // wct_common.h: which (term, window position) this lane group holds
-      off[s][u] = (t.pos / 3) * I2W + t.pos % 3 + (t.term == 1 ? lo_plane : 0);
+      off[s][u] = ((t.pos / 3) * I2W + t.pos % 3 + (t.term == 1 ? lo_plane : 0)) * 8;
     }
 }
 
@@ -381,10 +382,10 @@ __device__ __forceinline__ void l1_load_weights(const L1Conv& c, int li, int kq,
 template <bool RELU = true>
 __device__ __forceinline__ f32x4 l1_conv_group(const u32x2* imgH, int base, const L1Weights& w, int ct) {
   f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-  const u32x2* p = imgH + base;
+  const char* p = reinterpret_cast<const char*>(imgH) + base * 8;
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
-    const u32x2 r0 = p[w.off[s][0]], r1 = p[w.off[s][1]];
+    const u32x2 r0 = *reinterpret_cast<const u32x2*>(p + w.off[s][0]), r1 = *reinterpret_cast<const u32x2*>(p + w.off[s][1]);
     acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w.a[ct][s], __builtin_bit_cast(f16x8, u32x4{r0[0], r0[1], r1[0], r1[1]}), acc, 0, 0, 0);
   }
   f32x4 x;
@@ -401,10 +402,10 @@ __device__ __forceinline__ f32x4 l1_conv_group(const u32x2* imgH, int base, cons
 template <bool RELU = true>
 __device__ __forceinline__ void l1_conv_pair(const u32x2* imgH, int base, const L1Weights& w, f32x4& x0, f32x4& x1) {
   f32x4 a0 = f32x4{0.f, 0.f, 0.f, 0.f}, a1 = a0;
-  const u32x2* p = imgH + base;
+  const char* p = reinterpret_cast<const char*>(imgH) + base * 8;
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
-    const u32x2 r0 = p[w.off[s][0]], r1 = p[w.off[s][1]];
+    const u32x2 r0 = *reinterpret_cast<const u32x2*>(p + w.off[s][0]), r1 = *reinterpret_cast<const u32x2*>(p + w.off[s][1]);
     const f16x8 b = __builtin_bit_cast(f16x8, u32x4{r0[0], r0[1], r1[0], r1[1]});
     a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w.a[0][s], b, a0, 0, 0, 0);
     a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w.a[1][s], b, a1, 0, 0, 0);
