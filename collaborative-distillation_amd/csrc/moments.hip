@@ -226,7 +226,7 @@ struct L1MomArgs {
   const float* img;
   L1Conv c;
   int H, W, x0, x1, tiles_x, tiles_y;
-  int Cs;                // LDS row stride (floats): 48
+  int Cs;                // LDS row stride (floats): 44 (launch_l1_moments)
   double* part_sq;       // [grid][3][256]
   double* part_sum;      // [grid][32]
   unsigned* sat;         // sticky saturation counter of the context (image values beyond the f16 range), may be null
