@@ -768,11 +768,11 @@ __global__ __launch_bounds__(32 * TH, TH == 8 ? 2 : 1) void dec_tail_kernel(Tail
 template <int TH>
 struct TailUpGeo {
   static constexpr int NT = 32 * TH, NWV = TH / 2;
-  static constexpr int HROWS = TH + 2, NROWG = 2 * HROWS, NGRP = NROWG + 4, NG = (NGRP + NWV - 1) / NWV;
+  static constexpr int HROWS = TH + 2, NROWG = 2 * HROWS, NLEFT = 4 * ((HROWS / 2 + 15) / 16), NGRP = NROWG + NLEFT, NG = (NGRP + NWV - 1) / NWV;
   static constexpr int LW = FTW / 2 + 2, LH = TH / 2 + 2, NPL = (LW * LH + 15) / 16 * 16;     // low-resolution window 18 x (TH / 2 + 2): 256 / 192 / 112 slots
   static constexpr int NPX = (HROWS * PH_W + 15) / 16 * 16;
   static_assert(NWV % 4 == 0 && NROWG % 4 == 0 && 2 * LW * LH <= NT, "phase-uniform waves; one (pixel, channel half) slot per thread");
-  static_assert(HROWS / 2 <= 16, "a leftover column's rows of one parity fit one 16-pixel group (32 x 32 tiles were measured with two more groups' worth missing: -7 %, not pursued)");
+  // (the two leftover columns' rows of one parity: HROWS / 2 pixels per (column, parity) = one group of 16, or two at TH = 32)
   static constexpr size_t lds = ((size_t)4 * NPL + PH_WSLOTS + (size_t)4 * NPX) * 16;           // 93.2 / 66.6 / 47.1 KB
 };
 
@@ -811,7 +811,7 @@ __global__ __launch_bounds__(32 * TH, TH == 8 ? 2 : 1) void dec_tail_up_kernel(T
   for (int u = 0; u < NG; ++u) {
     const int g = wave + NWV * u;
     if (g < G::NROWG) { gpy[u] = g >> 1; gpx[u] = 2 * li + 1 - (g & 1); gok[u] = true; }
-    else { const int h = g - G::NROWG; gpx[u] = 33 - (h & 1); gpy[u] = 2 * li + (h >> 1); gok[u] = g < G::NGRP && gpy[u] < G::HROWS; }
+    else { const int idx = g - G::NROWG, h = idx & 3; gpx[u] = 33 - (h & 1); gpy[u] = 2 * (li + 16 * (idx >> 2)) + (h >> 1); gok[u] = g < G::NGRP && gpy[u] < G::HROWS; }
     if (!gok[u]) { gpy[u] = 1; gpx[u] = 1; }   // never stored; any in-window patch
     gslot[u] = gok[u] ? ph_slot(gpy[u], gpx[u]) : NPX - 1;   // lanes without a pixel store to a slot nobody reads (no exec masking)
     // interior tiles: window slot of the 2x2 patch's top-left = ((q >> 1) + parity) per axis, q = halo coordinate - 1
@@ -1066,6 +1066,8 @@ hipError_t launch_dec_tail(const ConvDesc& d0, const ConvDesc& d1, const float* 
       hipLaunchKernelGGL(kern, dim3(grid), dim3(G::NT), G::lds, s, a);
       return hipGetLastError();
     };
+    // (32 x 32 tiles -- 16 waves, four per SIMD -- need 128 registers and spill 9: 0.570 -> 0.597 ms per step; WCT_TAIL_TH=32 only)
+    if (th == 32) return gou(dec_tail_up_kernel<32>, TailUpGeo<32>{}, 1);
     if (th == 24) return gou(dec_tail_up_kernel<24>, TailUpGeo<24>{}, 1);
     return th == 16 ? gou(dec_tail_up_kernel<16>, TailUpGeo<16>{}, 1) : gou(dec_tail_up_kernel<8>, TailUpGeo<8>{}, 2);
   }
