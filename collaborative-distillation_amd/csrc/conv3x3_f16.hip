@@ -777,7 +777,7 @@ struct TailUpGeo {
 };
 
 template <int TH>
-__global__ __launch_bounds__(32 * TH, TH == 8 ? 2 : 1) void dec_tail_up_kernel(TailArgs a) {
+__global__ __launch_bounds__(32 * TH, TH <= 16 ? 2 : 1) void dec_tail_up_kernel(TailArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using G = TailUpGeo<TH>;
   constexpr int NT = G::NT, NWV = G::NWV, NG = G::NG, NPL = G::NPL, NPX = G::NPX, LW = G::LW, LH = G::LH;
@@ -1066,10 +1066,13 @@ hipError_t launch_dec_tail(const ConvDesc& d0, const ConvDesc& d1, const float* 
       hipLaunchKernelGGL(kern, dim3(grid), dim3(G::NT), G::lds, s, a);
       return hipGetLastError();
     };
-    // (32 x 32 tiles -- 16 waves, four per SIMD -- need 128 registers and spill 9: 0.570 -> 0.597 ms per step; WCT_TAIL_TH=32 only)
-    if (th == 32) return gou(dec_tail_up_kernel<32>, TailUpGeo<32>{}, 1);
-    if (th == 24) return gou(dec_tail_up_kernel<24>, TailUpGeo<24>{}, 1);
-    return th == 16 ? gou(dec_tail_up_kernel<16>, TailUpGeo<16>{}, 1) : gou(dec_tail_up_kernel<8>, TailUpGeo<8>{}, 2);
+    // This kernel needs 116-124 registers, so FOUR waves per SIMD fit: two 32 x 16 workgroups per CU (8 waves each, independent
+    // phases) beat one 32 x 24 workgroup (12 waves) by 5 % despite the larger halo recompute (1.20 vs 1.15).  32 x 32 tiles (16
+    // waves in one workgroup) need 128 registers and spill 9: slower (WCT_TAIL_TH=32 / 24 force those shapes).
+    const int thu = th_env ? th_env : (th == 24 ? 16 : th);
+    if (thu == 32) return gou(dec_tail_up_kernel<32>, TailUpGeo<32>{}, 1);
+    if (thu == 24) return gou(dec_tail_up_kernel<24>, TailUpGeo<24>{}, 1);
+    return thu == 16 ? gou(dec_tail_up_kernel<16>, TailUpGeo<16>{}, 2) : gou(dec_tail_up_kernel<8>, TailUpGeo<8>{}, 2);
   }
   auto go = [&](auto kern, auto geo, int per_cu) -> hipError_t {
     using G = decltype(geo);
