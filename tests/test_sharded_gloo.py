@@ -130,7 +130,8 @@ def _free_port():
     (6, 32, 1152, False, "recompute"),   # 6 ranks: every level's style side on another rank, rank 5 none
     (3, 48, 1925, True, "recompute"),    # rank 0 solves and broadcasts (M, b)
     (3, 48, 1925, False, "exchange"),    # exact per-level margins + neighbour exchange of the decoded edge columns;
-    (6, 32, 1157, True, "exchange")])    # 1157 -> 1152 columns after level 5: the last strip shrinks before it is sent
+    (6, 32, 1157, True, "exchange"),     # 1157 -> 1152 columns after level 5: the last strip shrinks before it is sent
+    (8, 32, 1290, False, "exchange")])   # BASELINE configs[3]'s topology: 8 strips, neighbour exchange (1290 -> 1280 columns)
 def test_sharded_equals_untiled(tmp_path, oracle, weights16x, world, H, W, bmap, halo):
     out = str(tmp_path / "sharded.npy")
     mp.spawn(_worker, args=(world, _free_port(), H, W, out, bmap, halo), nprocs=world, join=True)
