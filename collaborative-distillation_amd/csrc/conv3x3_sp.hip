@@ -504,6 +504,13 @@ bool conv_sp_supported(const ConvDesc& d) {
          d.cout_pad <= 512;
 }
 
+// does launch_conv3x3_sp run this layer in the upsample form (per-parity 2x2 convolutions on the low-resolution grid)?
+bool conv_sp_up_form(const ConvDesc& d, int H, int W) {
+  static const int up_env = [] { const char* e = wct_debug_env("WCT_SP_UP"); return e ? atoi(e) : 1; }();
+  return up_env && (d.flags & CONV_UP_IN) && d.wup16 && !(d.flags & CONV_POOL_OUT) && !d.inv_scale_ptr && !(H & 1) && !(W & 1) &&
+         (d.cout_pad % 32) == 0;
+}
+
 // in: SP16 (CONV_IN_SP16 must be set); out: SP16 (CONV_OUT_SP16) or fp32 NHWC
 hipError_t launch_conv3x3_sp(const ConvDesc& d, const void* in, void* out, int H, int W, hipStream_t s) {
   if (H < 2 || W < 2 || !conv_sp_supported(d) || !(d.flags & CONV_IN_SP16)) return hipErrorInvalidValue;
@@ -520,8 +527,7 @@ hipError_t launch_conv3x3_sp(const ConvDesc& d, const void* in, void* out, int H
   a.sat = d.sat;
   const bool pool = d.flags & CONV_POOL_OUT, f32 = !(d.flags & CONV_OUT_SP16);
   // behind an upsample: per-parity 2x2 convolutions on the low-resolution grid (conv3x3_sp_up_kernel)
-  static const int up_env = [] { const char* e = wct_debug_env("WCT_SP_UP"); return e ? atoi(e) : 1; }();
-  if (up_env && a.up_in && d.wup16 && !pool && !d.inv_scale_ptr && !(H & 1) && !(W & 1) && (d.cout_pad % 32) == 0) {
+  if (conv_sp_up_form(d, H, W)) {
     a.wpk = reinterpret_cast<const u32x4*>(d.wup16);
     a.inv_scale = d.inv_scale_up;
     a.tiles_x = (a.inW + FTW - 1) / FTW; a.tiles_y = (a.inH + SPH - 1) / SPH;

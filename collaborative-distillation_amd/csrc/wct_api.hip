@@ -201,9 +201,11 @@ int run_conv(wct_ctx* ctx, Lane& ln, const ConvDesc& d, const float* in, float* 
   const bool spk = f16 && (d.flags & CONV_IN_SP16) && conv_sp_supported(d);   // DMA-staged persistent kernel
   if (!f16 && ((d.flags & CONV_IN_SP16) || ((d.flags & CONV_OUT_SP16) && !(d.flags & CONV_IN_NCHW3))))
     return fail(ctx, WCT_ERR_INVALID, "SP16 activations need the f16x3 path");
-  snprintf(name, sizeof name, "conv3x3%s<co=%d%s%s%s%s>", f16 ? "_f16x3" : "_f32", d.cout_pad > 128 ? 128 : d.cout_pad,
+  // the layers behind an upsample get their own family: they issue 4/9 of the operator's products, so their algorithmic rate must not be
+  // averaged into the nine-tap family's roofline figure
+  snprintf(name, sizeof name, "conv3x3%s<co=%d%s%s%s%s%s>", f16 ? "_f16x3" : "_f32", d.cout_pad > 128 ? 128 : d.cout_pad,
            (d.flags & CONV_IN_NCHW3) ? ",in3" : "", (d.flags & CONV_POOL_OUT) ? ",pool" : "", (d.flags & CONV_OUT_NCHW3) ? ",out3" : "",
-           spk ? ",dma" : "");
+           spk ? ",dma" : "", (spk && conv_sp_up_form(d, H, W)) ? ",up" : "");
   static const bool shapes = getenv("WCT_PROF_SHAPES") != nullptr;   // one profile row per layer shape instead of per family
   if (shapes) { const size_t n = strlen(name); snprintf(name + n, sizeof name - n, "@%dx%dx%d", H, W, d.cin); }
   const double px = (double)H * W;

@@ -85,6 +85,7 @@ size_t conv_f16_weight_bytes(int cin, int cout_pad, int taps);
 // SP16-input layers with >= 32 couts: persistent DMA-staged kernel (conv3x3_sp.hip)
 bool conv_sp_supported(const ConvDesc& d);
 hipError_t launch_conv3x3_sp(const ConvDesc& d, const void* in, void* out, int H, int W, hipStream_t s);
+bool conv_sp_up_form(const ConvDesc& d, int H, int W);   // that launch takes the upsample form (4/9 of the products): own profile family
 // fused full-resolution ends of the 16x networks (conv11+conv12+pool / conv12+conv11): see conv3x3_f16.hip
 bool conv_fusable_head(const ConvDesc& d0, const ConvDesc& d1);
 bool conv_fusable_tail(const ConvDesc& d0, const ConvDesc& d1);
