@@ -3,32 +3,44 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W]          (N > 1: launched by torch.distributed.run)
 
-A "step" is one end-to-end 5-level WCT stylisation (levels 5..1; style-side encodes, moments and
-eigensolves INCLUDED) of synthetic uniform-noise images already resident in HBM (fp32, planar 3xHxW).
+A "step" is one end-to-end 5-level WCT stylisation (levels 5..1; style-side encodes, moments and matrix functions INCLUDED) of
+synthetic images already resident in HBM (fp32, planar 3xHxW).  The frames are the SURVEY 8(d) ones: uniform noise from
+numpy.random.default_rng (content seed 1, style seed 2; config 3: seeds 3 / 4; config 4: seed 5), generated on the host and
+uploaded before the timed region -- the build container can regenerate them bit for bit, which is how the reference itself was
+run on the timed frame (tests/golden/g13_cfg2_noise.npz, tools/make_goldens.py gen_g13).
 
   --config cfg2 (default)   BASELINE.json configs[1]: `--mode 16x`, 3840x2160 content, 2048x2048 style.  With N > 1 the content
                             is N times wider (3840*N x 2160) and column-sharded, every rank a 3840-wide strip -> WEAK scaling
                             ("cfg2xN"); the line then also carries passes.cfg4_strong, ONE 10240x4096 frame in N strips.
   --config cfg4             BASELINE.json configs[3]: ONE 10240x4096 content (2048x2048 style) in N column strips -> STRONG
                             scaling (N = 1: the north_star's single-GPU target frame, untiled).
+  --config cfg3             BASELINE.json configs[2]: `--mode original` (un-pruned VGG-19 graph, GENERATED weights: the torch7
+                            checkpoints are absent, real-weight parity unpinned), 1920x1080 content and style; N = 1 only.
+                            The default run reports the same thing as passes.cfg3_original; this switch makes it the timed
+                            step so that tools/profile_round.sh can profile it.
 Sharding (wct_hip/sharded.py): per level one RCCL all-reduce of the fp64 content moments, one broadcast of the level's style
 statistics (or of the colouring map (M, b)), and -- for strips narrower than 2560 columns -- a neighbour exchange of the
 decoded edge columns instead of recomputed cumulative halos.  value = content megapixels / second over all ranks.
 
 The JSON line also carries
-  roofline      dominant kernel family: algorithmic FLOP per launch / HIP-event duration vs the gfx950 fp32-MFMA peak
-  passes        relu4_1 encode pass: algorithmic GB/s (364 B/px) and TFLOP/s (30 816 FLOP/px); the content
-                cascade against cached style statistics (reported separately, never `value`)
-  cpu_baseline  the CPU oracle (oracle/: numpy + C/OpenMP port of the reference's op sequence) timed on the host
-                cores on ONE frame of the timed configuration itself (3840x2160 + 2048x2048, ~25 s on 32 threads);
-                rank 0, N = 1 only.  The same frame is the parity gate of the timed path (`parity`): the timed call's
-                output against the oracle's fp64 arm ("truth": the reference's algorithm in exact arithmetic) and
-                against the oracle itself.  Two valid fp32 implementations of the reference differ by ~1e-3 end to end on
-                uniform noise (tests/test_hip_scale.py), so the gate is  |hip - truth| <= 1e-3  and
-                |hip - truth| <= 1.5 |oracle - truth| + 1e-4;  when it fails (or an activation left the f16x3 range)
-                the line says "parity_ok": false, `value` is null and the exit status is 1.
+  roofline      dominant kernel family: algorithmic FLOP per launch / HIP-event duration vs the f16x3 MFMA roofline
+  passes        relu4_1 encode pass (364 B/px, 30 816 FLOP/px); the cascade against cached style statistics and
+                with three frames in flight (cfg5_per_gpu); configs[3]'s frame untiled on one GPU; configs[2] (cfg3_original);
+                the uint8 image edge end to end over PCIe (u8_end_to_end: the reference's timer, WCT.py:118-131, includes
+                save_image); one rank's share of the 8-GPU config-4 job timed on this GPU (cfg4_rank_sim) -- never `value`
+  cpu_baseline  the CPU oracle (oracle/: numpy + C/OpenMP port of the reference's op sequence) timed on the host cores on ONE
+                frame of the timed configuration itself; rank 0, N = 1 only
+  parity        THE GATE (the same rule in tests/test_hip_scale.py and DESIGN.md 2): the timed call's output on
+                the timed frame against the REFERENCE'S OWN PIXELS for that frame (G13: util_wct.WCT on torch CPU, every pixel
+                the fixture holds = 1/16 lattice + 8 crops):
+                    hip_vs_reference <= max(1e-3, 1.25 * oracle_vs_reference)
+                i.e. the north_star's 1e-3 wherever the reference's arithmetic is itself reproducible to 1e-3 by a second valid
+                fp32 implementation of it (the oracle: the same op sequence in C loops), and otherwise no further from the
+                reference than that implementation is (+25 %).  Plus: the reference's UHD sample pair (G11) <= 1e-3 outright,
+                and no f16x3 saturation during the timed steps.  A failing gate prints "value": null and exits 1.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -44,27 +56,46 @@ for p in (REPO, PKG):
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
+from tests.fixture_compare import GATE, compare_to_fixture, noise_frame  # noqa: E402  (plain numpy helpers + the seeds)
+
 H, W, HS, WS = 2160, 3840, 2048, 2048      # BASELINE configs[1]
+H3, W3 = 1080, 1920                         # BASELINE configs[2]
 H4, W4 = 4096, 10240                        # BASELINE configs[3]: content of the north_star's target frame
-GATE = 1e-3                                 # north_star: max|d| / max|ref| end to end
 PEAK_F32_MFMA_TF = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / 32x32x2_f32, dense
 PEAK_HBM_GBS = 8000.0      # spec; 6290 measured copy
 PEAK_F16_MFMA_TF = 2500.0  # dense f16/bf16 MFMA (the f16x3 kernels issue 3 MFMAs per algorithmic product)
+MEASURED_F16X3_CEILING_TF = 420.0   # profiles/r02_mfma_ceiling_skeleton_random_pmc.txt: bare loop + DMA + stores, random operands
+GOLD = os.path.join(REPO, "tests", "golden")
+
+
+def source_id():
+    """sha256 over the kernel sources: ties a committed PMC summary to the build it was taken from."""
+    h = hashlib.sha256()
+    d = os.path.join(PKG, "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def pmc_traffic(family):
     """HBM bytes per launch of the kernel behind a profile family, from the committed rocprofv3 PMC passes
-    (profiles/hbm_traffic_latest.json, made by tools/pmc_summary.py; counters cannot be read from inside this process)."""
+    (profiles/hbm_traffic_latest.json, regenerated by tools/profile_round.sh; counters cannot be read from inside this process).
+    `stale` says whether the kernel sources changed since that profile was taken."""
     import re
     path = os.path.join(REPO, "profiles", "hbm_traffic_latest.json")
     if not os.path.exists(path):
         return None
-    ks = json.load(open(path))["kernels"]
+    doc = json.load(open(path))
+    ks = doc["kernels"]
+    src = {"file": "profiles/hbm_traffic_latest.json", "profiled_source_id": doc.get("source_id"), "source_id": source_id()}
+    src["stale"] = src["profiled_source_id"] != src["source_id"]
     m = re.match(r"conv3x3_f16x3<co=(\d+)(,pool)?(,out3)?(,dma)?>", family)
     if not m:
         return None
     co, pool, out3, dma = int(m.group(1)), bool(m.group(2)), bool(m.group(3)), bool(m.group(4))
-    tf = lambda b: "true" if b else "false"
+    tf = lambda b: "true" if b else "false"   # noqa: E731
     if dma:     # <CT, POOL, OUTF32, GROUPS[, DEEP]>: both output formats (and both pipeline depths) of the family
         rx = re.compile(r"void conv3x3_sp_kernel<(\d), (true|false), (true|false), (true|false)(?:, (true|false))?>\(SpArgs\)")
         rows = []
@@ -75,8 +106,8 @@ def pmc_traffic(family):
         if not rows:
             return None
         n = sum(r["calls"] for r in rows)
-        return {"hbm_bytes_per_launch": round(sum((r["read_MB_per_launch"] + r["write_MB_per_launch"]) * r["calls"] for r in rows) / n * 1e6),
-                "source": "profiles/hbm_traffic_latest.json", "pmc_avg_launch_us": round(sum(r["avg_us"] * r["calls"] for r in rows) / n, 2)}
+        src["pmc_avg_launch_us"] = round(sum(r["avg_us"] * r["calls"] for r in rows) / n, 2)
+        return round(sum((r["read_MB_per_launch"] + r["write_MB_per_launch"]) * r["calls"] for r in rows) / n * 1e6), src
     if co == 16:
         name = "void conv3x3_f16_c16_kernel<%s, %s>(F16Args)" % (tf(pool), tf(out3))
     else:
@@ -84,71 +115,63 @@ def pmc_traffic(family):
     e = ks.get(name)
     if not e:
         return None
-    return {"hbm_bytes_per_launch": round((e["read_MB_per_launch"] + e["write_MB_per_launch"]) * 1e6), "source": "profiles/hbm_traffic_latest.json",
-            "pmc_avg_launch_us": e["avg_us"]}
+    src["pmc_avg_launch_us"] = e["avg_us"]
+    return round((e["read_MB_per_launch"] + e["write_MB_per_launch"]) * 1e6), src
+
+
+def load_fixture(name):
+    path = os.path.join(GOLD, name)
+    if not os.path.exists(path):
+        return None
+    with np.load(path) as z:
+        return {k: z[k] for k in z.files}
 
 
 def cpu_baseline(weights, content, style):
-    """The oracle (a CPU port of the reference's op sequence: fp32 convs, fp64 two-GEMM WCT with SVD) on a bounded
-    sample of the same workload.  This is the ONLY place bench.py touches oracle/.
+    """The oracle (a CPU port of the reference's op sequence: fp32 convs, fp64 two-GEMM WCT with SVD) on ONE frame of the timed
+    configuration.  This and the parity leg are the only places bench.py touches oracle/.
     Threads: the C/OpenMP convolutions stop scaling at ~8-32 threads on the GPU box's host (1.3 s at 8..32 threads,
     3.8 s at 128, 23.6 s at 256 for a 512x512 sample: oversubscription), so min(cores, 32) are used and reported."""
     from oracle import wct_oracle
     threads = min(os.cpu_count() or 1, 32)
     wct_oracle.set_num_threads(threads)
     mods = wct_oracle.Modules("16x", weights)
-    hc, wc, hs, ws = H, W, HS, WS               # ONE frame of the timed configuration itself
-    c, s = content, style
     t0 = time.perf_counter()
-    out = wct_oracle.stylize(mods, c, s, 1.0)
+    out = wct_oracle.stylize(mods, content, style, 1.0)
     dt = time.perf_counter() - t0
     assert np.isfinite(out).all()
     # second arm ("best-effort CPU", BASELINE.md 3.2): the same convolutions, the transform as ONE fp32 affine map
     # csF = M cF + b (M, b from the fp64 C x C statistics) instead of the reference's two fp64 C x C . C x hw GEMMs + elementwise
-    # passes -- what a CPU implementer free to restructure would do.  Quarter-size sample to bound the run.
-    rng = np.random.default_rng(0)
-    cq, sq = rng.random((3, 1080, 1920), dtype=np.float32), rng.random((3, 1024, 1024), dtype=np.float32)
+    # passes -- what a CPU implementer free to restructure would do.  Same full-size frame.
     t1 = time.perf_counter()
-    outq = wct_oracle.stylize(mods, cq, sq, 1.0, fused_affine=True)
+    outq = wct_oracle.stylize(mods, content, style, 1.0, fused_affine=True)
     dq = time.perf_counter() - t1
     assert np.isfinite(outq).all()
-    t2 = time.perf_counter()
-    truth = wct_oracle.stylize(wct_oracle.Modules("16x", weights, precision="fp64"), c, s, 1.0)   # parity yardstick, not a baseline
-    dtruth = time.perf_counter() - t2
-    return {"value": round(hc * wc / 1e6 / dt, 5), "unit": "MP/s", "cores": threads, "kind": "port",
+    mp = content.shape[1] * content.shape[2] / 1e6
+    return {"value": round(mp / dt, 5), "unit": "MP/s", "cores": threads, "kind": "port",
             "sample": "ONE frame of the timed configuration: 5-level 16x WCT, %dx%d content + %dx%d style (uniform noise), %.1f s "
                       "wall, %d OpenMP threads for the convolutions (of %d host cores), numpy/OpenBLAS for the fp64 transform"
-                      % (wc, hc, ws, hs, dt, wct_oracle.num_threads(), os.cpu_count() or 1),
-            "best_effort": {"value": round(1080 * 1920 / 1e6 / dq, 5), "unit": "MP/s", "cores": threads,
-                            "sample": "1920x1080 content + 1024x1024 style, transform as one fp32 affine map (fused), %.1f s wall" % dq},
-            "truth_arm_s": round(dtruth, 1)}, out, truth
+                      % (content.shape[2], content.shape[1], style.shape[2], style.shape[1], dt, wct_oracle.num_threads(), os.cpu_count() or 1),
+            "best_effort": {"value": round(mp / dq, 5), "unit": "MP/s", "cores": threads,
+                            "sample": "the same full-size frame, transform as one fp32 affine map (fused), %.1f s wall" % dq}}, out
 
 
-def uhd_pair_parity(wct, weights):
-    """green_park-wallpaper-3840x2160.jpg + style/in1.jpg (2048x2048), the reference's sample data at config-2 size:
-    this library vs the oracle, and both vs the reference's own pixels (tests/golden/g11_uhd_pair.npz).  None when the fixtures
-    or Pillow are missing."""
-    gold = os.path.join(REPO, "tests", "golden")
-    files = [os.path.join(gold, f) for f in ("g11_uhd_content_3840x2160.jpg", "g11_style_2048x2048.jpg", "g11_uhd_pair.npz")]
+def uhd_pair_parity(wct):
+    """green_park-wallpaper-3840x2160.jpg + style/in1.jpg (2048x2048), the reference's sample data at config-2 size: this library
+    against the reference's own pixels (tests/golden/g11_uhd_pair.npz).  None when the fixtures or Pillow are missing."""
+    files = [os.path.join(GOLD, f) for f in ("g11_uhd_content_3840x2160.jpg", "g11_style_2048x2048.jpg")]
+    g = load_fixture("g11_uhd_pair.npz")
     try:
         from PIL import Image
     except ImportError:
         return None
-    if not all(os.path.exists(f) for f in files):
+    if g is None or not all(os.path.exists(f) for f in files):
         return None
-    from oracle import wct_oracle
-    c_u8, s_u8 = (np.array(Image.open(f).convert("RGB")) for f in files[:2])
-    g = np.load(files[2])
-    ref = wct_oracle.stylize(wct_oracle.Modules("16x", weights), wct_oracle.to_tensor_u8(c_u8), wct_oracle.to_tensor_u8(s_u8), 1.0)
+    c_u8, s_u8 = (np.array(Image.open(f).convert("RGB")) for f in files)
     got = wct.stylize(wct.to_tensor_u8(torch.from_numpy(c_u8)), wct.to_tensor_u8(torch.from_numpy(s_u8))).cpu().numpy()[0]
-    mx = float(g["max"])
-    e = float(np.abs(got - ref).max() / np.abs(ref).max())
-    crops = []
-    for i in range(4):
-        y0, x0 = (int(v) for v in g["crop%d.origin" % i])
-        crops.append(float(np.abs(got[:, y0:y0 + 96, x0:x0 + 96].astype(np.float64) - g["crop%d" % i]).max() / mx))
-    return {"hip_vs_oracle": e, "hip_vs_reference_pixels": max(crops), "gate": GATE, "ok": bool(e <= GATE and max(crops) <= GATE),
-            "frame": "reference sample data: UHD_content/green_park 3840x2160 + style/in1.jpg 2048x2048"}
+    r = compare_to_fixture(got, g)
+    return {"hip_vs_reference": r["max"], "down16": r["down16_max"], "gate": GATE, "ok": bool(r["max"] <= GATE),
+            "frame": "reference sample data: UHD_content/green_park 3840x2160 + style/in1.jpg 2048x2048 (G11: four 96x96 crops)"}
 
 
 def main():
@@ -156,15 +179,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", choices=["cfg2", "cfg4"], default="cfg2",
+    ap.add_argument("--config", choices=["cfg2", "cfg3", "cfg4"], default="cfg2",
                     help="cfg2: 3840x2160 content per GPU (N > 1: weak scaling over an N x 3840 wide frame); "
-                         "cfg4: ONE 10240x4096 content in N column strips (strong scaling)")
+                         "cfg4: ONE 10240x4096 content in N column strips (strong scaling); cfg3: --mode original at 1920x1080 (N = 1)")
     ap.add_argument("--halo-mode", choices=["auto", "recompute", "exchange"], default="auto")
     ap.add_argument("--debug-set", action="append", default=[], metavar="KEY=VALUE", help="wct_debug_set switches for A/B runs")
-    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle run (and with it the parity gate)")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle run (the parity gate then has no oracle arm)")
     ap.add_argument("--steps-only", action="store_true",
-                    help="skip the extra passes (relu4_1 encode, cached style, frames in flight): every launch then belongs to a "
-                         "stylise step, so a rocprofv3 --stats summary of the run averages the same launch mix as `roofline`")
+                    help="skip the extra passes and the parity leg: every launch then belongs to a stylise step, so a rocprofv3 "
+                         "--stats summary of the run averages the same launch mix as `roofline`")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -173,6 +196,8 @@ def main():
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d bench.py --gpus %d"
                          % (args.gpus, args.gpus))
+    if args.config == "cfg3" and world > 1:
+        raise SystemExit("--config cfg3 is a single-GPU configuration")
     assert torch.cuda.is_available(), "bench.py needs the MI355X (no CPU path)"
     # one rank per GPU; WCT_DIST_BACKEND=gloo lets several ranks share one GPU (used only to smoke-test the N > 1 code
     # path on a single-GPU box -- RCCL needs one device per rank)
@@ -190,40 +215,47 @@ def main():
 
     from wct_hip import WCT, model_zoo
     weights = model_zoo.load_npz_weights(os.path.join(PKG, "weights", "16x.npz"))
-    wct = WCT(types.SimpleNamespace(mode="16x", alpha=1.0), weights=weights)
+    wct16 = WCT(types.SimpleNamespace(mode="16x", alpha=1.0), weights=weights)
     for kv in args.debug_set:
-        wct.debug_set(kv.split("=")[0], float(kv.split("=")[1]))
+        wct16.debug_set(kv.split("=")[0], float(kv.split("=")[1]))
 
-    def noise(seed, h, w):   # uniform noise, no zeros (zero-filled inputs clock higher), seeded
-        return torch.rand((3, h, w), device="cuda", generator=torch.Generator(device="cuda").manual_seed(seed))
+    def original_engine():
+        return WCT(types.SimpleNamespace(mode="original", alpha=1.0), weights=model_zoo.synth_weights("original", 3))
 
-    style = noise(2, HS, WS)                                               # the same style on every rank
+    wct = original_engine() if args.config == "cfg3" else wct16
+    cu = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).cuda()   # noqa: E731
+
+    style_np = noise_frame(4, H3, W3) if args.config == "cfg3" else noise_frame(2, HS, WS)     # the same style on every rank
+    style = cu(style_np)
+    hs_, ws_ = style_np.shape[1:]
 
     def frame_columns(x0, x1, cfg):
-        """Columns [x0, x1) of the benchmark's (virtual) content frame.  cfg2: N seeded 3840-wide panels side by side (panel
-        0 = the N = 1 frame); cfg4: one seeded 10240-wide frame, generated in 1280-column panels so that a rank only
-        materialises what it needs."""
-        pw, ph, seed0 = (W, H, 1) if cfg == "cfg2" else (1280, H4, 500)
+        """Columns [x0, x1) of the benchmark's (virtual) content frame, host numpy.  cfg2: N seeded 3840-wide panels side by side
+        (panel 0 = the N = 1 frame, seed 1; panel r > 0: seed 1000 + r); cfg4: the ONE 10240x4096 frame of seed 5; cfg3: seed 3."""
+        if cfg == "cfg4":
+            return np.ascontiguousarray(noise_frame(5, H4, W4)[:, :, x0:x1])
+        if cfg == "cfg3":
+            return noise_frame(3, H3, W3)
         parts = []
-        for r in range(x0 // pw, (x1 - 1) // pw + 1):
-            a, b = max(x0, r * pw), min(x1, (r + 1) * pw)
-            parts.append(noise(seed0 + r, ph, pw)[:, :, a - r * pw:b - r * pw])
-        return torch.cat(parts, dim=2).contiguous()
+        for r in range(x0 // W, (x1 - 1) // W + 1):
+            a, b = max(x0, r * W), min(x1, (r + 1) * W)
+            parts.append(noise_frame(1 if r == 0 else 1000 + r, H, W)[:, :, a - r * W:b - r * W])
+        return np.ascontiguousarray(np.concatenate(parts, axis=2))
 
-    def make_step(cfg):
-        """-> (step(), megapixels of the whole frame, description)"""
-        fh, fw = (H, W * world) if cfg == "cfg2" else (H4, W4)
+    def make_step(cfg, eng):
+        """-> (step(), megapixels of the whole frame, description, content on the device)"""
+        fh, fw = {"cfg2": (H, W * world), "cfg3": (H3, W3), "cfg4": (H4, W4)}[cfg]
         if world > 1:
             from wct_hip.sharded import ShardedStylizer
-            runner = ShardedStylizer(wct, dist, fh, fw, HS, WS, halo_mode=args.halo_mode)
+            runner = ShardedStylizer(eng, dist, fh, fw, hs_, ws_, halo_mode=args.halo_mode)
             x0, x1 = runner.input_columns()                                # own strip + halo of the halo mode
-            content = frame_columns(x0, x1, cfg)
+            content = cu(frame_columns(x0, x1, cfg))
             return (lambda: runner.stylize_strip(content, style)), fh * fw / 1e6, \
-                "%dx%d content in %d column strips (halo: %s), %dx%d style" % (fw, fh, world, runner.halo_mode, WS, HS), content
-        content = frame_columns(0, fw, cfg)
-        wct.reserve(fh, fw, HS, WS)
+                "%dx%d content in %d column strips (halo: %s), %dx%d style" % (fw, fh, world, runner.halo_mode, ws_, hs_), content
+        content = cu(frame_columns(0, fw, cfg))
+        eng.reserve(fh, fw, hs_, ws_)
         out = torch.empty((3, fh, fw), device="cuda")
-        return (lambda: wct.stylize(content, style, out=out)), fh * fw / 1e6, "%dx%d content, %dx%d style" % (fw, fh, WS, HS), content
+        return (lambda: eng.stylize(content, style, out=out)), fh * fw / 1e6, "%dx%d content, %dx%d style" % (fw, fh, ws_, hs_), content
 
     def barrier():
         if dist is not None:
@@ -246,33 +278,28 @@ def main():
         assert bool(torch.isfinite(res).all())
         return dt
 
-    step, mp, desc, content = make_step(args.config)
-    wct.saturation_count(reset=True)
-    dt = timed(step, args.steps, args.warmup)
-    value = mp * args.steps / dt
-    saturated = wct.saturation_count()      # threads that clamped an activation to the f16x3 range during the timed steps
-
-    # ---- roofline leg (rank 0): HIP events around every kernel launch on the context's stream
-    roof, passes, profile = None, None, None
-    nprof = 2
-    if rank == 0:
-        wct.set_overlap(False)   # kernels one at a time, so that an event pair times exactly one launch
-        wct.profile_reset()
-        wct.profile(True)
-    for _ in range(nprof):      # every rank runs these steps (they contain collectives); only rank 0 records events
-        step()
-    barrier()
-    if rank == 0:
-        wct.profile(False)
-        wct.set_overlap(True)
-        ents = sorted(wct.profile_read(), key=lambda e: -e["ms"])
+    def kernel_profile(eng, step, nprof=2, record=True):
+        """HIP events around every kernel launch on the context's stream, overlap off so one event pair times one launch.
+        Every rank runs the steps (they contain collectives); only a recording rank gets
+        (rows for the `kernels` list, dominant conv family as a roofline dict, kernel time per step)."""
+        if record:
+            eng.set_overlap(False)
+            eng.profile_reset()
+            eng.profile(True)
+        for _ in range(nprof):
+            step()
+        barrier()
+        if not record:
+            return None, None, None
+        eng.profile(False)
+        eng.set_overlap(True)
+        ents = sorted(eng.profile_read(), key=lambda e: -e["ms"])
         tot = sum(e["ms"] for e in ents)
-        profile = [{"kernel": e["name"], "ms_per_step": round(e["ms"] / nprof, 4), "launches_per_step": e["launches"] // nprof,
-                    "tflops": round(e["flops"] / e["ms"] / 1e9, 2) if e["flops"] else None,
-                    "algo_GBs": round(e["bytes"] / e["ms"] / 1e6, 1) if e["bytes"] else None} for e in ents]
+        rows = [{"kernel": e["name"], "ms_per_step": round(e["ms"] / nprof, 4), "launches_per_step": e["launches"] // nprof,
+                 "tflops": round(e["flops"] / e["ms"] / 1e9, 2) if e["flops"] else None,
+                 "algo_GBs": round(e["bytes"] / e["ms"] / 1e6, 1) if e["bytes"] else None} for e in ents]
         # dominant kernel FAMILY with algorithmic work attached; its binding roofline is the larger of the two fractions
-        convs = [e for e in ents if e["flops"] > 0 and e["name"].startswith("conv3x3")]
-        d = convs[0]
+        d = [e for e in ents if e["flops"] > 0 and e["name"].startswith("conv3x3")][0]
         f16 = "f16x3" in d["name"]
         peak_tf = PEAK_F16_MFMA_TF / 3.0 if f16 else PEAK_F32_MFMA_TF
         tf, gbs = d["flops"] / d["ms"] / 1e9, d["bytes"] / d["ms"] / 1e6
@@ -283,11 +310,23 @@ def main():
             roof = {"kernel": d["name"], "bound": "mfma", "achieved": round(tf, 2), "peak": round(peak_tf, 1), "unit": "TFLOP/s",
                     "frac": round(tf / peak_tf, 4), "traffic": None,
                     "peak_note": "2.5 PF dense f16 MFMA / 3 split terms" if f16 else "fp32 MFMA"}
-        pmc = pmc_traffic(d["name"])     # HBM bytes per launch from the committed rocprofv3 PMC passes (a number, or null)
-        roof["traffic"] = pmc["hbm_bytes_per_launch"] if pmc else None
-        roof["traffic_source"] = ({"file": pmc["source"], "pmc_avg_launch_us": pmc["pmc_avg_launch_us"]} if pmc else None)
+            if f16:
+                roof["frac_of_measured_ceiling_420TF"] = round(tf / MEASURED_F16X3_CEILING_TF, 4)
         roof.update({"avg_launch_ms": round(d["ms"] / d["launches"], 4), "share_of_kernel_time": round(d["ms"] / tot, 3),
                      "algo_flop_per_launch": d["flops"] / d["launches"], "algo_bytes_per_launch": d["bytes"] / d["launches"]})
+        return rows, roof, round(tot / nprof, 3)
+
+    step, mp, desc, content = make_step(args.config, wct)
+    wct.saturation_count(reset=True)
+    dt = timed(step, args.steps, args.warmup)
+    value = mp * args.steps / dt
+    saturated = wct.saturation_count()      # threads that clamped an activation to the f16x3 range during the timed steps
+
+    # ---- roofline leg (rank 0 records; every rank runs the steps: they contain collectives)
+    profile, roof, _ = kernel_profile(wct, step, record=(rank == 0))
+    if rank == 0:
+        pm = pmc_traffic(roof["kernel"])     # HBM bytes per launch from the committed rocprofv3 PMC passes (a number, or null)
+        roof["traffic"], roof["traffic_source"] = (pm[0], pm[1]) if pm else (None, None)
     del step
 
     # ---- extra passes (never `value`)
@@ -296,94 +335,188 @@ def main():
     if extra and world > 1 and args.config == "cfg2":
         # BASELINE configs[3] beside the weak-scaling number: ONE 10240x4096 frame in N strips (strong scaling)
         del content
-        step4, mp4, desc4, content4 = make_step("cfg4")
+        step4, mp4, desc4, content4 = make_step("cfg4", wct)
         k4 = max(3, args.steps // 2)
         dt4 = timed(step4, k4, 2)
         passes["cfg4_strong"] = {"workload": desc4, "ms_per_frame": round(dt4 / k4 * 1e3, 3), "MPs": round(mp4 * k4 / dt4, 1), "scaling": "strong"}
         del step4, content4
-    if extra and rank == 0 and world == 1:
-        content4k = content if args.config == "cfg2" else frame_columns(0, W, "cfg2")
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
-        def ev_ms(fn, n=5, warm=2):
-            for _ in range(warm):
-                fn()
-            e0.record()
-            for _ in range(n):
-                fn()
-            e1.record()
-            torch.cuda.synchronize()
-            return e0.elapsed_time(e1) / n
+    def ev_ms(fn, n=5, warm=2):
+        for _ in range(warm):
+            fn()
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / n
 
+    if extra and rank == 0 and world == 1 and args.config != "cfg3":
+        content4k = content if args.config == "cfg2" else cu(frame_columns(0, W, "cfg2"))
         # relu4_1 encode pass on the 4K content (north_star's named pass)
-        ms = ev_ms(lambda: wct.encode(4, content4k, layout="nhwc"))
+        ms = ev_ms(lambda: wct16.encode(4, content4k, layout="nhwc"))
         passes["relu4_1_encode"] = {"ms": round(ms, 3), "algo_GBs": round(364.0 * H * W / ms / 1e6, 1),
                                     "frac_hbm_8TBs": round(364.0 * H * W / ms / 1e6 / PEAK_HBM_GBS, 4),
                                     "tflops": round(30816.0 * H * W / ms / 1e9, 2),
                                     "frac_f16x3_mfma_833TF": round(30816.0 * H * W / ms / 1e9 / (PEAK_F16_MFMA_TF / 3.0), 4)}
         # the cascade against cached style statistics ("style cached" reported separately)
-        wct.style_prepare(style)
-        msc = ev_ms(lambda: wct.stylize_prepared(content4k))
-        cached = {"ms": round(msc, 3), "MPs": round(H * W / 1e6 / msc * 1e3, 1)}
-        # the same with three frames in flight on this GPU (wct_hip/pipeline.py; throughput of the batch / video case)
+        wct16.style_prepare(style)
+        msc = ev_ms(lambda: wct16.stylize_prepared(content4k))
+        passes["style_cached_cascade"] = {"ms": round(msc, 3), "MPs": round(H * W / 1e6 / msc * 1e3, 1)}
+        # BASELINE configs[4] seen from ONE GPU: distinct 4K contents against one style, three frames in flight
+        # (wct_hip/pipeline.py; the per-GPU throughput of the batch / video case; 8 such GPUs share nothing but the style statistics)
         from wct_hip.pipeline import FramePipeline
         pipe = FramePipeline(lambda: WCT(types.SimpleNamespace(mode="16x", alpha=1.0), weights=weights), slots=3)
         pipe.set_style(style)
-        frames = [content4k] * 12
+        frames = [content4k] + [cu(noise_frame(10 + i, H, W)) for i in range(3)]     # SURVEY 8d cfg5 seeds 10..
+        frames = (frames * 3)[:12]
         pipe.stylize_many(frames[:6])
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         pipe.stylize_many(frames)
         torch.cuda.synchronize()
         msp = (time.perf_counter() - t0) / len(frames) * 1e3
-        cached["three_frames_in_flight"] = {"ms_per_frame": round(msp, 3), "MPs": round(H * W / 1e6 / msp * 1e3, 1)}
-        del pipe
-        passes["style_cached_cascade"] = cached
+        passes["cfg5_per_gpu"] = {"workload": "distinct 3840x2160 contents x 1 style (2048x2048), style statistics cached, three frames "
+                                              "in flight on this GPU (wct_hip/pipeline.py)", "ms_per_frame": round(msp, 3),
+                                  "MPs": round(H * W / 1e6 / msp * 1e3, 1)}
+        del pipe, frames
+        # the reference's timed region includes save_image (WCT.py:118-131): uint8 frame in pinned host memory -> H2D ->
+        # ToTensor + cascade + save_image's conversion on the device (wct_stylize_u8) -> D2H, and the host JPEG encode beside it
+        c_u8 = torch.from_numpy((frame_columns(0, W, "cfg2").transpose(1, 2, 0) * 255).astype(np.uint8)).pin_memory()
+        s_u8 = torch.from_numpy((style_np.transpose(1, 2, 0) * 255).astype(np.uint8)).pin_memory()
+        o_u8 = torch.empty((H, W, 3), dtype=torch.uint8).pin_memory()
+
+        def u8_frame():
+            o_u8.copy_(wct16.stylize_u8(c_u8.cuda(non_blocking=True), s_u8.cuda(non_blocking=True)), non_blocking=True)
+        for _ in range(2):
+            u8_frame()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            u8_frame()
+        torch.cuda.synchronize()
+        ms_u8 = (time.perf_counter() - t0) / 5 * 1e3
+        u8 = {"workload": "3840x2160 uint8 content + 2048x2048 uint8 style in pinned host memory -> H2D -> wct_stylize_u8 -> D2H "
+                          "(pinned)", "ms_per_frame": round(ms_u8, 3), "MPs": round(H * W / 1e6 / ms_u8 * 1e3, 1)}
+        try:
+            import io
+            from PIL import Image
+            t0 = time.perf_counter()
+            Image.fromarray(o_u8.numpy()).save(io.BytesIO(), format="JPEG")
+            u8["host_jpeg_encode_ms"] = round((time.perf_counter() - t0) * 1e3, 1)
+            u8["note"] = "the JPEG codec stays on the host (Pillow, one core) and is NOT in ms_per_frame"
+        except ImportError:
+            pass
+        passes["u8_end_to_end"] = u8
+        del c_u8, s_u8, o_u8
         if args.config == "cfg2":
             # BASELINE configs[3]'s frame, 10240x4096, untiled on this ONE GPU (the north_star's target configuration)
-            c4 = frame_columns(0, W4, "cfg4")
+            c4 = cu(frame_columns(0, W4, "cfg4"))
             o4 = torch.empty((3, H4, W4), device="cuda")
-            ms4 = ev_ms(lambda: wct.stylize(c4, style, out=o4), n=3, warm=1)
+            ms4 = ev_ms(lambda: wct16.stylize(c4, style, out=o4), n=3, warm=1)
+            ms4e = ev_ms(lambda: wct16.encode(4, c4, layout="nhwc"), n=3, warm=1)
             passes["cfg4_single_gpu"] = {"workload": "10240x4096 content, 2048x2048 style, untiled on one GPU", "ms_per_frame": round(ms4, 3),
-                                         "MPs": round(H4 * W4 / 1e6 / ms4 * 1e3, 1), "finite": bool(torch.isfinite(o4).all())}
-            del c4, o4
+                                         "MPs": round(H4 * W4 / 1e6 / ms4 * 1e3, 1), "finite": bool(torch.isfinite(o4).all()),
+                                         "relu4_1_encode_ms": round(ms4e, 3),
+                                         "relu4_1_encode_frac_hbm_8TBs": round(364.0 * H4 * W4 / ms4e / 1e6 / PEAK_HBM_GBS, 4)}
+            del o4
+            # one rank's share of the 8-GPU config-4 job (8 x 1280 columns, exchange-mode halos), timed on this GPU with its
+            # peers emulated (wct_hip/sharded.py LoopbackGroup): ranks 0 (edge strip, style level 5) and 3 (interior, level 2)
+            passes["cfg4_rank_sim"] = rank_sim(wct16, c4, style, ms4)
+            del c4
+
+    if extra and rank == 0 and world == 1:
+        # BASELINE configs[2]: --mode original, generated weights
+        eng3 = wct if args.config == "cfg3" else original_engine()
+        c3, s3 = cu(noise_frame(3, H3, W3)), cu(noise_frame(4, H3, W3))
+        eng3.reserve(H3, W3, H3, W3)
+        o3 = torch.empty((3, H3, W3), device="cuda")
+        step3 = lambda: eng3.stylize(c3, s3, out=o3)   # noqa: E731
+        eng3.saturation_count(reset=True)
+        ms3 = ev_ms(step3, n=5, warm=2)
+        sat3 = eng3.saturation_count()
+        rows3, roof3, ksum3 = kernel_profile(eng3, step3)
+        got3 = step3().cpu().numpy()[0]
+        p3 = {"weights": "GENERATED (model_zoo.synth_weights('original', 3)); the torch7 checkpoints are absent: real-weight parity unpinned",
+              "f16x3_saturated_threads": int(sat3)}
+        g14 = load_fixture("g14_cfg3_original.npz")
+        if g14 is not None:
+            r = compare_to_fixture(got3, g14)
+            p3.update({"hip_vs_reference": r["max"], "lattice_p9999": r.get("lattice_p9999"), "lattice_frac_gt_1e-3": r.get("lattice_frac_gt_gate"),
+                       "down16": r["down16_max"],
+                       "reference": "G14: the reference's own classes (model_original.py) + util_wct.WCT.transform with the same generated "
+                                    "weights, torch CPU; random 512-channel stacks are chaotic under five whitenings (oracle vs reference "
+                                    "on this frame: see tests/test_hip_scale.py) -- reported, not gated end to end"})
+        passes["cfg3_original"] = {"workload": "PytorchWCT/WCT.py --mode original, 1920x1080 content + 1920x1080 style -> 1920x1072 (BASELINE configs[2])",
+                                   "ms_per_frame": round(ms3, 3), "MPs": round(H3 * W3 / 1e6 / ms3 * 1e3, 2),
+                                   # 3 094 272 FLOP per content pixel (enc + dec, 5 levels) + 1 547 136 per style pixel
+                                   "algo_TFLOPs": round((3094272.0 + 1547136.0) * H3 * W3 / ms3 / 1e9, 1),
+                                   "algo_frac_f16x3_833TF": round((3094272.0 + 1547136.0) * H3 * W3 / ms3 / 1e9 / (PEAK_F16_MFMA_TF / 3.0), 4),
+                                   "algo_frac_of_measured_ceiling_420TF": round((3094272.0 + 1547136.0) * H3 * W3 / ms3 / 1e9 / MEASURED_F16X3_CEILING_TF, 4),
+                                   "kernel_time_sum_ms": ksum3, "roofline": roof3, "parity": p3,
+                                   "kernels": rows3[:10]}
+        if eng3 is not wct:
+            del eng3
 
     cpu, parity, parity_ok = None, None, None
-    if rank == 0 and world == 1 and args.config == "cfg2" and not args.no_cpu_baseline:
-        c_np, s_np = content.cpu().numpy(), style.cpu().numpy()
-        cpu, ref, truth = cpu_baseline(weights, c_np, s_np)
+    if rank == 0 and world == 1 and args.config == "cfg2" and extra:
         got = wct.stylize(content, style).cpu().numpy()[0]     # the timed call on the timed inputs
-        rel = lambda a, b: float(np.abs(a - b).max() / np.abs(b).max())   # noqa: E731
-        e_truth, o_truth, e_ref = rel(got, truth), rel(ref, truth), rel(got, ref)
-        parity = {"hip_vs_truth": e_truth, "oracle_vs_truth": o_truth, "hip_vs_oracle": e_ref, "gate": GATE,
-                  "margin": round(1.0 - e_truth / GATE, 3), "frame": "the timed frame (%dx%d + %dx%d)" % (W, H, WS, HS),
-                  "truth": "oracle/ with precision fp64: the reference's op sequence, every activation and accumulation in fp64",
-                  "allclose_truth_rtol_atol_1e-3": bool(np.allclose(got, truth, rtol=GATE, atol=GATE * float(np.abs(truth).max()))),
+        g13 = load_fixture("g13_cfg2_noise.npz")
+        parity = {"gate": "hip_vs_reference <= max(1e-3, 1.25 * oracle_vs_reference); reference UHD pair <= 1e-3; no f16x3 saturation",
+                  "frame": "the timed frame (%dx%d seed 1 + %dx%d seed 2, numpy default_rng)" % (W, H, WS, HS),
                   "f16x3_saturated_threads": int(saturated)}
-        parity_ok = bool(e_truth <= 1.5 * o_truth + 1e-4 and e_truth <= 2 * GATE and saturated == 0)
-        parity["within_1e-3_of_truth"] = bool(e_truth <= GATE)
+        parity_ok = saturated == 0
+        rh = None
+        if g13 is not None:
+            assert abs(float(content.sum(dtype=torch.float64)) - float(g13["content.checksum"])) < 1e-3, "timed frame != G13's input"
+            rh = compare_to_fixture(got, g13)
+            parity.update({"reference": "G13: util_wct.WCT (real 16x checkpoints, torch %s CPU) on this frame; 1/16 lattice + 8 crops "
+                                        "= %d reference pixels" % (str(g13["torch"]), rh["lattice_pixels"] + 8 * 3 * 96 * 96),
+                           "hip_vs_reference": rh["max"], "hip_vs_reference_p9999": rh["lattice_p9999"],
+                           "hip_frac_pixels_gt_1e-3": rh["lattice_frac_gt_gate"], "hip_vs_reference_down16": rh["down16_max"]})
+        else:
+            parity_ok = False
+            parity["error"] = "tests/golden/g13_cfg2_noise.npz missing"
+        ro = None
+        if not args.no_cpu_baseline:
+            cpu, ref = cpu_baseline(weights, content.cpu().numpy(), style_np)
+            parity["hip_vs_oracle"] = float(np.abs(got - ref).max() / np.abs(ref).max())
+            if g13 is not None:
+                ro = compare_to_fixture(ref, g13)
+                parity.update({"oracle_vs_reference": ro["max"], "oracle_vs_reference_p9999": ro["lattice_p9999"],
+                               "oracle_frac_pixels_gt_1e-3": ro["lattice_frac_gt_gate"]})
+        if rh is not None:
+            limit = max(GATE, 1.25 * ro["max"]) if ro is not None else GATE
+            parity["limit"] = limit
+            parity["within_1e-3_of_reference"] = bool(rh["max"] <= GATE)
+            parity_ok = parity_ok and rh["max"] <= limit
         # the reference's own UHD sample pair at the same size (tests/golden/g11_*: data files of the reference + the
-        # reference's own output pixels): natural images leave the north_star gate 10x of room, so here it is absolute
-        up = uhd_pair_parity(wct, weights)
+        # reference's own output pixels): natural images leave the north_star gate an order of magnitude of room
+        up = uhd_pair_parity(wct)
         if up is not None:
             parity["reference_uhd_pair"] = up
             parity_ok = parity_ok and up["ok"]
+        parity_ok = bool(parity_ok)
     elif saturated:
         parity_ok = False
         parity = {"f16x3_saturated_threads": int(saturated)}
 
     if rank == 0:
-        cfg2 = args.config == "cfg2"
+        cfg = args.config
+        mode = "original (generated weights)" if cfg == "cfg3" else "16x"
         line = {
-            "metric": "content megapixels/sec, end-to-end 5-level WCT (16x VGG, %s, 2K style)" % ("4K content" if cfg2 else "10240x4096 content"),
+            "metric": "content megapixels/sec, end-to-end 5-level WCT (%s)" % {"cfg2": "16x VGG, 4K content, 2K style", "cfg4": "16x VGG, 10240x4096 content, 2K style",
+                                                                              "cfg3": "un-pruned VGG-19, generated weights, 1920x1080"}[cfg],
             "value": (round(value, 2) if parity_ok is not False else None), "unit": "MP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak" if cfg2 else "strong",
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong" if cfg == "cfg4" else "weak",
             "vs_baseline": None, "dtype": "f32 (f16x3 split-MFMA products, fp32 accumulate)", "data": "synthetic",
             "parity_ok": parity_ok, "parity": parity,
-            "config": {"workload": "PytorchWCT/WCT.py --mode 16x, 5-level WCT, %s, alpha=1, style-side work included, images resident in HBM; %s"
-                                   % (desc, ("BASELINE configs[1]" + ("" if world == 1 else " x%d wide (weak scaling)" % world)) if cfg2 else "BASELINE configs[3] (strong scaling)"),
-                       "name": ("cfg2" if world == 1 else "cfg2x%d" % world) if cfg2 else "cfg4",
-                       "content_total": "%dx%d" % ((W * world, H) if cfg2 else (W4, H4)), "parallelism": "content column strips x%d" % world,
+            "config": {"workload": "PytorchWCT/WCT.py --mode %s, 5-level WCT, %s, alpha=1, style-side work included, images resident in HBM; %s"
+                                   % (mode, desc, {"cfg2": "BASELINE configs[1]" + ("" if world == 1 else " x%d wide (weak scaling)" % world),
+                                                   "cfg3": "BASELINE configs[2]", "cfg4": "BASELINE configs[3] (strong scaling)"}[cfg]),
+                       "name": ("cfg2" if world == 1 else "cfg2x%d" % world) if cfg == "cfg2" else cfg,
+                       "content_total": "%dx%d" % {"cfg2": (W * world, H), "cfg3": (W3, H3), "cfg4": (W4, H4)}[cfg], "parallelism": "content column strips x%d" % world,
                        "dist_backend": (backend if world > 1 else None)},
             "roofline": roof, "passes": passes or None, "cpu_baseline": cpu, "kernels": profile,
         }
@@ -394,6 +527,61 @@ def main():
         dist.destroy_process_group()
     if parity_ok is False:
         sys.exit(1)
+
+
+def rank_sim(wct, c4, style, ms_untiled, world=8, ranks=(0, 3), frames=4):
+    """What ONE rank of the `world`-GPU config-4 job executes (ShardedStylizer.stylize_strip on its strip + exchange-mode halos,
+    the style levels it owns, the per-level collectives as launches on a 1-rank RCCL communicator, the neighbour exchange as
+    device copies), timed on this GPU.  `host_enqueue_ms`: wall time until stylize_strip has returned for every frame (Python +
+    torch.distributed + ctypes orchestration, nothing waited for); `ms_per_frame`: the same frames with the final sync.  The
+    slowest rank bounds the N = 8 frame time: no link time, no skew -- the compute-only strong-scaling prediction."""
+    import torch.distributed as tdist
+    from wct_hip.sharded import LoopbackGroup, ShardedStylizer
+    real = None
+    try:
+        if not tdist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29591")
+            tdist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", torch.cuda.current_device()))
+        real = tdist
+    except Exception as e:      # noqa: BLE001  -- the simulation still runs, with the collectives as no-ops
+        real = None
+        note = "1-rank RCCL communicator unavailable (%s): collectives not launched" % type(e).__name__
+    else:
+        note = "all_reduce / owned broadcasts launched on a 1-rank RCCL communicator (launch cost, no link time)"
+    wct.style_prepare(style)
+    stats = {L: wct.style_export(L).clone() for L in (5, 4, 3, 2, 1)}
+    torch.cuda.synchronize()
+    res = {"world": world, "halo_mode": None, "collectives": note, "ranks": {}}
+    worst = 0.0
+    for r in ranks:
+        grp = LoopbackGroup(r, world, real)
+        grp.style_stats = stats
+        sh = ShardedStylizer(wct, grp, H4, W4, HS, WS, halo_mode="auto")
+        res["halo_mode"] = sh.halo_mode
+        x0, x1 = sh.input_columns()
+        strip = c4[:, :, x0:x1].contiguous()
+        for _ in range(2):
+            sh.stylize_strip(strip, style)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(frames):
+            out = sh.stylize_strip(strip, style)
+        t1 = time.perf_counter()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        assert bool(torch.isfinite(out).all())
+        ms = (t2 - t0) / frames * 1e3
+        worst = max(worst, ms)
+        res["ranks"][str(r)] = {"columns_in": x1 - x0, "columns_owned": sh.own[1] - sh.own[0], "ms_per_frame": round(ms, 3),
+                                "host_enqueue_ms": round((t1 - t0) / frames * 1e3, 3)}
+    if real is not None and tdist.is_initialized():
+        tdist.destroy_process_group()
+    res["predicted_8gpu_ms_per_frame"] = round(worst, 3)
+    res["predicted_8gpu_MPs"] = round(H4 * W4 / 1e6 / worst * 1e3, 1)
+    res["predicted_speedup_vs_1gpu"] = round(ms_untiled / worst, 2)
+    res["note"] = "compute + orchestration of the slowest simulated rank; xGMI transfer time (<= 3.5 MB per exchange, 132 KB per all-reduce) and rank skew not included"
+    return res
 
 
 if __name__ == "__main__":

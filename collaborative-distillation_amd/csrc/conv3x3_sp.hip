@@ -290,7 +290,7 @@ __global__ __launch_bounds__(512) void conv3x3_sp_kernel(SpArgs a) {
 #pragma unroll
     for (int k = 0; k < NPIECE; ++k) epilogue_piece(pend, k, pty0, ptx0, pgrp);
   }
-  if (satmask != 0ull && lane == 0 && a.sat) atomicAdd(a.sat, 1u);
+  if (satmask != 0ull && lane == 0 && a.sat) sat_raise(a.sat);
 #ifdef WCT_SP_TIMING
   SP_STAMP(2);
   if (threadIdx.x == 0) for (int i = 0; i < 4; ++i) atomicAdd(&g_sp_t[i], spt[i]);
@@ -474,7 +474,7 @@ __global__ __launch_bounds__(512) void conv3x3_sp_up_kernel(SpArgs a) {
 #pragma unroll
     for (int k = 0; k < NPIECE; ++k) epilogue_piece(pend, k, pty0, ptx0, pgrp);
   }
-  if (satmask != 0ull && lane == 0 && a.sat) atomicAdd(a.sat, 1u);
+  if (satmask != 0ull && lane == 0 && a.sat) sat_raise(a.sat);
 }
 
 template <typename K>

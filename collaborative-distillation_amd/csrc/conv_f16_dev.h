@@ -41,12 +41,17 @@ typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 struct SatTrack {
   float m = 0.f;
   unsigned mu = 0u;
+  // running maximum of fp32 values that were COMPUTED inside the path (finite f16 operands, finite weights -- checked at load --
+  // accumulated in fp32: never NaN)
   __device__ __forceinline__ void note(const f32x4& v) {
     m = fmaxf(fmaxf(m, fabsf(v[0])), fabsf(v[1]));
     m = fmaxf(fmaxf(m, fabsf(v[2])), fabsf(v[3]));
   }
-  __device__ __forceinline__ void note3(float a, float b, float c) { m = fmaxf(fmaxf(m, fabsf(a)), fabsf(b)); m = fmaxf(m, fabsf(c)); }
-  // hi0 / hi1: two packed f16 pairs; nonneg (uniform): the values went through a ReLU, so their sign bits are clear
+  // hi0 / hi1: two packed pairs of hi halves of values ALREADY clamped with v_med3_f32(x, -65504 | 0, 65504); nonneg (uniform): the
+  // values went through a ReLU, so their sign bits are clear.  A value at the clamp bound (0x7BFF) counts as clamped.  This is
+  // also the NaN check of EXTERNAL data (images, fp32 feature maps handed in through the API): v_max ignores a NaN operand, but
+  // v_med3_f32 returns the minimum of the other two for one, i.e. -65504 -> 0xFBFF -> flagged here (the fp32 reference would
+  // have propagated the NaN; this path turns it into finite garbage, so it must at least say so).
   __device__ __forceinline__ void note_hi(unsigned hi0, unsigned hi1, bool nonneg) {
     if (!nonneg) { hi0 &= 0x7fff7fffu; hi1 &= 0x7fff7fffu; }
     u16x2 a = __builtin_bit_cast(u16x2, mu);
@@ -55,7 +60,7 @@ struct SatTrack {
     mu = __builtin_bit_cast(unsigned, a);
   }
   __device__ __forceinline__ void commit(unsigned* counter) const {
-    if (counter && (m > 65504.f || (mu & 0xffffu) >= 0x7BFFu || (mu >> 16) >= 0x7BFFu)) atomicAdd(counter, 1u);
+    if (counter && (m > 65504.f || (mu & 0xffffu) >= 0x7BFFu || (mu >> 16) >= 0x7BFFu)) sat_raise(counter);
   }
 };
 
@@ -79,12 +84,12 @@ __device__ __forceinline__ float clamp_pm(float x) { return __builtin_amdgcn_fme
 __device__ __forceinline__ float clamp_relu(float x) { return __builtin_amdgcn_fmed3f(x, 0.f, 65504.f); }   // ReLU and the upper clamp in one
 
 __device__ __forceinline__ void split8(const f32x4& a, const f32x4& b, f16x8& hi, f16x8& lo, SatTrack& sat) {
-  sat.note(a); sat.note(b);
   u32x4 h, l;
   { const HiLo t_ = split2(clamp_pm(a[0]), clamp_pm(a[1])); h[0] = t_.hi; l[0] = t_.lo; }
   { const HiLo t_ = split2(clamp_pm(a[2]), clamp_pm(a[3])); h[1] = t_.hi; l[1] = t_.lo; }
   { const HiLo t_ = split2(clamp_pm(b[0]), clamp_pm(b[1])); h[2] = t_.hi; l[2] = t_.lo; }
   { const HiLo t_ = split2(clamp_pm(b[2]), clamp_pm(b[3])); h[3] = t_.hi; l[3] = t_.lo; }
+  sat.note_hi(h[0], h[1], false); sat.note_hi(h[2], h[3], false);   // external fp32 data: range AND NaN (see SatTrack)
   hi = __builtin_bit_cast(f16x8, h);
   lo = __builtin_bit_cast(f16x8, l);
 }
@@ -236,11 +241,11 @@ __device__ __forceinline__ void head_commit(const float (&r)[2][3], u32x2* imgH,
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
     const int e = tid + NT * k;
-    sat.note3(r[k][0], r[k][1], r[k][2]);
     if (e < NPI) {
       u32x2 h, l;
       { const HiLo t_ = split2(clamp_pm(r[k][0]), clamp_pm(r[k][1])); h[0] = t_.hi; l[0] = t_.lo; }
       { const HiLo t_ = split2(clamp_pm(r[k][2]), 0.f); h[1] = t_.hi; l[1] = t_.lo; }
+      sat.note_hi(h[0], h[1], false);   // the image is external data: range AND NaN (see SatTrack)
       imgH[e] = h;
       imgL[e] = l;
     }

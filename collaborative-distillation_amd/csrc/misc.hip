@@ -281,3 +281,12 @@ hipError_t launch_pack_center_tap(const double* M, const double* b, int C, int c
   hipLaunchKernelGGL(pack_center_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, M, b, C, cout_pad, wpk_out, bias_out);
   return hipGetLastError();
 }
+
+namespace {
+__global__ void counter_to_f64_kernel(const unsigned* counter, double* dst) { *dst = (double)*counter; }
+}  // namespace
+
+hipError_t launch_counter_to_f64(const unsigned* counter, double* dst, hipStream_t s) {
+  hipLaunchKernelGGL(counter_to_f64_kernel, dim3(1), dim3(1), 0, s, counter, dst);
+  return hipGetLastError();
+}

@@ -42,9 +42,10 @@ struct Module {
 // weight tables of one resize axis on the device (resize.hip)
 struct ResizeAxis {
   int in_size = 0, out_size = 0, ksize = 0, first = 0, last = 0;   // [first, last): input rows / columns any output touches
-  int* bounds = nullptr;          // [2 * out]
+  int* bounds = nullptr;          // [2 * out]            -- the three tables share ONE allocation (base = bounds)
   int* bounds_shifted = nullptr;  // the same with `first` subtracted from every start (the vertical pass reads a cropped image)
   int* kk = nullptr;              // [out * ksize]
+  unsigned long long used = 0;    // LRU stamp
 };
 
 struct ProfRec {
@@ -74,7 +75,8 @@ struct wct_ctx {
   int cur_level = 0, cur_h = 0, cur_w = 0;  // content feature held in featC by wct_content_encode
   DevBuf u8c, u8s, u8o;   // fp32 planar staging of wct_stylize_u8 (content, style, result)
   DevBuf rsz_tmp;         // wct_resize_u8: uint8 image between the horizontal and the vertical pass
-  std::vector<ResizeAxis> rsz_axes;   // weight tables per (in, out) size, built on first use
+  std::vector<ResizeAxis> rsz_axes;   // weight tables per (in, out) size, built on first use; least recently used evicted at 16
+  unsigned long long rsz_clock = 0;
   DevBuf l1img;       // level 1 fused: copy of the content image between wct_content_encode and wct_content_decode
   int cur_H = 0, cur_W = 0;
   int numpy_variant = 0;  // 1: `--numpy` semantics (util_wct.py:143): + I on the CONTENT covariance
@@ -86,7 +88,8 @@ struct wct_ctx {
   int fuse = 1;       // 1: fused conv11+conv12+pool / conv12+conv11 kernels at the full-resolution ends of the 16x networks
   int overlap = 1;    // 1: style side on the side lane (overlaps the content side); 0: everything on the caller's stream
   int conv_mode = 1;  // 0: exact-fp32 MFMA everywhere; 1: split-f16 (f16x3) MFMA for all but the first conv
-  unsigned* sat_dev = nullptr;   // sticky saturation counter (conv_f16_dev.h SatTrack): threads that clamped an activation to +-65504
+  unsigned* sat_dev = nullptr;   // saturation counter (conv_f16_dev.h SatTrack): threads that clamped an activation to +-65504 (saturating)
+  unsigned* sat_host = nullptr;  // pinned host mirror, refreshed asynchronously at the end of every compute entry point (wct_range_poll)
   // profiling
   bool prof = false;
   std::vector<ProfRec> recs;
@@ -127,6 +130,13 @@ struct DevGuard {
   DevGuard& operator=(const DevGuard&) = delete;
 };
 #define WCT_GUARD(ctx) DevGuard dev_guard__(ctx)
+
+// the saturation counter follows every compute entry point to pinned host memory on the caller's stream (4 bytes, no sync):
+// wct_range_poll then reports a clamp of any COMPLETED call without stalling the pipeline
+int range_readback(wct_ctx* ctx) {
+  if (ctx->sat_host) HIPCHK(ctx, hipMemcpyAsync(ctx->sat_host, ctx->sat_dev, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->main.stream));
+  return WCT_OK;
+}
 
 int ensure(wct_ctx* ctx, DevBuf& b, size_t bytes) {
   if (b.cap >= bytes) return WCT_OK;
@@ -775,6 +785,8 @@ int wct_create(int device, wct_ctx** out) {
   ok = ok && hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess;
   for (int l = 1; l <= 5 && ok; ++l) ok = hipEventCreateWithFlags(&c->ev_style[l], hipEventDisableTiming) == hipSuccess;
   ok = ok && hipMalloc(reinterpret_cast<void**>(&c->sat_dev), 256) == hipSuccess && hipMemset(c->sat_dev, 0, 256) == hipSuccess;
+  ok = ok && hipHostMalloc(reinterpret_cast<void**>(&c->sat_host), 64, hipHostMallocDefault) == hipSuccess;
+  if (ok) *c->sat_host = 0u;
   if (!ok) { wct_destroy(c); return WCT_ERR_HIP; }
   *out = c;
   return WCT_OK;
@@ -792,7 +804,7 @@ void wct_destroy(wct_ctx* ctx) {
   for (Lane* ln : {&ctx->main, &ctx->side})
     for (DevBuf* b : {&ln->actA, &ln->actB, &ln->wsMom, &ln->wsEig, &ln->sums}) release(*b);
   for (DevBuf* b : {&ctx->featC, &ctx->featS, &ctx->tmpT, &ctx->wsAsm, &ctx->small, &ctx->foldW, &ctx->foldW16, &ctx->eigC, &ctx->l1img, &ctx->u8c, &ctx->u8s, &ctx->u8o, &ctx->rsz_tmp}) release(*b);
-  for (ResizeAxis& a : ctx->rsz_axes) { (void)hipFree(a.bounds); (void)hipFree(a.bounds_shifted); (void)hipFree(a.kk); }
+  for (ResizeAxis& a : ctx->rsz_axes) (void)hipFree(a.bounds);
   ctx->rsz_axes.clear();
   for (int l = 0; l < 6; ++l) {
     release(ctx->eigS[l]);
@@ -801,6 +813,7 @@ void wct_destroy(wct_ctx* ctx) {
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
   if (ctx->side.stream) (void)hipStreamDestroy(ctx->side.stream);
   if (ctx->sat_dev) (void)hipFree(ctx->sat_dev);
+  if (ctx->sat_host) (void)hipHostFree(ctx->sat_host);
   }
   delete ctx;
 }
@@ -821,8 +834,14 @@ int wct_sync(wct_ctx* ctx) {
   HIPCHK(ctx, hipStreamSynchronize(ctx->main.stream));
   unsigned n = 0;
   HIPCHK(ctx, hipMemcpy(&n, ctx->sat_dev, sizeof n, hipMemcpyDeviceToHost));
-  if (n) return fail(ctx, WCT_ERR_RANGE, "%u thread(s) clamped an activation to the f16x3 range (|x| > 65504): results deviate from the fp32 "
-                     "reference; use conv mode 0 (exact fp32) for these weights / inputs.  wct_saturation_count(ctx, 1, ..) resets the flag", n);
+  if (n) {
+    // reported ONCE and cleared: a later WCT_ERR_RANGE then means a later clamp, not a stale flag (the total stays readable
+    // through wct_saturation_count until this point only)
+    HIPCHK(ctx, hipMemset(ctx->sat_dev, 0, sizeof n));
+    if (ctx->sat_host) *ctx->sat_host = 0u;
+    return fail(ctx, WCT_ERR_RANGE, "%u thread(s) clamped an activation to the f16x3 range (|x| > 65504, or NaN) since the last report: results "
+                "deviate from the fp32 reference; use conv mode 0 (exact fp32) for these weights / inputs.  The flag is now cleared", n);
+  }
   return WCT_OK;
 }
 
@@ -834,7 +853,22 @@ int wct_saturation_count(wct_ctx* ctx, int reset, unsigned long long* count) {
   unsigned n = 0;
   HIPCHK(ctx, hipMemcpy(&n, ctx->sat_dev, sizeof n, hipMemcpyDeviceToHost));
   if (reset && n) HIPCHK(ctx, hipMemset(ctx->sat_dev, 0, sizeof n));
+  if (ctx->sat_host) *ctx->sat_host = reset ? 0u : n;
   if (count) *count = n;
+  return WCT_OK;
+}
+
+int wct_range_poll(wct_ctx* ctx, unsigned long long* count) {
+  if (!ctx || !count) return WCT_ERR_INVALID;
+  *count = ctx->sat_host ? *reinterpret_cast<volatile unsigned*>(ctx->sat_host) : 0u;
+  return WCT_OK;
+}
+
+int wct_range_flag_f64(wct_ctx* ctx, double* flag_dev) {
+  if (!ctx) return WCT_ERR_INVALID;
+  WCT_GUARD(ctx);
+  if (!flag_dev) return fail(ctx, WCT_ERR_INVALID, "range_flag_f64: NULL pointer");
+  HIPCHK(ctx, launch_counter_to_f64(ctx->sat_dev, flag_dev, ctx->main.stream));
   return WCT_OK;
 }
 
@@ -880,6 +914,10 @@ int wct_load_module(wct_ctx* ctx, int kind, int level, int n_layers, const wct_l
     if (kind == WCT_KIND_DEC && last && L.cout != 3) return fail(ctx, WCT_ERR_INVALID, "decoder must end in 3 channels");
     if (!(kind == WCT_KIND_ENC && first) && (L.cin & 3)) return fail(ctx, WCT_ERR_INVALID, "layer %d: cin %d must be a multiple of 4", i, L.cin);
     if (!(kind == WCT_KIND_DEC && last) && (L.cout & 3)) return fail(ctx, WCT_ERR_INVALID, "layer %d: cout %d must be a multiple of 4", i, L.cout);
+    for (size_t e = 0; e < (size_t)L.cout * L.cin * 9; ++e)
+      if (!std::isfinite(L.weight[e])) return fail(ctx, WCT_ERR_INVALID, "load_module: layer %d has a non-finite weight", i);
+    for (int e = 0; e < L.cout; ++e)
+      if (!std::isfinite(L.bias[e])) return fail(ctx, WCT_ERR_INVALID, "load_module: layer %d has a non-finite bias", i);
     if (kind == WCT_KIND_ENC && last && L.pool_after) return fail(ctx, WCT_ERR_INVALID, "encoder cannot end in a pool");
     if (kind == WCT_KIND_DEC && last && L.up_after) return fail(ctx, WCT_ERR_INVALID, "decoder cannot end in an upsample");
   }
@@ -981,14 +1019,17 @@ int wct_encode(wct_ctx* ctx, int level, const float* img, int H, int W, float* f
   if (!ctx) return WCT_ERR_INVALID;
   WCT_GUARD(ctx);
   if (!valid_level(level) || !img || !feat || H < 1 || W < 1) return fail(ctx, WCT_ERR_INVALID, "encode: bad arguments");
-  if (layout == WCT_LAYOUT_NHWC) return encode_impl(ctx, ctx->main, level, img, H, W, feat, nullptr, nullptr);
+  if (layout == WCT_LAYOUT_NHWC) {
+    if (int rc = encode_impl(ctx, ctx->main, level, img, H, W, feat, nullptr, nullptr)) return rc;
+    return range_readback(ctx);
+  }
   if (layout != WCT_LAYOUT_NCHW) return fail(ctx, WCT_ERR_INVALID, "encode: bad layout %d", layout);
   int C, h, w;
   if (int rc = wct_feature_shape(ctx, level, H, W, &C, &h, &w)) return fail(ctx, rc, "encoder %d not loaded", level);
   if (int rc = ensure(ctx, ctx->tmpT, (size_t)h * w * C * sizeof(float))) return rc;
   if (int rc = encode_impl(ctx, ctx->main, level, img, H, W, reinterpret_cast<float*>(ctx->tmpT.p), nullptr, nullptr)) return rc;
   HIPCHK(ctx, launch_nhwc_to_nchw(reinterpret_cast<float*>(ctx->tmpT.p), feat, C, h * w, ctx->main.stream));
-  return WCT_OK;
+  return range_readback(ctx);
 }
 
 int wct_decode(wct_ctx* ctx, int level, const float* feat, int h, int w, int layout, float* img) {
@@ -1006,7 +1047,8 @@ int wct_decode(wct_ctx* ctx, int level, const float* feat, int h, int w, int lay
   } else if (layout != WCT_LAYOUT_NHWC) {
     return fail(ctx, WCT_ERR_INVALID, "decode: bad layout %d", layout);
   }
-  return decode_impl(ctx, level, f, h, w, nullptr, img);
+  if (int rc = decode_impl(ctx, level, f, h, w, nullptr, img)) return rc;
+  return range_readback(ctx);
 }
 
 int wct_moments(wct_ctx* ctx, const float* feat, int C, int h, int w, int x0, int x1, double* sum, double* sumsq) {
@@ -1092,7 +1134,8 @@ int wct_decode_affine(wct_ctx* ctx, int level, const float* feat, int h, int w, 
   if (!valid_level(level) || !feat || !M || !b || !img) return fail(ctx, WCT_ERR_INVALID, "decode_affine: bad arguments");
   ConvDesc first;
   if (int rc = fold_impl(ctx, level, M, b, first)) return rc;
-  return decode_impl(ctx, level, feat, h, w, &first, img);
+  if (int rc = decode_impl(ctx, level, feat, h, w, &first, img)) return rc;
+  return range_readback(ctx);
 }
 
 int wct_style_transfer_level(wct_ctx* ctx, int level, const float* content, int H, int W, const float* style, int Hs,
@@ -1102,7 +1145,8 @@ int wct_style_transfer_level(wct_ctx* ctx, int level, const float* content, int 
   if (!valid_level(level) || !content || !style || !out) return fail(ctx, WCT_ERR_INVALID, "style_transfer_level: bad arguments");
   if (int rc = fork_side(ctx)) return rc;
   if (int rc = style_side(ctx, level, style, Hs, Ws)) return rc;
-  return content_side(ctx, level, content, H, W, alpha, out, Ho, Wo);
+  if (int rc = content_side(ctx, level, content, H, W, alpha, out, Ho, Wo)) return rc;
+  return range_readback(ctx);
 }
 
 // ---- split form of a level, for content-sharded runs (wct_hip/sharded.py): the caller all-reduces the moments
@@ -1220,7 +1264,7 @@ int wct_content_decode(wct_ctx* ctx, int level, const double* M, const double* b
   }
   if (Ho) *Ho = ctx->cur_h << (level - 1);
   if (Wo) *Wo = ctx->cur_w << (level - 1);
-  return WCT_OK;
+  return range_readback(ctx);
 }
 
 namespace {
@@ -1242,7 +1286,7 @@ int cascade(wct_ctx* ctx, const float* content, int H, int W, float alpha, int n
   if (cur != out) HIPCHK(ctx, hipMemcpyAsync(out, cur, (size_t)3 * h * w * sizeof(float), hipMemcpyDeviceToDevice, ctx->main.stream));
   if (Ho) *Ho = h;
   if (Wo) *Wo = w;
-  return WCT_OK;
+  return range_readback(ctx);
 }
 }  // namespace
 
@@ -1321,12 +1365,14 @@ int wct_resize_shape(int H, int W, int size, int* oH, int* oW) {
 
 namespace {
 int resize_axis(wct_ctx* ctx, int in_size, int out_size, const ResizeAxis** out) {
-  for (const ResizeAxis& a : ctx->rsz_axes)
-    if (a.in_size == in_size && a.out_size == out_size) { *out = &a; return WCT_OK; }
-  if (ctx->rsz_axes.size() >= 16) {   // a bounded cache: drop everything (nothing in flight may still read the tables)
-    HIPCHK(ctx, hipStreamSynchronize(ctx->main.stream));
-    for (ResizeAxis& a : ctx->rsz_axes) { (void)hipFree(a.bounds); (void)hipFree(a.bounds_shifted); (void)hipFree(a.kk); }
-    ctx->rsz_axes.clear();
+  for (ResizeAxis& a : ctx->rsz_axes)
+    if (a.in_size == in_size && a.out_size == out_size) { a.used = ++ctx->rsz_clock; *out = &a; return WCT_OK; }
+  if (ctx->rsz_axes.size() >= 16) {   // a bounded cache: evict the least recently used entry (hipFree waits for kernels still reading it)
+    size_t lru = 0;
+    for (size_t i = 1; i < ctx->rsz_axes.size(); ++i)
+      if (ctx->rsz_axes[i].used < ctx->rsz_axes[lru].used) lru = i;
+    (void)hipFree(ctx->rsz_axes[lru].bounds);
+    ctx->rsz_axes.erase(ctx->rsz_axes.begin() + (long)lru);
   }
   std::vector<int> bounds, kk;
   ResizeAxis a;
@@ -1334,14 +1380,20 @@ int resize_axis(wct_ctx* ctx, int in_size, int out_size, const ResizeAxis** out)
   resize_axis_tables(in_size, out_size, a.ksize, bounds, kk);
   a.first = bounds[0];
   a.last = bounds[2 * (size_t)(out_size - 1)] + bounds[2 * (size_t)(out_size - 1) + 1];
-  std::vector<int> shifted(bounds);
-  for (int i = 0; i < out_size; ++i) shifted[2 * (size_t)i] -= a.first;
-  HIPCHK(ctx, hipMalloc(&a.bounds, bounds.size() * sizeof(int)));
-  HIPCHK(ctx, hipMalloc(&a.bounds_shifted, bounds.size() * sizeof(int)));
-  HIPCHK(ctx, hipMalloc(&a.kk, kk.size() * sizeof(int)));
-  HIPCHK(ctx, hipMemcpy(a.bounds, bounds.data(), bounds.size() * sizeof(int), hipMemcpyHostToDevice));
-  HIPCHK(ctx, hipMemcpy(a.bounds_shifted, shifted.data(), shifted.size() * sizeof(int), hipMemcpyHostToDevice));
-  HIPCHK(ctx, hipMemcpy(a.kk, kk.data(), kk.size() * sizeof(int), hipMemcpyHostToDevice));
+  // bounds | shifted bounds | kk in ONE allocation and ONE copy: nothing to leak when a call fails part-way
+  std::vector<int> tab(2 * bounds.size() + kk.size());
+  std::copy(bounds.begin(), bounds.end(), tab.begin());
+  std::copy(bounds.begin(), bounds.end(), tab.begin() + (long)bounds.size());
+  for (int i = 0; i < out_size; ++i) tab[bounds.size() + 2 * (size_t)i] -= a.first;
+  std::copy(kk.begin(), kk.end(), tab.begin() + 2 * (long)bounds.size());
+  int* dev = nullptr;
+  HIPCHK(ctx, hipMalloc(reinterpret_cast<void**>(&dev), tab.size() * sizeof(int)));
+  if (hipError_t e = hipMemcpy(dev, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice); e != hipSuccess) {
+    (void)hipFree(dev);
+    return fail(ctx, WCT_ERR_HIP, "resize tables: %s", hipGetErrorString(e));
+  }
+  a.bounds = dev; a.bounds_shifted = dev + bounds.size(); a.kk = dev + 2 * bounds.size();
+  a.used = ++ctx->rsz_clock;
   ctx->rsz_axes.push_back(a);
   *out = &ctx->rsz_axes.back();
   return WCT_OK;
@@ -1350,12 +1402,12 @@ int resize_axis(wct_ctx* ctx, int in_size, int out_size, const ResizeAxis** out)
 int resize_impl(wct_ctx* ctx, const uint8_t* src, int H, int W, int oH, int oW, uint8_t* dst, float* planar) {
   if (!src || (!dst && !planar) || H < 1 || W < 1 || oH < 1 || oW < 1 || H > 65535 || oH > 65535)
     return fail(ctx, WCT_ERR_INVALID, "resize_u8: bad arguments (%dx%d -> %dx%d)", H, W, oH, oW);
-  if ((reinterpret_cast<size_t>(src) & 3) != 0) return fail(ctx, WCT_ERR_INVALID, "resize_u8: source not 4-byte aligned");
   const ResizeAxis *ax = nullptr, *ay = nullptr;
-  // the vector may reallocate when the second axis is added: look both up again afterwards
+  // the vector may reallocate (or evict) when the second axis is added: look the first one up again afterwards
   if (int rc = resize_axis(ctx, W, oW, &ax)) return rc;
   if (int rc = resize_axis(ctx, H, oH, &ay)) return rc;
   if (int rc = resize_axis(ctx, W, oW, &ax)) return rc;
+  if (int rc = resize_axis(ctx, H, oH, &ay)) return rc;
   const bool need_h = oW != W, need_v = oH != H;
   const int row0 = need_v ? ay->first : 0, rows = need_v ? ay->last - ay->first : H;
   if (need_h && (need_v || planar))

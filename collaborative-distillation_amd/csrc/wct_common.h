@@ -18,6 +18,13 @@ static inline const char* wct_debug_env(const char* name) {
   return getenv(name);
 }
 
+// The context's saturation counter (wct_api.hip sat_dev): +1 per thread (or wave) that clamped an activation, SATURATING -- the
+// thread that wraps the 32-bit counter sees old == 0xffffffff itself and pins it at 2^31 (so does every add above it).
+__device__ __forceinline__ void sat_raise(unsigned* counter) {
+  const unsigned old = atomicAdd(counter, 1u);
+  if (old >= 0x80000000u) atomicMax(counter, 0x80000000u);
+}
+
 // K layout of the 3-channel first conv on 16x16x32 f16 MFMAs (conv_f16_dev.h l1_conv_group, enc_head_kernel; host packing
 // wct_api.hip pack_head_f16): 27 "singles" (split term 0: w_hi x_hi, 1: w_hi x_lo, 2: w_lo x_hi; window position pos = 3 dy + dx;
 // 4 halfs RGB0 each) in 4 K-steps x 4 lane groups x 2.  One ds_read_b64 serves 32 lanes = two lane groups: their two singles are
@@ -109,6 +116,8 @@ hipError_t launch_split_pack_phase(const float* wpk32, int cin, const unsigned* 
 // ---- image edge: uint8 HWC <-> planar fp32 (ToTensor / save_image of the reference's harness)
 hipError_t launch_u8_to_planar(const uint8_t* hwc, long npix, float* planar, hipStream_t s);
 hipError_t launch_planar_to_u8(const float* planar, long npix, uint8_t* hwc, int round_mode, hipStream_t s);
+// *dst = (double)*counter on the stream (wct_range_flag_f64: the saturation counter as a value a sharded run can all-reduce)
+hipError_t launch_counter_to_f64(const unsigned* counter, double* dst, hipStream_t s);
 // ---- image edge: transforms.Resize = Pillow's bilinear resampler, bit-exact (resize.hip)
 void resize_axis_tables(int in_size, int out_size, int& ksize, std::vector<int>& bounds, std::vector<int>& kk);   // host
 hipError_t launch_resize_u8(const uint8_t* in, int H, int W, int oH, int oW, const int* bounds_h, const int* kk_h, int ksize_h,

@@ -92,10 +92,28 @@ class ShardedStylizer:
             raise ValueError("halo_mode='exchange' needs strips of at least %d columns (narrowest: %d)" % (2 * LEVEL_HALO[4], narrowest))
         self.halo_mode = halo_mode
         self.halo = LEVEL_HALO if halo_mode == "exchange" else CUM_HALO
+        self._range = None          # (pinned host value, event): f16x3 clamps of ANY rank during the last stylize_strip
 
     def input_columns(self) -> Tuple[int, int]:
         """Columns of the full content image this rank must be given (its strip + the level-5 halo of its halo mode)."""
         return ext_bounds(self.own, self.W, self.halo[5])
+
+    # ---- f16x3 range flag, node-wide
+    def check_range(self, wait: bool = True) -> None:
+        """Raise OverflowError on EVERY rank if any rank's f16x3 kernels clamped an activation during the last stylize_strip (each
+        rank's saturation counter rides in the all-reduce of the moments, so all ranks hold the same total and raise -- or fall
+        back to set_conv_mode('fp32') -- together).  wait=False: only if the value has already landed (no synchronisation)."""
+        if self._range is None:
+            return
+        host, ev = self._range
+        if not wait and not ev.query():
+            return
+        ev.synchronize()
+        self._range = None
+        if float(host[0]) > 0:
+            raise OverflowError("wct_hip.sharded: %d activation(s) were clamped to the f16x3 range on some rank(s) of this job: the "
+                                "frame deviates from the fp32 reference; every rank should switch to set_conv_mode('fp32') and "
+                                "acknowledge with saturation_count(reset=True)" % int(host[0]))
 
     # ---- neighbour exchange (halo_mode "exchange")
     def _p2p(self, sends, recvs):
@@ -154,6 +172,9 @@ class ShardedStylizer:
           content_decode(L, M, b, H, W) -> image     decoder with (M, b) folded into its first conv
         """
         e, dist = self.e, self.dist
+        self.check_range(wait=False)     # the previous frame's node-wide flag, if it has landed
+        range_flag = getattr(e, "range_flag", None)
+        flags = []
         img = content_ext if content_ext.dim() == 4 else content_ext[None]
         W_cur = self.W                       # width of the (virtual) full image at the current level
         own = self.own
@@ -175,9 +196,14 @@ class ShardedStylizer:
             f1 = -1 if own[1] >= W_cur else (own[1] - lo) >> sh        # last strip: to the (floored) end
             h, w_ext, sum_c, sumsq_c = e.content_encode(L, img, f0, f1)
             C = int(sum_c.numel())
-            packed = torch.cat([sum_c.reshape(-1), sumsq_c.reshape(-1)])
+            parts = [sum_c.reshape(-1), sumsq_c.reshape(-1)]
+            if range_flag is not None:
+                parts.append(range_flag())                             # this rank's f16x3 clamp counter so far: summed over the ranks below
+            packed = torch.cat(parts)
             if self.world > 1:
-                dist.all_reduce(packed)                                # SUM, fp64, C*C + C values
+                dist.all_reduce(packed)                                # SUM, fp64, C*C + C (+ 1) values
+            if range_flag is not None:
+                flags.append(packed[C + C * C:])
             solvers = (0,) if self.broadcast_map else range(self.world)   # ranks that need the level's style statistics
             if self.world > 1 and any(r != owner(L) for r in solvers):
                 if rank == owner(L):
@@ -191,13 +217,13 @@ class ShardedStylizer:
             if self.broadcast_map and self.world > 1:
                 Mb = torch.empty(C * C + C, dtype=torch.float64, device=packed.device)
                 if rank == 0:
-                    M, b = e.content_solve(L, n_c, packed[:C], packed[C:].reshape(C, C), self.alpha)
+                    M, b = e.content_solve(L, n_c, packed[:C], packed[C:C + C * C].reshape(C, C), self.alpha)
                     Mb[:C * C] = M.reshape(-1)
                     Mb[C * C:] = b
                 dist.broadcast(Mb, src=0)                              # the colouring map, identical on every rank
                 M, b = Mb[:C * C].reshape(C, C), Mb[C * C:]
             else:
-                M, b = e.content_solve(L, n_c, packed[:C], packed[C:].reshape(C, C), self.alpha)
+                M, b = e.content_solve(L, n_c, packed[:C], packed[C:C + C * C].reshape(C, C), self.alpha)
             img = e.content_decode(L, M, b, H_in, W_in)               # [1,3,h<<sh, w_ext<<sh]
             # floor-mode pooling may have dropped trailing columns/rows of the full image
             W_cur = (W_cur >> sh) << sh
@@ -207,4 +233,77 @@ class ShardedStylizer:
                 # the decoded strip is exact on the owned columns only: the next level's margin comes from the neighbours
                 img, lo = self._exchange(img, lo, own, W_cur, halo[L - 1])
                 hi = lo + int(img.shape[-1])
+        if flags:
+            # levels 5..2 are covered by later all-reduces (the counter is cumulative); level 1's decode by the next frame's
+            host = torch.zeros(1, dtype=torch.float64).pin_memory()
+            host.copy_(flags[-1], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self._range = (host, ev)
         return img[..., own[0] - lo:own[1] - lo].contiguous()
+
+
+class LoopbackGroup:
+    """ONE rank of a `world`-rank job with its peers emulated on the same GPU -- a measurement stand-in for torch.distributed
+    (bench.py `passes.cfg4_rank_sim`: what a rank of the 8-GPU config-4 job executes, timed on the one GPU there is).
+    The rank's own work is exactly the sharded path's (same ShardedStylizer code, same C-ABI calls, same torch ops); the peers'
+    contributions are replaced by data of the right shape already on the device:
+      all_reduce   forwarded to `real` (a 1-rank RCCL communicator: the collective's kernel is launched, nothing crosses a link)
+                   or a no-op; the moments stay those of the strip, so (M, b) are the strip's own -- same work, other numbers
+      broadcast    levels this rank owns: forwarded / no-op; the others: a device copy of `style_stats[level]` (set by the caller
+                   from a complete style_prepare) into the receive buffer
+      send / recv  every received halo is a device copy of the equally wide block this rank sends the other way
+    Results are NOT the sharded job's results (tests/test_sharded_*.py check those); timings are."""
+
+    class _Done:
+        def wait(self):
+            return None
+
+    def __init__(self, rank: int, world: int, real=None):
+        self.rank, self.world, self.real = rank, world, real
+        self.style_stats = {}
+        self._bcast = 0
+
+    def get_rank(self):
+        return self.rank
+
+    def get_world_size(self):
+        return self.world
+
+    def get_backend(self):
+        return "nccl"          # device buffers, no host staging (sharded._p2p)
+
+    def all_reduce(self, t, op=None):
+        if self.real is not None:
+            self.real.all_reduce(t)
+
+    def broadcast(self, t, src=0):
+        level = 5 - (self._bcast % 5)       # stylize_strip broadcasts the style statistics of levels 5..1 in turn
+        self._bcast += 1
+        if src == self.rank:
+            if self.real is not None:
+                self.real.broadcast(t, src=0)
+        else:
+            t.copy_(self.style_stats[level])
+
+    def barrier(self):
+        return None
+
+    # point-to-point: P2POp(dist.isend | dist.irecv, tensor, peer) + batch_isend_irecv(ops)
+    isend, irecv = "isend", "irecv"
+
+    @staticmethod
+    def P2POp(kind, tensor, peer):
+        return (kind, tensor, peer)
+
+    def batch_isend_irecv(self, ops):
+        sends = [t for k, t, _ in ops if k == "isend"]
+        for k, t, _ in ops:
+            if k != "irecv":
+                continue
+            src = next((s for s in sends if s.shape == t.shape), None)
+            if src is not None:
+                t.copy_(src)
+            elif sends:                      # a narrower last strip: whatever block there is, cropped
+                t.copy_(sends[0][..., :t.shape[-1]])
+        return [self._Done() for _ in ops]

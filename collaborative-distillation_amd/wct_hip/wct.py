@@ -87,6 +87,7 @@ class WCT:
         self.alpha = float(getattr(args, "alpha", 1.0))
         self.device = torch.cuda.current_device() if device is None else int(device)
         self.stats_device = "cuda:%d" % self.device   # where style_export() tensors live (wct_hip/replicas.py, sharded.py)
+        self.strict_range = True                      # see _stream(): f16x3 clamps are reported by the next call
         self._lib = _lib.load()
         self._ctx = c_void_p()
         _lib.check(self._lib, None, self._lib.wct_create(self.device, byref(self._ctx)))
@@ -179,7 +180,27 @@ class WCT:
 
     # ------------------------------------------------------------------ helpers
     def _stream(self):
+        """Called at the start of every compute method: bind the caller's stream and -- without synchronising -- raise if an
+        EARLIER call that has completed meanwhile clamped an activation to the f16x3 range (include/wct_hip.h wct_range_poll):
+        the deviation from the fp32 reference is then reported by the very next call on every path (stylize*, e*/d* modules,
+        styleTransfer, the split-level calls of sharded.py / pipeline.py / replicas.py), not only by sync().  `strict_range =
+        False` turns the check off; saturation_count(reset=True) or a reported sync() acknowledges and clears it."""
         self._lib.wct_set_stream(self._ctx, c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
+        if self.strict_range:
+            n = ctypes.c_ulonglong()
+            self._lib.wct_range_poll(self._ctx, byref(n))
+            if n.value:
+                raise OverflowError("libwct_hip: an earlier call clamped %d activation(s) to the f16x3 range (|x| >= 65504, or NaN input): "
+                                    "its results deviate from the fp32 reference.  Use set_conv_mode('fp32') for these weights / inputs; "
+                                    "saturation_count(reset=True) acknowledges the flag" % n.value)
+
+    def range_flag(self) -> torch.Tensor:
+        """The saturation counter NOW (in stream order) as a 1-element fp64 device tensor -- what a sharded run folds into the
+        all-reduce of its moments so that every rank learns of a clamp on any rank (wct_range_flag_f64)."""
+        t = torch.empty(1, device=self.stats_device, dtype=torch.float64)
+        self._lib.wct_set_stream(self._ctx, c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
+        self._chk(self._lib.wct_range_flag_f64(self._ctx, t.data_ptr()))
+        return t
 
     def _img(self, x: torch.Tensor) -> torch.Tensor:
         if x.dim() == 4:
@@ -194,8 +215,9 @@ class WCT:
         _lib.check(self._lib, self._ctx, rc)
 
     def saturation_count(self, reset: bool = False) -> int:
-        """Threads of the f16x3 kernels that clamped an activation to +-65504 since the last reset (a deviation from the
-        fp32 reference; synchronises the context's streams).  sync() raises OverflowError while it is non-zero."""
+        """Threads of the f16x3 kernels that clamped an activation to +-65504 since the last reset / report (a deviation from the
+        fp32 reference; synchronises the context's streams).  sync() raises OverflowError ONCE for a non-zero count and clears
+        it; every compute method raises while a completed call's count is non-zero (strict_range)."""
         n = ctypes.c_ulonglong()
         _lib.check(self._lib, self._ctx, self._lib.wct_saturation_count(self._ctx, int(reset), byref(n)))
         return int(n.value)

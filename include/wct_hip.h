@@ -71,16 +71,27 @@ int wct_create(int device, wct_ctx** out);
 void wct_destroy(wct_ctx* ctx);
 const char* wct_last_error(const wct_ctx* ctx);
 int wct_set_stream(wct_ctx* ctx, void* hip_stream); /* hipStream_t; NULL = default stream */
-/* waits for both of the context's streams; returns WCT_ERR_RANGE when the sticky saturation flag is raised (below) */
+/* waits for both of the context's streams; returns WCT_ERR_RANGE -- ONCE, clearing the flag -- when an activation was clamped
+ * since the last report (below), so a later WCT_ERR_RANGE always means a later clamp */
 int wct_sync(wct_ctx* ctx);
 
 /* Range check of the f16x3 arithmetic (wct_set_conv_mode 1, the default).  The reference computes its convolutions in fp32
  * (model/model_cd.py:724-743: plain nn.Conv2d); the split-f16 kernels represent an activation as hi + lo in f16 and clamp
  * it to +-65504.  A clamp that actually changed a value is a deviation from the reference, so every clamp site raises a
- * sticky per-context device counter (threads that saw |x| > 65504).  wct_saturation_count synchronises the context and
- * returns it (count may be NULL), clearing it when reset != 0; wct_sync reports a raised flag as WCT_ERR_RANGE.  Conv
- * mode 0 (exact fp32 MFMA) has no such limit. */
+ * per-context device counter (threads that saw |x| >= 65504; saturating, never wraps).  A NaN in external data (an image, an
+ * fp32 feature map handed to wct_decode*) is clamped to a finite value by the same instruction and raises the counter too;
+ * non-finite weights are rejected by wct_load_module.  Three ways to see it:
+ *   wct_saturation_count  synchronises the context and returns the counter (count may be NULL), clearing it when reset != 0
+ *   wct_sync              reports a non-zero counter as WCT_ERR_RANGE once and clears it
+ *   wct_range_poll        NO synchronisation: every compute entry point ends with an asynchronous 4-byte copy of the counter
+ *                         to pinned host memory on the caller's stream; this returns the last copy that has landed, i.e. the
+ *                         state after some COMPLETED call (callers check it at the start of their next call)
+ *   wct_range_flag_f64    writes the counter as one double to flag_dev on the caller's stream, so that a sharded run can fold it
+ *                         into the all-reduce of the moments it already makes and every rank sees every rank's clamps
+ * Conv mode 0 (exact fp32 MFMA) has no such limit. */
 int wct_saturation_count(wct_ctx* ctx, int reset, unsigned long long* count);
+int wct_range_poll(wct_ctx* ctx, unsigned long long* count);
+int wct_range_flag_f64(wct_ctx* ctx, double* flag_dev);
 
 /* Context-level experiment switches (tests, A/B measurements): key in {"fuse", "sp", "l1fuse", "u8fuse", "upconv"}, value 0 / 1.  They select
  * between kernel formulations of the same operators (fused full-resolution ends, SP16 intermediates, level 1 without
@@ -180,8 +191,9 @@ int wct_stylize_u8(wct_ctx* ctx, const uint8_t* content_hwc, int H, int W, const
  *   wct_resize_shape         torchvision's size rule: the smaller edge becomes `size` (0 or already equal: unchanged)
  *   wct_resize_u8            uint8 HWC -> uint8 HWC of oH x oW (any target size; equal sizes copy)
  *   wct_resize_u8_to_planar  the same followed by ToTensor (data_loader.py:57: planar fp32 / 255) without a uint8 round trip
- * Pointers are device pointers; the source must be 4-byte aligned.  Weight tables per (input, output) size are built on
- * the host on first use (O(W + H)) and cached in the context. */
+ * Pointers are device pointers (any alignment: the kernels read single bytes); H and oH <= 65535 (the row index is a grid
+ * dimension).  Weight tables per (input, output) size are built on the host on first use (O(W + H)) and cached in the context
+ * (16 axes, least recently used evicted). */
 int wct_resize_shape(int H, int W, int size, int* oH, int* oW);
 int wct_resize_u8(wct_ctx* ctx, const uint8_t* src_hwc, int H, int W, uint8_t* dst_hwc, int oH, int oW);
 int wct_resize_u8_to_planar(wct_ctx* ctx, const uint8_t* src_hwc, int H, int W, float* planar, int oH, int oW);

@@ -1,28 +1,22 @@
-"""GPU parity tests at BENCHMARK scale: the HIP cascade end to end at BASELINE.json's own sizes, against the CPU oracle
-and against its fp64 "truth" arm -- the error budget of an end-to-end comparison.
+"""GPU parity tests at BENCHMARK scale: the HIP cascade end to end at BASELINE.json's own sizes.
 
-Why a budget.  The 5-level cascade amplifies any fp32-level difference (every level's whitening divides by sqrt(lambda_min)),
-and uniform noise -- bench.py's input -- is its worst case.  Measured on the 1080p sample (uniform noise; max|d| / max|y|):
+THE GATE (one rule; the same in bench.py and BASELINE.md 3.5 / DESIGN.md 2).  Every full-size frame is compared with THE REFERENCE'S
+OWN PIXELS for that frame -- fixtures made by running the reference itself (util_wct.WCT, real 16x checkpoints, torch CPU) in the
+build container, tools/make_goldens.py:
+    G13  the two SYNTHETIC config-2 frames (SURVEY 8d seeds: numpy default_rng; `noise` = bench.py's timed frame, `smooth`)
+    G11  the reference's UHD sample pair (green_park 3840x2160 + style/in1.jpg 2048x2048)
+    G14  config 3: the reference's un-pruned classes with GENERATED weights (the torch7 checkpoints are absent)
+each holding a 1/16 lattice of the output + crops + a 16x-downsampled image (tests/fixture_compare.py), and
+    hip_vs_reference <= max(1e-3, 1.25 * oracle_vs_reference)        max|d| / max|reference| over every reference pixel held
+i.e. the north_star's 1e-3 wherever a second valid fp32 implementation of the reference's arithmetic (the oracle: the same op
+sequence in C loops) itself reproduces the reference to 1e-3, and otherwise no further from the reference than that (+25 %).
+Measured in the build container (oracle vs reference): noise 6.0e-4, smooth 7.7e-4, UHD pair 1.2e-5 -> the limit IS 1e-3 on all
+config-2 frames; config 3 (generated weights, five whitenings of random 512-channel stacks: chaotic) 2.3e-3 -> limit 2.9e-3
+there, with the level-isolated comparison as the sharp check.
 
-    reference arithmetic, C loops (the oracle: fp32 conv stacks, fp64 transform)    vs exact fp64     6.9e-4
-    reference arithmetic, torch CPU fp32 convolutions (oneDNN)                     vs exact fp64     4.1e-4
-    those two VALID fp32 implementations of the reference                          vs each other     9.7e-4
-    this library (f16x3)                                                           vs exact fp64     6.1e-4
-    torch fp64 convolutions vs the oracle's fp64 arm                                                 1.3e-12
-
-(tools/experiments/truth_budget_cpu.py, tools/experiments/torch_vs_oracle.py; level-isolated 3e-5 at level 5 .. 1e-6 at level
-1 in every arm.)  So the exact result ("truth" = wct_oracle with precision="fp64": the reference's algorithm, every
-activation and accumulation in fp64) is well defined to 1e-12, every fp32 implementation sits 4e-4 .. 7e-4 away from it,
-and two of them differ by about the north_star tolerance itself.  At the full config-2 size (3840x2160 + 2048x2048) the
-same arms read (MI355X box, this suite):   noise  |oracle - truth| 8.4e-4, |hip - truth| 1.06e-3, |hip - oracle| 1.12e-3;
-smooth  |oracle - truth| 1.04e-3, |hip - truth| 7.4e-4, |hip - oracle| 1.21e-3 -- on SYNTHETIC inputs the reference's own
-arithmetic does not hold 1e-3 against its own exact result.  On the reference's own UHD sample pair (natural images) the
-oracle sits 5e-5 from the truth and the gate has an order of magnitude of room.  Hence:
-    synthetic frames (noise = bench.py's timed frame, smooth)
-        |hip - truth| <= 1.5 |oracle - truth| + 1e-4     no further from the exact result than the reference's own arithmetic
-        |hip - truth| <= 1e-3 at 1080p, <= 2e-3 at 4K    absolute sanity
-    the reference's UHD sample pair at config-2 size (test_e2e_config2_reference_uhd_pair)
-        |hip - oracle| <= 1e-3, |hip - reference's own pixels| <= 1e-3        the north_star gate as written
+Beside the gate, an error budget against the exact result (test_error_budget_vs_fp64_truth, 1080p): "truth" = wct_oracle with
+precision="fp64", the reference's algorithm with every activation and accumulation in fp64 (torch's own fp64 convolutions agree
+with it to 1.3e-12); every fp32 implementation sits 4e-4 .. 7e-4 from it on uniform noise, this library included.
 Everything that can be compared level-isolated (each level on the oracle's own input) is held 10x tighter, here and in
 tests/test_hip_parity.py.
 """
@@ -34,11 +28,16 @@ import numpy as np
 import pytest
 
 from tests.conftest import rel_err
+from tests.fixture_compare import GATE, cfg2_frames, cfg3_frames, compare_to_fixture, smooth_frame as _smooth_frame
 from wct_hip import model_zoo
 
 pytestmark = pytest.mark.gpu
 
-GATE = 1e-3   # BASELINE.json north_star: 1e-3 relative per-pixel tolerance, as max|d| / max|ref|
+# GATE = 1e-3: BASELINE.json north_star, 1e-3 relative per-pixel tolerance, as max|d| / max|ref|
+
+
+def gate_limit(oracle_vs_reference):
+    return max(GATE, 1.25 * oracle_vs_reference)
 
 
 @pytest.fixture(scope="module")
@@ -58,11 +57,7 @@ def cu(torch, a):
     return torch.from_numpy(np.ascontiguousarray(a, np.float32)).cuda()
 
 
-def smooth(rng, shape, it=3):
-    x = rng.random(shape, dtype=np.float32)
-    for _ in range(it):
-        x = (x + np.roll(x, 1, 1) + np.roll(x, 1, 2) + np.roll(x, -1, 1) + np.roll(x, -1, 2)) / 5
-    return np.ascontiguousarray((x - x.min()) / (x.max() - x.min()))
+smooth = _smooth_frame
 
 
 def _threads(oracle):
@@ -75,32 +70,31 @@ def _report(name, **kv):
 
 # --------------------------------------------------------------------------- config 2 at full size, end to end
 @pytest.mark.parametrize("kind", ["noise", "smooth"])
-def test_e2e_config2_full_size(torch_cuda, wct16, oracle, weights16x, kind):
-    """BASELINE configs[1] exactly as bench.py times it: --mode 16x, 3840x2160 content + 2048x2048 style, 5 levels,
-    alpha = 1 -- the HIP cascade vs wct_oracle.stylize (the reference's op sequence, WCT.py:120-125) in its fp32 and fp64
-    arms; uniform noise (bench.py's frame, same seeds) and smooth content (dead channels, ill-conditioned covariances)."""
+def test_e2e_config2_full_size(torch_cuda, wct16, oracle, weights16x, golden, kind):
+    """BASELINE configs[1] exactly as bench.py times it: --mode 16x, 3840x2160 content + 2048x2048 style, 5 levels, alpha = 1,
+    the SURVEY 8(d) frames (numpy seeds 1 / 2; `smooth`: dead channels, ill-conditioned covariances) -- the HIP cascade against
+    the REFERENCE'S OWN OUTPUT on that frame (G13) under the one gate of this module, the oracle beside it."""
     torch = torch_cuda
     _threads(oracle)
-    if kind == "noise":     # bench.py's timed frame: torch.rand on the device, seeds 1 (content) and 2 (style)
-        c = torch.rand((3, 2160, 3840), device="cuda", generator=torch.Generator(device="cuda").manual_seed(1)).cpu().numpy()
-    else:
-        c = smooth(np.random.default_rng(101), (3, 2160, 3840))
-    s = torch.rand((3, 2048, 2048), device="cuda", generator=torch.Generator(device="cuda").manual_seed(2)).cpu().numpy()
+    g = golden("g13_cfg2_%s.npz" % kind)
+    c, s = cfg2_frames(kind)
+    assert abs(float(c.sum(dtype=np.float64)) - float(g["content.checksum"])) < 1e-6      # the seeds reproduce the reference's input
+    assert abs(float(s.sum(dtype=np.float64)) - float(g["style.checksum"])) < 1e-6
     t0 = time.time()
     ref = oracle.stylize(oracle.Modules("16x", weights16x), c, s, 1.0)
     t1 = time.time()
-    truth = oracle.stylize(oracle.Modules("16x", weights16x, precision="fp64"), c, s, 1.0)
-    t2 = time.time()
     wct16.saturation_count(reset=True)
     got = wct16.stylize(cu(torch, c), cu(torch, s)).cpu().numpy()[0]
     assert wct16.saturation_count() == 0
-    e_truth, e_ref, ref_truth = rel_err(got, truth), rel_err(got, ref), rel_err(ref, truth)
-    _report("e2e cfg2 " + kind, hip_vs_truth=e_truth, oracle_vs_truth=ref_truth, hip_vs_oracle=e_ref, gate=GATE,
-            oracle_s=round(t1 - t0, 1), truth_s=round(t2 - t1, 1))
     assert got.shape == ref.shape == (3, 2160, 3840)
-    assert e_truth <= 1.5 * ref_truth + 1e-4          # in the reference arithmetic's own accuracy class ...
-    assert e_truth <= 2 * GATE and e_ref <= e_truth + ref_truth + 1e-6
-    assert np.allclose(got, truth, rtol=2 * GATE, atol=2 * GATE * float(np.abs(truth).max()))
+    rh, ro = compare_to_fixture(got, g), compare_to_fixture(ref, g)
+    _report("e2e cfg2 " + kind, hip_vs_reference=rh["max"], oracle_vs_reference=ro["max"], limit=gate_limit(ro["max"]),
+            hip_p9999=rh["lattice_p9999"], oracle_p9999=ro["lattice_p9999"], hip_frac_gt_1e3=rh["lattice_frac_gt_gate"],
+            hip_down16=rh["down16_max"], hip_vs_oracle=rel_err(got, ref), reference_pixels=rh["lattice_pixels"], oracle_s=round(t1 - t0, 1))
+    assert ro["max"] <= GATE                                   # the oracle reproduces the reference on this frame: the limit is 1e-3
+    assert rh["max"] <= gate_limit(ro["max"])                  # THE GATE
+    assert rh["down16_max"] <= GATE / 4 and rh["mean_diff"] <= 1e-5
+    assert rh["lattice_p9999"] <= GATE / 2                     # and it is not a near miss everywhere: 99.99 % of the pixels within 5e-4
 
 
 def test_e2e_config2_reference_uhd_pair(torch_cuda, wct16, oracle, weights16x, golden):
@@ -187,20 +181,21 @@ def test_error_budget_vs_fp64_truth(torch_cuda, oracle, weights16x, kind):
 
 
 # --------------------------------------------------------------------------- config 3: --mode original at 1920x1080
-def test_e2e_config3_original_mode(torch_cuda, oracle):
+def test_e2e_config3_original_mode(torch_cuda, oracle, golden):
     """BASELINE configs[2]: --mode original (un-pruned VGG-19 graph, 512/512/256/128/64 channels), 1920x1080 content and
     style -> 1920x1072 output.  The torch7 checkpoints are absent from the reference snapshot (README.md:26), so the
-    weights are the generated set model_zoo.synth_weights("original", seed) (real-weight parity unpinned).  With
-    random 512-channel stacks the cascade is chaotic at the level of the reference's OWN arithmetic (oracle fp32 vs fp64 truth:
-    1e-3 .. 4e-3 end to end, He-uniform and orthogonalised weights alike), so:
-      level-isolated (each level on the truth's level input)   |hip - truth| <= 1.5 |oracle - truth| + 2e-5, and <= 5e-4
-      end to end                                                |hip - truth| <= 1.5 |oracle - truth| + 1e-4"""
+    weights are the generated set model_zoo.synth_weights("original", 3): real-weight parity is UNPINNED.
+    Expected output: G14 = the reference's own classes (model_original.py Encoder/Decoder{1..5}) + util_wct.WCT.transform on
+    this frame with these weights.  With random 512-channel stacks the cascade is chaotic at the level of the reference's OWN
+    arithmetic (oracle vs reference 2.3e-3; oracle vs its fp64 arm 1e-3 .. 4e-3), so the sharp check is level-isolated:
+      per level, on the truth's level input   |hip - truth| <= 1.5 |oracle - truth| + 2e-5, and <= 5e-4
+      end to end, the module's gate            hip_vs_reference <= max(1e-3, 1.25 * oracle_vs_reference)"""
     from wct_hip import WCT
     torch = torch_cuda
     _threads(oracle)
+    g = golden("g14_cfg3_original.npz")
     w = model_zoo.synth_weights("original", 3)
-    c = np.random.default_rng(3).random((3, 1080, 1920), dtype=np.float32)
-    s = np.random.default_rng(4).random((3, 1080, 1920), dtype=np.float32)
+    c, s = cfg3_frames()
     m32, m64 = oracle.Modules("original", w), oracle.Modules("original", w, precision="fp64")
     wct = WCT(types.SimpleNamespace(mode="original", alpha=1.0), weights=w)
     t64 = []
@@ -212,20 +207,22 @@ def test_e2e_config3_original_mode(torch_cuda, oracle):
     iso_hip, iso_ref, img = [], [], c
     for t in t64:
         x32 = np.asarray(img, np.float32)
-        g = wct.style_transfer_level(t["level"], cu(torch, x32), cu(torch, s)).cpu().numpy()[0]
-        iso_hip.append(rel_err(g, t["out"]))
+        y = wct.style_transfer_level(t["level"], cu(torch, x32), cu(torch, s)).cpu().numpy()[0]
+        iso_hip.append(rel_err(y, t["out"]))
         iso_ref.append(rel_err(oracle.style_transfer(m32, t["level"], x32, s, 1.0), t["out"]))
         img = t["out"]
     got = wct.stylize(cu(torch, c), cu(torch, s)).cpu().numpy()[0]
-    e_truth, ref_truth, e_ref = rel_err(got, truth), rel_err(ref, truth), rel_err(got, ref)
-    _report("e2e cfg3 original", hip_vs_truth=e_truth, oracle_vs_truth=ref_truth, hip_vs_oracle=e_ref,
+    rh, ro = compare_to_fixture(got, g), compare_to_fixture(ref, g)
+    _report("e2e cfg3 original", hip_vs_reference=rh["max"], oracle_vs_reference=ro["max"], limit=gate_limit(ro["max"]),
+            hip_p9999=rh["lattice_p9999"], oracle_p9999=ro["lattice_p9999"], hip_vs_truth=rel_err(got, truth), oracle_vs_truth=rel_err(ref, truth),
             iso_hip=" ".join("%.1e" % v for v in iso_hip), iso_oracle=" ".join("%.1e" % v for v in iso_ref),
             oracle_s=round(t1 - t0, 1), truth_s=round(t2 - t1, 1), saturated=wct.saturation_count())
     assert got.shape == ref.shape == (3, 1072, 1920)
     assert wct.saturation_count() == 0
     for a, b in zip(iso_hip, iso_ref):
         assert a <= 1.5 * b + 2e-5 and a <= 5e-4
-    assert e_truth <= 1.5 * ref_truth + 1e-4
+    assert rh["max"] <= gate_limit(ro["max"])                  # THE GATE (the limit is 1.25 x oracle_vs_reference here)
+    assert rh["lattice_p9999"] <= 1.5 * ro["lattice_p9999"] + 1e-4
 
 
 # --------------------------------------------------------------------------- config 4 size on one GPU (properties)
@@ -290,8 +287,10 @@ def test_num_run_2(torch_cuda, wct16, oracle, weights16x):
 # --------------------------------------------------------------------------- f16x3 range: never silent
 def test_f16x3_saturation_is_flagged(torch_cuda, weights16x):
     """The f16x3 kernels clamp activations to +-65504; with weights scaled so that relu1_2 of the level-3 encoder reaches
-    ~1e6 the sticky flag must come up (OverflowError from sync(), non-zero saturation_count), must be resettable, and the
-    exact-fp32 mode must run the same weights without it and agree with the oracle."""
+    ~1e6 the flag must come up -- OverflowError from sync() ONCE (reported and cleared: a later error means a later clamp),
+    OverflowError from the NEXT compute call of any kind without a sync (the asynchronous read-back of wct_range_poll), a
+    non-zero saturation_count -- and the exact-fp32 mode must run the same weights without it and agree with the oracle.
+    A NaN pixel (external data) is turned into a finite value by the same clamp instruction and must raise it too."""
     from wct_hip import WCT
     torch = torch_cuda
     w = dict(weights16x)
@@ -304,14 +303,23 @@ def test_f16x3_saturation_is_flagged(torch_cuda, weights16x):
     wct.e2(c)
     wct.sync()                                   # level 2 uses other weights: nothing flagged
     y = wct.e3(c)
-    assert bool(torch.isfinite(y).all())          # saturates, never inf
+    assert bool(torch.isfinite(y).all())          # saturates, never inf (this also waits for the call: its read-back has landed)
+    with pytest.raises(OverflowError):            # ... so the next call of ANY kind reports it, without a sync()
+        wct.e2(c)
     with pytest.raises(OverflowError):
-        wct.sync()
-    assert wct.saturation_count() > 0
-    with pytest.raises(OverflowError):            # sticky until reset
-        wct.sync()
+        wct.stylize(c, c)
+    assert wct.saturation_count() > 0             # reading does not clear
+    with pytest.raises(OverflowError):
+        wct.sync()                                # reported once ...
+    wct.sync()                                    # ... and cleared
+    assert wct.saturation_count() == 0
+    wct.e2(c)
+    wct.strict_range = False                      # opt out of the per-call check: only sync() / saturation_count() tell
+    wct.e3(c)
+    torch.cuda.synchronize()
+    wct.e3(c)
     assert wct.saturation_count(reset=True) > 0
-    wct.sync()
+    wct.strict_range = True
     wct.set_conv_mode("fp32")
     y32 = wct.e3(c)
     wct.sync()
@@ -323,6 +331,26 @@ def test_f16x3_saturation_is_flagged(torch_cuda, weights16x):
     wct.set_conv_mode("f16x3")
     wct.e5(c * 1e6)
     assert wct.saturation_count(reset=True) > 0
+    # NaN in external data: one NaN pixel in the image (fused head, level-1 kernels), one NaN in an fp32 feature map (decoder)
+    clean = WCT(types.SimpleNamespace(mode="16x", alpha=1.0), weights=weights16x)
+    clean.strict_range = False
+    bad = c.clone()
+    bad[0, 1, 40, 50] = float("nan")
+    for level in (5, 1):
+        clean.encode(level, bad)
+        assert clean.saturation_count(reset=True) > 0, level
+    clean.stylize(bad, c)
+    assert clean.saturation_count(reset=True) > 0
+    f = clean.encode(3, c)
+    assert clean.saturation_count() == 0
+    f[0, 7, 3, 5] = float("nan")
+    clean.decode(3, f)
+    assert clean.saturation_count(reset=True) > 0
+    with pytest.raises(ValueError):               # non-finite weights never get as far as a kernel
+        wn = dict(weights16x)
+        wn["d2.conv21.weight"] = wn["d2.conv21.weight"].copy()
+        wn["d2.conv21.weight"][0, 0, 0, 0] = np.float32("inf")
+        WCT(types.SimpleNamespace(mode="16x", alpha=1.0), weights=wn)
 
 
 # --------------------------------------------------------------------------- reference checkpoints through WCT(args)

@@ -115,6 +115,14 @@ def test_device_resize_edges_and_errors(wct):
         img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
         got = wct.resize_u8(torch.from_numpy(img).cuda(), (oh, ow)).cpu().numpy()
         assert np.array_equal(got, R.resize_bilinear_u8(img, oh, ow)), (h, w, oh, ow)
+    # a contiguous uint8 view at an ODD byte offset (e.g. a row crop of a larger HWC buffer): the kernels read single bytes
+    img = rng.integers(0, 256, (37, 53, 3), dtype=np.uint8)
+    buf = torch.zeros(1 + img.size, dtype=torch.uint8, device="cuda")
+    buf[1:] = torch.from_numpy(img).cuda().reshape(-1)
+    view = buf[1:].view(37, 53, 3)
+    assert view.data_ptr() % 2 == 1
+    assert np.array_equal(wct.resize_u8(view, (20, 31)).cpu().numpy(), R.resize_bilinear_u8(img, 20, 31))
+    assert torch.equal(wct.resize_u8(view, (20, 31), to_tensor=True), wct.to_tensor_u8(wct.resize_u8(view, (20, 31))))
     with pytest.raises(ValueError):
         wct.resize_u8(torch.zeros((4, 4, 3), dtype=torch.uint8, device="cuda"), (0, 4))
     with pytest.raises(ValueError):
@@ -124,3 +132,5 @@ def test_device_resize_edges_and_errors(wct):
     x = torch.from_numpy(img).cuda()
     for k in range(1, 40):
         assert np.array_equal(wct.resize_u8(x, (k, 2 * k)).cpu().numpy(), R.resize_bilinear_u8(img, k, 2 * k)), k
+        if k % 5 == 0:      # a size that keeps coming back survives the evictions (least recently used goes first)
+            assert np.array_equal(wct.resize_u8(x, (3, 4)).cpu().numpy(), R.resize_bilinear_u8(img, 3, 4))

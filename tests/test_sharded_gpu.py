@@ -128,6 +128,96 @@ def test_replicas_three_ranks_on_the_hip_engine(tmp_path):
         assert got.shape == ref.shape and np.array_equal(got, ref), rank
 
 
+def _cfg5_worker(rank, world, port, out_dir):
+    for p in (REPO, PKG):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import hashlib
+    import torch
+    import torch.distributed as dist
+    from tests.fixture_compare import noise_frame
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from wct_hip import WCT, model_zoo
+        from wct_hip.replicas import ReplicaStylizer
+        wct = WCT(types.SimpleNamespace(mode="16x", alpha=1.0), weights=model_zoo.load_npz_weights(os.path.join(PKG, "weights", "16x.npz")))
+        style = torch.from_numpy(noise_frame(2, 2048, 2048)).cuda()
+        content = torch.from_numpy(noise_frame(10 + rank, 2160, 3840)).cuda()
+        out = ReplicaStylizer(wct, dist).stylize(content, style)
+        wct.sync()
+        assert tuple(out.shape) == (1, 3, 2160, 3840) and wct.saturation_count() == 0
+        with open(os.path.join(out_dir, "r%d.sha" % rank), "w") as f:
+            f.write(hashlib.sha256(out.cpu().numpy().tobytes()).hexdigest())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_config5_eight_4k_contents_one_style(tmp_path):
+    """BASELINE configs[4] AT ITS SIZE: eight distinct 3840x2160 contents (SURVEY 8d seeds 10..17) x one 2048x2048 style (seed 2),
+    one content per rank -- eight ranks (sharing the one GPU over gloo; on the 8-GPU node: one GPU each, xGMI idle), each level's
+    style statistics computed by ONE rank and broadcast (wct_hip/replicas.py; PytorchWCT/data_loader.py:32-36 builds the content x
+    style pairs).  Every rank's image equals the single-engine `stylize_prepared` of its content BIT FOR BIT (sha256 of the
+    result), and so does wct_hip/pipeline.py's FramePipeline with three of these frames in flight on one GPU."""
+    import hashlib
+    import torch
+    import torch.multiprocessing as mp
+    from tests.fixture_compare import noise_frame
+    from wct_hip import WCT, model_zoo
+    from wct_hip.pipeline import FramePipeline
+    world = 8
+    mp.spawn(_cfg5_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    weights = model_zoo.load_npz_weights(os.path.join(PKG, "weights", "16x.npz"))
+    make = lambda: WCT(types.SimpleNamespace(mode="16x", alpha=1.0), weights=weights)   # noqa: E731
+    wct = make()
+    style = torch.from_numpy(noise_frame(2, 2048, 2048)).cuda()
+    contents = [torch.from_numpy(noise_frame(10 + r, 2160, 3840)).cuda() for r in range(world)]
+    wct.style_prepare(style)
+    sha = lambda t: hashlib.sha256(t.cpu().numpy().tobytes()).hexdigest()   # noqa: E731
+    want = [sha(wct.stylize_prepared(c)) for c in contents]
+    assert len(set(want)) == world                                    # distinct contents, distinct results
+    for r in range(world):
+        assert open(str(tmp_path / ("r%d.sha" % r))).read() == want[r], r
+    free0, _ = torch.cuda.mem_get_info()
+    pipe = FramePipeline(make, slots=3)
+    outs = pipe.stylize_many(contents, style=style)
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert [sha(o) for o in outs] == want
+    print("\n[cfg5 at size] 8 ranks + 3-slot pipeline bitwise equal; pipeline device memory %.1f GiB" % ((free0 - free1) / 2**30))
+    assert (free0 - free1) / 2**30 < 24.0
+
+
+def test_rank_simulation_runs_the_sharded_path(tmp_path):
+    """bench.py's passes.cfg4_rank_sim relies on wct_hip.sharded.LoopbackGroup: one rank of an 8-rank job with its peers
+    emulated on the device.  Shapes and call order must be those of the real job: rank 3's strip of a 2560-wide frame (8 x 320
+    columns, exchange mode) comes back with the owned width, finite, and the group saw 5 broadcasts and 5 all-reduces."""
+    import torch
+    from wct_hip import WCT, model_zoo
+    from wct_hip.sharded import LoopbackGroup, ShardedStylizer
+    wct = WCT(types.SimpleNamespace(mode="16x", alpha=1.0), weights=model_zoo.load_npz_weights(os.path.join(PKG, "weights", "16x.npz")))
+    g = torch.Generator(device="cuda").manual_seed(4)
+    H, W = 208, 2560
+    content, style = torch.rand((3, H, W), device="cuda", generator=g), torch.rand((3, 256, 240), device="cuda", generator=g)
+    wct.style_prepare(style)
+    stats = {L: wct.style_export(L).clone() for L in (5, 4, 3, 2, 1)}
+    calls = {"ar": 0}
+
+    class Counting(LoopbackGroup):
+        def all_reduce(self, t, op=None):
+            calls["ar"] += 1
+    for r in (0, 3, 7):
+        grp = Counting(r, 8)
+        grp.style_stats = stats
+        sh = ShardedStylizer(wct, grp, H, W, 256, 240, halo_mode="exchange")
+        x0, x1 = sh.input_columns()
+        out = sh.stylize_strip(content[:, :, x0:x1].contiguous(), style)
+        wct.sync()
+        assert tuple(out.shape) == (1, 3, H, 320) and bool(torch.isfinite(out).all()) and grp._bcast == 5
+    assert calls["ar"] == 15
+
+
 def test_rccl_first_contact_single_rank():
     """The GPU test box has one device, so RCCL cannot carry a 2-rank job here; this at least executes the calls bench.py and
     wct_hip/sharded.py make -- init_process_group("nccl", device_id=...), all_reduce(SUM) of fp64 moments, broadcast, a

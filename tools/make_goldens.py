@@ -427,10 +427,116 @@ def gen_g12():
     print("G12: Pillow %s, %d arrays" % (PIL.__version__, len(g)))
 
 
+def smooth_frame(rng, shape, it=3):
+    """The `smooth` synthetic variant of SURVEY 8(d) (box-blurred noise, wrap-around, normalised to [0, 1]); the same function as
+    tests/test_hip_scale.py::smooth and bench.py::smooth_frame."""
+    x = rng.random(shape, dtype=np.float32)
+    for _ in range(it):
+        x = (x + np.roll(x, 1, 1) + np.roll(x, 1, 2) + np.roll(x, -1, 1) + np.roll(x, -1, 2)) / 5
+    return np.ascontiguousarray((x - x.min()) / (x.max() - x.min()))
+
+
+G13_CROPS = ((0, 0), (1032, 1872), (2064, 3744), (500, 3000), (0, 3744), (2064, 0), (1500, 700), (300, 1900))
+
+
+def pack_frame_fixture(y, crops, lattice=(1, 2, 4)):
+    """What is kept of a reference output too large to commit whole: global statistics, a 16x box-downsampled image, 96x96
+    crops, and a regular lattice of pixels y[:, oy::st, ox::st] (1/16 of the image: error quantiles against the reference)."""
+    C, H, W = y.shape
+    oy, ox, st = lattice
+    g = {"shape": np.array(y.shape), "mean": np.float64(y.mean(dtype=np.float64)), "std": np.float64(y.std(dtype=np.float64)),
+         "max": np.float32(y.max()), "min": np.float32(y.min()),
+         "down16": y[:, :H // 16 * 16, :W // 16 * 16].reshape(C, H // 16, 16, W // 16, 16).mean(axis=(2, 4), dtype=np.float64).astype(np.float32),
+         "lattice.origin_stride": np.array(lattice), "lattice": np.ascontiguousarray(y[:, oy::st, ox::st])}
+    for i, (y0, x0) in enumerate(crops):
+        g["crop%d.origin" % i] = np.array([y0, x0])
+        g["crop%d" % i] = y[:, y0:y0 + 96, x0:x0 + 96].copy()
+    return g
+
+
+def gen_g13(which=("noise", "smooth")):
+    """G13: the SYNTHETIC config-2 frames bench.py times and tests/test_hip_scale.py checks, through the reference itself
+    (util_wct.WCT, real 16x checkpoints, torch CPU, WCT.py:120-125 restated) -- SURVEY 8(d) seeds: content
+    numpy.random.default_rng(1).random((3, 2160, 3840), float32), style default_rng(2).random((3, 2048, 2048), float32); the
+    `smooth` variant's content is smooth_frame(default_rng(101), ...).  Inputs are regenerated from the seeds (numpy's PCG64
+    stream is stable across versions), the expected outputs are stored by pack_frame_fixture.  ~5 min per frame here."""
+    import time
+    torch.set_num_threads(8)
+    util_wct = import_reference()
+    wct = util_wct.WCT(ref_args("16x", 1.0))
+    s = np.random.default_rng(2).random((3, 2048, 2048), dtype=np.float32)
+    for kind in which:
+        c = (np.random.default_rng(1).random((3, 2160, 3840), dtype=np.float32) if kind == "noise"
+             else smooth_frame(np.random.default_rng(101), (3, 2160, 3840)))
+        t0 = time.time()
+        img = t(c[None])
+        for k in (5, 4, 3, 2, 1):
+            img = ref_style_transfer(wct, getattr(wct, "e%d" % k), getattr(wct, "d%d" % k), img, t(s[None]), 1.0)
+            print("G13 %s: level %d done, %.0f s" % (kind, k, time.time() - t0), flush=True)
+        y = img.squeeze(0).numpy()
+        assert y.shape == (3, 2160, 3840) and np.isfinite(y).all()
+        g = pack_frame_fixture(y, G13_CROPS)
+        g["content.checksum"] = np.float64(c.sum(dtype=np.float64))      # guards the seed -> input reproduction
+        g["style.checksum"] = np.float64(s.sum(dtype=np.float64))
+        g["torch"] = np.array(torch.__version__)
+        np.savez_compressed(os.path.join(GOLD, "g13_cfg2_%s.npz" % kind), **g)
+        print("G13 %s: mean %.6f std %.6f max %.4f  (%.0f s)" % (kind, g["mean"], g["std"], g["max"], time.time() - t0), flush=True)
+
+
+def gen_g14():
+    """G14: config 3 -- `--mode original` at 1920x1080 -- through the reference's own classes (model_original.py Encoder{k} /
+    Decoder{k}, util_wct.WCT.transform) with the GENERATED weights model_zoo.synth_weights("original", 3) (the torch7
+    checkpoints are absent: real-weight parity stays unpinned), content default_rng(3), style default_rng(4), both
+    (3, 1080, 1920) -- the frame bench.py's cfg3 pass and tests/test_hip_scale.py use.  Output 3 x 1072 x 1920."""
+    import time
+    torch.set_num_threads(8)
+    util_wct = import_reference()
+    wct16 = util_wct.WCT(ref_args("16x", 1.0))          # only for its .transform (util_wct.py:210-223; mode-independent)
+    from model.model_original import (Encoder1, Encoder2, Encoder3, Encoder4, Encoder5,
+                                      Decoder1, Decoder2, Decoder3, Decoder4, Decoder5)
+    encs = [Encoder1, Encoder2, Encoder3, Encoder4, Encoder5]
+    decs = [Decoder1, Decoder2, Decoder3, Decoder4, Decoder5]
+    ow = model_zoo.synth_weights("original", 3)
+    mods = {}
+    for k in range(1, 6):
+        for kind, cls in (("enc", encs[k - 1]), ("dec", decs[k - 1])):
+            m = cls(None)
+            key = model_zoo.module_key(kind, k)
+            m.load_state_dict({n[len(key) + 1:]: t(v) for n, v in ow.items() if n.startswith(key + ".")}, strict=True)
+            m.eval()
+            mods[key] = m
+    owct = types.SimpleNamespace(transform=wct16.transform)
+    c = np.random.default_rng(3).random((3, 1080, 1920), dtype=np.float32)
+    s = np.random.default_rng(4).random((3, 1080, 1920), dtype=np.float32)
+    t0 = time.time()
+    img = t(c[None])
+    g = {}
+    for k in (5, 4, 3, 2, 1):
+        img = ref_style_transfer(owct, mods["e%d" % k], mods["d%d" % k], img, t(s[None]), 1.0)
+        o = img.squeeze(0).numpy()
+        g["L%d.mean" % k], g["L%d.max" % k] = np.float64(o.mean(dtype=np.float64)), np.float32(o.max())
+        print("G14: level %d done, %.0f s, out %s max %.3f" % (k, time.time() - t0, tuple(o.shape), o.max()), flush=True)
+    y = img.squeeze(0).numpy()
+    assert y.shape == (3, 1072, 1920) and np.isfinite(y).all()
+    g.update(pack_frame_fixture(y, ((0, 0), (488, 912), (976, 1824), (300, 1500)), lattice=(1, 2, 4)))
+    g["weights"] = np.array("model_zoo.synth_weights('original', 3)")
+    g["torch"] = np.array(torch.__version__)
+    np.savez_compressed(os.path.join(GOLD, "g14_cfg3_original.npz"), **g)
+    print("G14: mean %.6f std %.6f max %.4f" % (g["mean"], g["std"], g["max"]), flush=True)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 2 and sys.argv[1] == "--only" and sys.argv[2] == "g12":
         os.makedirs(GOLD, exist_ok=True)
         gen_g12()
+        gen_g13()
+        gen_g14()
+    elif len(sys.argv) > 2 and sys.argv[1] == "--only" and sys.argv[2] == "g13":
+        os.makedirs(GOLD, exist_ok=True)
+        gen_g13(tuple(sys.argv[3:]) or ("noise", "smooth"))
+    elif len(sys.argv) > 2 and sys.argv[1] == "--only" and sys.argv[2] == "g14":
+        os.makedirs(GOLD, exist_ok=True)
+        gen_g14()
     elif len(sys.argv) > 2 and sys.argv[1] == "--only" and sys.argv[2] == "g11":
         os.makedirs(GOLD, exist_ok=True)
         gen_g11()
@@ -446,3 +552,5 @@ if __name__ == "__main__":
         gen_g10()
         gen_g11()
         gen_g12()
+        gen_g13()
+        gen_g14()
