@@ -190,6 +190,13 @@ def main():
                          "--stats summary of the run averages the same launch mix as `roofline`")
     args = ap.parse_args()
 
+    # ONE JSON line on stdout, nothing else: RCCL prints a version banner to stdout when a communicator is created (N > 1, and the
+    # 1-rank communicator of passes.cfg4_rank_sim), so everything this process and its libraries print goes to stderr and the line
+    # is written to the saved descriptor at the end
+    sys.stdout.flush()
+    line_fd = os.dup(1)
+    os.dup2(2, 1)
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -522,7 +529,7 @@ def main():
         }
         if parity_ok is False:
             line["unverified_value"] = round(value, 2)
-        print(json.dumps(line))
+        os.write(line_fd, (json.dumps(line) + "\n").encode())
     if dist is not None:
         dist.destroy_process_group()
     if parity_ok is False:

@@ -211,10 +211,13 @@ __global__ __launch_bounds__(32 * TH) void conv3x3_f16_kernel(F16Args a) {
         f32x4 m;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float v = fmaxf(acc[c][0][4 * q + r], acc[c][1][4 * q + r]);
-          v = fmaxf(v, lane_xor1(v));
-          v = v * inv + bias[r];
-          m[r] = a.relu ? fmaxf(v, 0.f) : v;
+          const float v = fmaxf(acc[c][0][4 * q + r], acc[c][1][4 * q + r]);
+          m[r] = fmaxf(v, lane_xor1(v));
+        }
+        m = fma4(m, inv, bias);
+        if (a.relu) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) m[r] = fmaxf(m[r], 0.f);
         }
         const int oy = (ty0 + wave * 2) >> 1, ox = gx >> 1;
         const bool ok = !(li & 1) && oy < Hp && ox < Wp && co < a.cout;
@@ -228,11 +231,10 @@ __global__ __launch_bounds__(32 * TH) void conv3x3_f16_kernel(F16Args a) {
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
           const int gy = ty0 + wave * 2 + p;
-          f32x4 v;
+          f32x4 v = fma4(f32x4{acc[c][p][4 * q], acc[c][p][4 * q + 1], acc[c][p][4 * q + 2], acc[c][p][4 * q + 3]}, inv, bias);
+          if (a.relu) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            v[r] = acc[c][p][4 * q + r] * inv + bias[r];
-            if (a.relu) v[r] = fmaxf(v[r], 0.f);
+            for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
           }
           const bool ok = gy < a.H && gx < a.W && co < a.cout;
           if (a.out_sp) {
@@ -319,10 +321,13 @@ __global__ __launch_bounds__(256) void conv3x3_f16_c16_kernel(F16Args a) {
       f32x4 m;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        float v = fmaxf(acc[0][h][r], acc[1][h][r]);
-        v = fmaxf(v, lane_xor1(v));
-        v = v * inv + bias[r];
-        m[r] = a.relu ? fmaxf(v, 0.f) : v;
+        const float v = fmaxf(acc[0][h][r], acc[1][h][r]);
+        m[r] = fmaxf(v, lane_xor1(v));
+      }
+      m = fma4(m, inv, bias);
+      if (a.relu) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) m[r] = fmaxf(m[r], 0.f);
       }
       const int oy = (ty0 + wave * 2) >> 1, ox = gx >> 1;
       if (!(li & 1) && oy < Hp && ox < Wp && co < a.cout) {
@@ -333,11 +338,10 @@ __global__ __launch_bounds__(256) void conv3x3_f16_c16_kernel(F16Args a) {
 #pragma unroll
       for (int r2 = 0; r2 < 2; ++r2) {
         const int gy = ty0 + wave * 2 + r2;
-        f32x4 v;
+        f32x4 v = fma4(acc[r2][h], inv, bias);
+        if (a.relu) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          v[r] = acc[r2][h][r] * inv + bias[r];
-          if (a.relu) v[r] = fmaxf(v[r], 0.f);
+          for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
         }
         if (gy < a.H && gx < a.W) {
           if constexpr (OUT3) {
@@ -511,10 +515,7 @@ __global__ __launch_bounds__(32 * TH, HeadGeo<TH>::PER_CU) void enc_head_kernel(
 #pragma unroll
       for (int u = 0; u < 3; ++u) {
         if (i + u >= NG) continue;
-        f32x4 x;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) x[r] = acc[u][r] * a.inv11 + bias11[r];
-        store_split4<true>(act, NPP, gpix[i + u], kq, x, sat);
+        store_split4<true>(act, NPP, gpix[i + u], kq, fma4(acc[u], a.inv11, bias11), sat);
       }
     }
     HT_STAMP(2);
@@ -535,11 +536,12 @@ __global__ __launch_bounds__(32 * TH, HeadGeo<TH>::PER_CU) void enc_head_kernel(
       f32x4 m;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        float x = fmaxf(acc[0][h][r], acc[1][h][r]);
-        x = fmaxf(x, lane_xor1(x));
-        x = x * a.inv12 + bias12[r];
-        m[r] = fmaxf(x, 0.f);
+        const float x = fmaxf(acc[0][h][r], acc[1][h][r]);
+        m[r] = fmaxf(x, lane_xor1(x));
       }
+      m = fma4(m, a.inv12, bias12);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) m[r] = fmaxf(m[r], 0.f);
       const int ox = (tx0 >> 1) + h * 8 + (li >> 1);
       if (!(li & 1) && oy < Hp && ox < Wp) {
         char* dst = orow + h * 8 * 64 + out_lane;
@@ -736,10 +738,7 @@ __global__ __launch_bounds__(32 * TH, TH == 8 ? 2 : 1) void dec_tail_kernel(Tail
       }
 #pragma unroll
       for (int u = 0; u < NG; ++u) {
-        f32x4 x;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) x[r] = acc[u][r] * inv12 + bias12[r];
-        store_split4<true>(act1, NPX, gslot[u], kq, x, sat);
+        store_split4<true>(act1, NPX, gslot[u], kq, fma4(acc[u], inv12, bias12), sat);
       }
     }
     __syncthreads();
@@ -893,10 +892,7 @@ __global__ __launch_bounds__(32 * TH, TH <= 16 ? 2 : 1) void dec_tail_up_kernel(
       }
 #pragma unroll
       for (int u = 0; u < NG; ++u) {
-        f32x4 x;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) x[r] = acc[u][r] * a.inv12u + bias12[r];
-        store_split4<true>(act1, NPX, gslot[u], kq, x, sat);
+        store_split4<true>(act1, NPX, gslot[u], kq, fma4(acc[u], a.inv12u, bias12), sat);
       }
     }
     __syncthreads();
@@ -930,10 +926,18 @@ __global__ void absmax_kernel(const float* w, long n, unsigned* maxbits) {
   if ((threadIdx.x & 63) == 0) atomicMax(maxbits, __float_as_uint(m));
 }
 
-__global__ void split_pack_kernel(const float* wpk32, int chunks, int cout_pad, int taps, const unsigned* maxbits,
+// max |w| from one word, or from nmax per-row maxima (launch_fold_fast: no atomics, no memset) -- non-negative floats order like
+// their bit patterns
+__device__ __forceinline__ float pack_max(const unsigned* maxbits, int nmax) {
+  unsigned m = 0u;
+  for (int j = 0; j < nmax; ++j) m = max(m, maxbits[j]);    // wave-uniform addresses: scalar / broadcast loads, <= 128 of them
+  return __uint_as_float(m);
+}
+
+__global__ void split_pack_kernel(const float* wpk32, int chunks, int cout_pad, int taps, const unsigned* maxbits, int nmax,
                                   u32x4* out, float* inv_scale_out) {
   // scale = 2^e with max|w| * scale in [256, 512)
-  const float mx = __uint_as_float(*maxbits);
+  const float mx = pack_max(maxbits, nmax);
   int ex = 0;
   if (mx > 0.f && mx < 3.0e38f) { (void)frexpf(mx, &ex); ex = 9 - ex; }
   ex = ex > 100 ? 100 : (ex < -100 ? -100 : ex);
@@ -963,8 +967,8 @@ __global__ void split_pack_kernel(const float* wpk32, int chunks, int cout_pad, 
 }
 
 // the block-packed form (conv_f16_dev.h c3_block_compute) of a cout_pad-16 layer with 3 real couts, same scale as above
-__global__ void split_pack_phase_kernel(const float* wpk32, int chunks, const unsigned* maxbits, u32x4* out) {
-  const float mx = __uint_as_float(*maxbits);
+__global__ void split_pack_phase_kernel(const float* wpk32, int chunks, const unsigned* maxbits, int nmax, u32x4* out) {
+  const float mx = pack_max(maxbits, nmax);
   int ex = 0;
   if (mx > 0.f && mx < 3.0e38f) { (void)frexpf(mx, &ex); ex = 9 - ex; }
   ex = ex > 100 ? 100 : (ex < -100 ? -100 : ex);
@@ -1093,7 +1097,7 @@ size_t conv_f16_weight_bytes(int cin, int cout_pad, int taps) {
 }
 
 hipError_t launch_split_pack(const float* wpk32, int cin, int cout_pad, int taps, unsigned* maxbits_dev, void* out,
-                             float* inv_scale_out, hipStream_t s, bool have_max) {
+                             float* inv_scale_out, hipStream_t s, bool have_max, int nmax) {
   const int chunks = (cin + 15) / 16;
   if (!have_max) {
     hipError_t e = hipMemsetAsync(maxbits_dev, 0, sizeof(unsigned), s);
@@ -1103,16 +1107,16 @@ hipError_t launch_split_pack(const float* wpk32, int cin, int cout_pad, int taps
   }
   const long total = (long)chunks * taps * 4 * cout_pad;
   hipLaunchKernelGGL(split_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, wpk32, chunks, cout_pad, taps,
-                     maxbits_dev, reinterpret_cast<u32x4*>(out), inv_scale_out);
+                     maxbits_dev, have_max ? nmax : 1, reinterpret_cast<u32x4*>(out), inv_scale_out);
   return hipGetLastError();
 }
 
 size_t conv_phase_weight_bytes(int cin) { return (size_t)((cin + 15) / 16) * PH_WSLOTS * 16; }
 
-hipError_t launch_split_pack_phase(const float* wpk32, int cin, const unsigned* maxbits_dev, void* out, hipStream_t s) {
+hipError_t launch_split_pack_phase(const float* wpk32, int cin, const unsigned* maxbits_dev, void* out, hipStream_t s, int nmax) {
   const int chunks = (cin + 15) / 16;
   const long total = (long)chunks * PH_WSLOTS;
-  hipLaunchKernelGGL(split_pack_phase_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, wpk32, chunks, maxbits_dev,
+  hipLaunchKernelGGL(split_pack_phase_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, wpk32, chunks, maxbits_dev, nmax,
                      reinterpret_cast<u32x4*>(out));
   return hipGetLastError();
 }

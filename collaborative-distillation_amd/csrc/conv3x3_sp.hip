@@ -159,18 +159,21 @@ __global__ __launch_bounds__(512) void conv3x3_sp_kernel(SpArgs a) {
     if constexpr (POOL) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        float t = fmaxf(r[c][0][4 * q + k], r[c][1][4 * q + k]);
-        t = fmaxf(t, lane_xor1(t));
-        t = t * inv + bias[k];
-        x[k] = (OUTF32 && a.relu) ? fmaxf(t, 0.f) : t;
+        const float t = fmaxf(r[c][0][4 * q + k], r[c][1][4 * q + k]);
+        x[k] = fmaxf(t, lane_xor1(t));
+      }
+      x = fma4(x, inv, bias);
+      if (OUTF32 && a.relu) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) x[k] = fmaxf(x[k], 0.f);
       }
       oy = (ty0 + rw * 2) >> 1; ox = gx >> 1;
       ok = !(li & 1) && oy < oH && ox < oW && co < a.cout;
     } else {
+      x = fma4(f32x4{r[c][p][4 * q], r[c][p][4 * q + 1], r[c][p][4 * q + 2], r[c][p][4 * q + 3]}, inv, bias);
+      if (OUTF32 && a.relu) {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        x[k] = r[c][p][4 * q + k] * inv + bias[k];
-        if (OUTF32 && a.relu) x[k] = fmaxf(x[k], 0.f);
+        for (int k = 0; k < 4; ++k) x[k] = fmaxf(x[k], 0.f);
       }
       oy = ty0 + rw * 2 + p; ox = gx;
       ok = oy < oH && ox < oW && co < a.cout;
@@ -368,11 +371,10 @@ __global__ __launch_bounds__(512) void conv3x3_sp_up_kernel(SpArgs a) {
     const int b = k & 1, q = ((k >> 1) & 1) | (((k >> 2) & 1) << 1), p = k >> 3, pa = pgrp & 1;
     const int co = (pgrp >> 1) * COW + 8 * q + 4 * kh;
     const f32x4 bias = *reinterpret_cast<const f32x4*>(biasL + co);
-    f32x4 x;
+    f32x4 x = fma4(f32x4{r[b][p][4 * q], r[b][p][4 * q + 1], r[b][p][4 * q + 2], r[b][p][4 * q + 3]}, inv, bias);
+    if (OUTF32 && a.relu) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      x[e] = r[b][p][4 * q + e] * inv + bias[e];
-      if (OUTF32 && a.relu) x[e] = fmaxf(x[e], 0.f);
+      for (int e = 0; e < 4; ++e) x[e] = fmaxf(x[e], 0.f);
     }
     const int oy = 2 * (ty0 + rw * 2 + p) + pa, ox = 2 * (tx0 + li) + b;
     const bool ok = oy < a.H && ox < a.W && co < a.cout;

@@ -38,6 +38,24 @@ __device__ __forceinline__ int xcd_swizzle(int bid, int n) {
 //              anyway -- the DMA conv kernel sits at 256 VGPRs and spilled 18 of them with note().  hi == 0x7BFF means
 //              x >= 65488 (everything that rounds to the largest f16), i.e. it also fires in the last 0.02 % below the limit.
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// x * s + b on four values: the scale + bias step of every epilogue.  WCT_PKFMA builds it from TWO v_pk_fma_f32 (gfx950 issues a
+// packed fp32 fma at the rate of a scalar one; the compiler pairs them only when the source says so) -- the same fused
+// multiply-add per element, bit-identical results.  Measured (round 3, same-box A/B of three builds, tools/experiments/
+// ab_libs.sh): the packed form is NOT faster -- enc_head +3 % (1.28 -> 1.33 ms per step: its register pairs cost a third spilled
+// VGPR at the 168-register cap), dec_tail +1 %, level 1 and the DMA convolutions unchanged -- so the scalar form stays the default.
+__device__ __forceinline__ f32x4 fma4(const f32x4& x, float s, const f32x4& b) {
+#ifdef WCT_PKFMA
+  const f32x2 s2 = {s, s};
+  const f32x2 lo = __builtin_elementwise_fma(f32x2{x[0], x[1]}, s2, f32x2{b[0], b[1]});
+  const f32x2 hi = __builtin_elementwise_fma(f32x2{x[2], x[3]}, s2, f32x2{b[2], b[3]});
+  return f32x4{lo[0], lo[1], hi[0], hi[1]};
+#else
+  return f32x4{x[0] * s + b[0], x[1] * s + b[1], x[2] * s + b[2], x[3] * s + b[3]};
+#endif
+}
+
 struct SatTrack {
   float m = 0.f;
   unsigned mu = 0u;
@@ -393,11 +411,10 @@ __device__ __forceinline__ f32x4 l1_conv_group(const u32x2* imgH, int base, cons
     const u32x2 r0 = *reinterpret_cast<const u32x2*>(p + w.off[s][0]), r1 = *reinterpret_cast<const u32x2*>(p + w.off[s][1]);
     acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w.a[ct][s], __builtin_bit_cast(f16x8, u32x4{r0[0], r0[1], r1[0], r1[1]}), acc, 0, 0, 0);
   }
-  f32x4 x;
+  f32x4 x = fma4(acc, w.inv, w.bias[ct]);
+  if constexpr (RELU) {
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    x[r] = acc[r] * w.inv + w.bias[ct][r];
-    if constexpr (RELU) x[r] = fmaxf(x[r], 0.f);
+    for (int r = 0; r < 4; ++r) x[r] = fmaxf(x[r], 0.f);
   }
   return x;
 }
@@ -415,11 +432,11 @@ __device__ __forceinline__ void l1_conv_pair(const u32x2* imgH, int base, const 
     a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w.a[0][s], b, a0, 0, 0, 0);
     a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w.a[1][s], b, a1, 0, 0, 0);
   }
+  x0 = fma4(a0, w.inv, w.bias[0]);
+  x1 = fma4(a1, w.inv, w.bias[1]);
+  if constexpr (RELU) {
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    x0[r] = a0[r] * w.inv + w.bias[0][r];
-    x1[r] = a1[r] * w.inv + w.bias[1][r];
-    if constexpr (RELU) { x0[r] = fmaxf(x0[r], 0.f); x1[r] = fmaxf(x1[r], 0.f); }
+    for (int r = 0; r < 4; ++r) { x0[r] = fmaxf(x0[r], 0.f); x1[r] = fmaxf(x1[r], 0.f); }
   }
 }
 

@@ -159,6 +159,138 @@ __global__ __launch_bounds__(256) void fold_block_kernel(const float* w, const f
   if (maxbits && (tid & 63) == 0) atomicMax(maxbits, __float_as_uint(mx));
 }
 
+// ---- the fold WITHOUT the C x C products on the content side's critical path (16x: cin <= 128).
+// csF = M cF + b with M = alpha Ss Wc + (1 - alpha) I (Ss = cov_s^(1/2): style side; Wc = cov_c^(-1/2): content side), so
+//   W'[o][i][t] = alpha SUM_k Ws[(o,t)][k] Wc[k][i] + (1 - alpha) W[o][i][t],     Ws[(o,t)][k] = SUM_c W[o][c][t] Ss[c][k]
+//   b'[o]       = bias[o] + alpha (Wmus[o] - SUM_k WsumS[o][k] v[k]),             v = Wc mu_c,  WsumS = SUM_t Ws,  Wmus = Wsum mu_s
+// Ws / WsumS / Wmus depend on the style only: fold_style_kernel forms them once per style on the SIDE stream, and the content
+// side goes from Wc straight to the folded weights in ONE launch (fold_fast_kernel) -- no T = Ss Wc, no M, no b: launch_assemble
+// (9 us + a launch gap per level) leaves the critical path.  Everything in fp64 like the M-based fold; the association differs
+// ((W Ss) Wc instead of W (Ss Wc)), i.e. fp64 round-off, then the same rounding to fp32.
+// One workgroup per output channel o; a thread owns input column i and the taps tg, tg + G, ... (fold_row_kernel's scheme).
+// FOLD_NT threads = 256 column/tap owners x FOLD_CS slices of the contraction index: a thread's dependent chain is cin / FOLD_CS
+// steps (32 at cin = 128) instead of cin, the slices are summed through LDS in a fixed order.  NROW = 9 taps (+ 1: a tenth
+// left-hand row riding in the same pass, the bias row of fold_fast_kernel).
+constexpr int FOLD_CS = 4, FOLD_NT = 256 * FOLD_CS;
+
+template <int NROW, typename OUT>
+__device__ __forceinline__ void fold_columns(const double* lhs, int lhs_row_stride, int lhs_c_stride, const double* rhs, int cin, int ipad, bool live,
+                                             double* part /* LDS [FOLD_CS - 1][16 * ipad / ... see below] */, OUT&& emit) {
+  const int tid = threadIdx.x & 255, cs = threadIdx.x >> 8;
+  const int G = 256 / ipad, i = tid % ipad, tg = tid / ipad;
+  const int c0 = (cin * cs) / FOLD_CS, c1 = (cin * (cs + 1)) / FOLD_CS;
+  auto run = [&](auto nt_tag) {
+    constexpr int NT = decltype(nt_tag)::value;
+    double s[NT];
+    int tp[NT];
+#pragma unroll
+    for (int k = 0; k < NT; ++k) { s[k] = 0.; const int t = tg + k * G; tp[k] = t < NROW ? t : NROW - 1; }   // clamped: a surplus slot repeats the last row
+    if (live && i < cin)
+#pragma unroll 4
+      for (int c = c0; c < c1; ++c) {
+        const double m = rhs[(size_t)c * cin + i];
+#pragma unroll
+        for (int k = 0; k < NT; ++k) s[k] += lhs[tp[k] * lhs_row_stride + c * lhs_c_stride] * m;
+      }
+    // slices 1.. park their partial sums in LDS ([slice - 1][k][256 owners]); slice 0 adds them in slice order
+    if (cs > 0) {
+#pragma unroll
+      for (int k = 0; k < NT; ++k) part[((cs - 1) * NT + k) * 256 + tid] = s[k];
+    }
+    __syncthreads();
+    if (cs == 0) {
+#pragma unroll
+      for (int k = 0; k < NT; ++k) {
+#pragma unroll
+        for (int q = 1; q < FOLD_CS; ++q) s[k] += part[((q - 1) * NT + k) * 256 + tid];
+        const int row = tg + k * G;
+        if (row < NROW) emit(row, i, s[k]);
+      }
+    }
+  };
+  constexpr int R = NROW;
+  if (G == 1) run(std::integral_constant<int, R>{});
+  else if (G == 2) run(std::integral_constant<int, (R + 1) / 2>{});
+  else if (G == 4) run(std::integral_constant<int, (R + 3) / 4>{});
+  else if (G == 8) run(std::integral_constant<int, (R + 7) / 8>{});
+  else run(std::integral_constant<int, 1>{});
+}
+// cin <= 128 (fold_fast_capable) means ipad <= 128, i.e. G >= 2 column groups and NT <= (nrow + 1) / 2 rows per thread
+__host__ __device__ inline size_t fold_part_doubles(int nrow) { return (size_t)(FOLD_CS - 1) * ((nrow + 1) / 2) * 256; }
+
+// style side: Ws [cout][9][cin] | WsumS [cout][cin] | Wmus [cout]   (doubles, one buffer)
+__global__ __launch_bounds__(FOLD_NT) void fold_style_kernel(const float* w, int cout, int cin, const double* Ss, const double* mu_s, double* Ws,
+                                                               double* WsumS, double* Wmus) {
+  extern __shared__ double fsm[];          // wrow [cin * 9] (as doubles, [c][t]) | ws [9 * ipad] | part
+  __shared__ double red[256];
+  const int o = blockIdx.x, tid = threadIdx.x;
+  const int ipad = (cin + 15) / 16 * 16;
+  double* wrow = fsm;
+  double* ws = fsm + cin * 9;
+  double* part = ws + 9 * ipad;
+  for (int e = tid; e < cin * 9; e += FOLD_NT) wrow[e] = (double)w[(size_t)o * cin * 9 + e];
+  for (int e = tid; e < 9 * ipad; e += FOLD_NT) ws[e] = 0.;
+  __syncthreads();
+  fold_columns<9>(wrow, 1, 9, Ss, cin, ipad, true, part, [&](int tap, int i, double v) { ws[tap * ipad + i] = v; });
+  __syncthreads();
+  for (int e = tid; e < 9 * cin; e += FOLD_NT) { const int tap = e / cin, i = e - tap * cin; Ws[((size_t)o * 9 + tap) * cin + i] = ws[tap * ipad + i]; }
+  for (int i = tid; i < cin; i += FOLD_NT) {
+    double a = 0.;
+    for (int t = 0; t < 9; ++t) a += ws[t * ipad + i];
+    WsumS[(size_t)o * cin + i] = a;
+  }
+  double p = 0.;
+  if (tid < 256)
+    for (int c = tid; c < cin; c += 256) {
+      double a = 0.;
+      for (int t = 0; t < 9; ++t) a += wrow[c * 9 + t];
+      p += a * mu_s[c];
+    }
+  if (tid < 256) red[tid] = p;
+  __syncthreads();
+  for (int k = 128; k > 0; k >>= 1) { if (tid < k) red[tid] += red[tid + k]; __syncthreads(); }
+  if (tid == 0) Wmus[o] = red[0];
+}
+
+// content side: Wc (= F of the content's EigResult), mu_c -> packed fp32 weights + bias + per-row max |W'| (float bits; rows >=
+// cout are zero).  rowmax replaces the atomicMax on one word (and the memset in front of it): launch_split_pack reduces it.
+// The bias rides in the same pass as a TENTH left-hand row: (WsumS[o][:] Wc)[i], then a dot product with mu_c over i.
+__global__ __launch_bounds__(FOLD_NT) void fold_fast_kernel(const float* w, const float* bias, int cout, int cin, int cout_pad, const double* Ws,
+                                                              const double* WsumS, const double* Wmus, const double* Wc, const double* mu_c, double alpha,
+                                                              float* wpk, float* bias_out, unsigned* rowmax) {
+  extern __shared__ double fsm[];          // lhs [10 * cin] ([t][k]; row 9 = WsumS[o][:]) | part
+  __shared__ double red[256];
+  __shared__ float redf[4];
+  const int o = blockIdx.x, tid = threadIdx.x;
+  const int ipad = (cin + 15) / 16 * 16;
+  const bool live = o < cout;
+  double* lhs = fsm;
+  double* part = fsm + 10 * cin;
+  if (live) {
+    for (int e = tid; e < 9 * cin; e += FOLD_NT) lhs[e] = Ws[(size_t)o * 9 * cin + e];
+    for (int e = tid; e < cin; e += FOLD_NT) lhs[9 * cin + e] = WsumS[(size_t)o * cin + e];
+  }
+  if (tid < 256) red[tid] = 0.;
+  __syncthreads();
+  float mx = 0.f;
+  fold_columns<10>(lhs, cin, 1, Wc, cin, ipad, live, part, [&](int row, int i, double sacc) {
+    if (row == 9) { red[i] = (live && i < cin) ? sacc * mu_c[i] : 0.; return; }      // ipad <= 256 columns: one slot each
+    double x = alpha * sacc;
+    if (live && i < cin && alpha != 1.0) x += (1.0 - alpha) * (double)w[((size_t)o * cin + i) * 9 + row];
+    const float f = (float)x;
+    mx = fmaxf(mx, fabsf(f));
+    const int chunk = i >> 4, kq = (i >> 2) & 3, r = i & 3;
+    wpk[((((size_t)chunk * 9 + row) * 4 + kq) * cout_pad + o) * 4 + r] = f;
+  });
+  __syncthreads();
+  for (int k = 128; k > 0; k >>= 1) { if (tid < k) red[tid] += red[tid + k]; __syncthreads(); }
+  if (tid == 0) bias_out[o] = live ? (float)((double)bias[o] + alpha * (Wmus[o] - red[0])) : 0.f;
+  for (int k = 32; k > 0; k >>= 1) mx = fmaxf(mx, __shfl_xor(mx, k));
+  if (tid < 256 && (tid & 63) == 0) redf[tid >> 6] = mx;
+  __syncthreads();
+  if (tid == 0) rowmax[o] = __float_as_uint(fmaxf(fmaxf(redf[0], redf[1]), fmaxf(redf[2], redf[3])));
+}
+
 // 1x1 affine as a centre-tap-only 3x3: used by wct_apply / wct_transform (the un-fused drop-in surface)
 __global__ void pack_center_kernel(const double* M, const double* b, int C, int cout_pad, float* wpk, float* bias_out) {
   const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -272,6 +404,34 @@ hipError_t launch_fold_affine(const float* w, const float* bias, int cout, int c
   }
   hipLaunchKernelGGL(fold_row_kernel, dim3((unsigned)cout_pad), dim3(256), (size_t)cin * 9 * sizeof(float), s, w, bias, cout, cin, cout_pad, M, b,
                      wpk_out, bias_out, maxbits_dev);
+  return hipGetLastError();
+}
+
+bool fold_fast_capable(int cin) {
+  const int ipad = (cin + 15) / 16 * 16;
+  return cin <= 128 && ipad <= 128 && (256 % ipad) == 0;
+}
+size_t fold_style_doubles(int cout, int cin) { return (size_t)cout * 9 * cin + (size_t)cout * cin + (size_t)cout; }
+
+hipError_t launch_fold_style(const float* w, int cout, int cin, const double* Ss, const double* mu_s, double* buf, hipStream_t s) {
+  if (!fold_fast_capable(cin)) return hipErrorInvalidValue;
+  const int ipad = (cin + 15) / 16 * 16;
+  double* Ws = buf;
+  double* WsumS = Ws + (size_t)cout * 9 * cin;
+  double* Wmus = WsumS + (size_t)cout * cin;
+  hipLaunchKernelGGL(fold_style_kernel, dim3((unsigned)cout), dim3(FOLD_NT), (size_t)(cin * 9 + 9 * ipad + fold_part_doubles(9)) * sizeof(double), s, w,
+                     cout, cin, Ss, mu_s, Ws, WsumS, Wmus);
+  return hipGetLastError();
+}
+
+hipError_t launch_fold_fast(const float* w, const float* bias, int cout, int cin, int cout_pad, const double* style_buf, const double* Wc,
+                            const double* mu_c, double alpha, float* wpk_out, float* bias_out, unsigned* rowmax_dev, hipStream_t s) {
+  if (!fold_fast_capable(cin)) return hipErrorInvalidValue;
+  const double* Ws = style_buf;
+  const double* WsumS = Ws + (size_t)cout * 9 * cin;
+  const double* Wmus = WsumS + (size_t)cout * cin;
+  hipLaunchKernelGGL(fold_fast_kernel, dim3((unsigned)cout_pad), dim3(FOLD_NT), (size_t)(10 * cin + fold_part_doubles(10)) * sizeof(double), s, w, bias,
+                     cout, cin, cout_pad, Ws, WsumS, Wmus, Wc, mu_c, alpha, wpk_out, bias_out, rowmax_dev);
   return hipGetLastError();
 }
 

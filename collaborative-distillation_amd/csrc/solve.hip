@@ -75,21 +75,34 @@ __device__ __forceinline__ double rotation(double al, double be, double ga, doub
 __host__ __device__ inline size_t eig_doubles(int C) { return 2 * (size_t)C * C + 2 * (size_t)C + 4; }
 __host__ __device__ inline size_t eig_F_offset(int C) { return (size_t)C * C + 2 * (size_t)C + 4; }
 
-__global__ void cov_kernel(int C, double n, const double* sum, const double* sumsq, double* res, double diag_add) {
-  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (blockIdx.x == 0 && threadIdx.x < 64) {   // eigenvalue floor from max E[x^2]: one wave, strided + shuffle max
-    double ex2 = 0.;                            // (a single thread walking the diagonal cost 19 us of dependent loads)
-    for (int j = threadIdx.x; j < C; j += 64) ex2 = fmax(ex2, sumsq[(size_t)j * C + j]);
-    for (int o = 32; o > 0; o >>= 1) ex2 = fmax(ex2, __shfl_xor(ex2, o));
-    if (threadIdx.x == 0) res[(size_t)C * C + 2 * C] = ABS_FLOOR * ex2 / n;
-  }
-  if (e >= (long)C * C) return;
+// element e of the covariance (+ mean, + floor by the first wave): shared by cov_kernel (grid-wide) and the single-workgroup
+// kernels that start from the raw moments (ns_lds_kernel, ns_prep_kernel) -- one arithmetic, bit-identical results
+__device__ __forceinline__ void cov_floor(int C, double n, const double* sumsq, double* res, int lane) {
+  double ex2 = 0.;                              // eigenvalue floor from max E[x^2]: one wave, strided + shuffle max
+  for (int j = lane; j < C; j += 64) ex2 = fmax(ex2, sumsq[(size_t)j * C + j]);   // (a single thread walking the diagonal cost 19 us of dependent loads)
+  for (int o = 32; o > 0; o >>= 1) ex2 = fmax(ex2, __shfl_xor(ex2, o));
+  if (lane == 0) res[(size_t)C * C + 2 * C] = ABS_FLOOR * ex2 / n;
+}
+__device__ __forceinline__ void cov_element(long e, int C, double n, const double* sum, const double* sumsq, double* res, double diag_add) {
   const int r = (int)(e / C), c = (int)(e % C);
   const double mr = sum[r] / n, mc = sum[c] / n;
   // symmetric by construction: use the (min,max) entry for both halves
   const int lo = r < c ? r : c, hi = r < c ? c : r;
   res[e] = (sumsq[(size_t)lo * C + hi] - n * mr * mc) / (n - 1.0) + (r == c ? diag_add : 0.0);   // diag_add: `--numpy` (+ I)
   if (c == 0) res[(size_t)C * C + C + r] = mr;  // mu
+}
+
+__global__ void cov_kernel(int C, double n, const double* sum, const double* sumsq, double* res, double diag_add) {
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (blockIdx.x == 0 && threadIdx.x < 64) cov_floor(C, n, sumsq, res, threadIdx.x);
+  if (e >= (long)C * C) return;
+  cov_element(e, C, n, sum, sumsq, res, diag_add);
+}
+
+// the covariance by ONE workgroup (the caller synchronises afterwards): the single-workgroup solvers start from the raw moments
+__device__ __forceinline__ void cov_by_block(int C, double n, const double* sum, const double* sumsq, double* res, double diag_add, int tid, int nt) {
+  if (tid < 64) cov_floor(C, n, sumsq, res, tid);
+  for (long e = tid; e < (long)C * C; e += nt) cov_element(e, C, n, sum, sumsq, res, diag_add);
 }
 
 // =====================================================================================================
@@ -125,9 +138,7 @@ struct NsWs {           // carved from the eig workspace
   int* ok;              // 1: F holds the Newton-Schulz result
 };
 
-__global__ __launch_bounds__(1024) void ns_init_kernel(const double* res, int C, double eps_rel, NsWs w, int maxit) {
-  __shared__ double red[1024];
-  __shared__ int sdead[512];
+__device__ __forceinline__ void ns_init_body(const double* res, int C, double eps_rel, const NsWs& w, int maxit, double* red, int* sdead) {
   const int tid = threadIdx.x;
   const double floor_ = res[(size_t)C * C + 2 * C];
   for (int j = tid; j < C; j += 1024) { const int d = !(res[(size_t)j * C + j] > floor_); w.dead[j] = d; sdead[j] = d; }
@@ -168,14 +179,39 @@ __global__ __launch_bounds__(1024) void ns_init_kernel(const double* res, int C,
   }
 }
 
+__global__ __launch_bounds__(1024) void ns_init_kernel(const double* res, int C, double eps_rel, NsWs w, int maxit) {
+  __shared__ double red[1024];
+  __shared__ int sdead[512];
+  ns_init_body(res, C, eps_rel, w, maxit, red, sdead);
+}
+
+__device__ __forceinline__ void ns_fill_element(long e, const double* res, int C, int Cp, const NsWs& w, const int* dead, double s0, double s1) {
+  const int r = (int)(e / Cp), c = (int)(e % Cp);
+  double y = r == c ? 1.0 : 0.0;     // padding rows/cols and dead channels: identity block
+  if (r < C && c < C && !dead[r] && !dead[c]) y = (res[(size_t)r * C + c] + (r == c ? s1 : 0.0)) / s0;
+  w.Y[0][e] = y;
+  w.Z[0][e] = r == c ? 1.0 : 0.0;
+}
+
 __global__ void ns_fill_kernel(const double* res, int C, int Cp, NsWs w) {
   const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= (long)Cp * Cp) return;
-  const int r = (int)(e / Cp), c = (int)(e % Cp);
-  double y = r == c ? 1.0 : 0.0;     // padding rows/cols and dead channels: identity block
-  if (r < C && c < C && !w.dead[r] && !w.dead[c]) y = (res[(size_t)r * C + c] + (r == c ? w.scal[1] : 0.0)) / w.scal[0];
-  w.Y[0][e] = y;
-  w.Z[0][e] = r == c ? 1.0 : 0.0;
+  ns_fill_element(e, res, C, Cp, w, w.dead, w.scal[0], w.scal[1]);
+}
+
+// Cp = 128 of the 16x levels: covariance + dead flags + Frobenius scale + Y0 / Z0 by ONE workgroup in ONE launch -- the three
+// kernels above each take 5-6 us of which most is launch latency, and they sit on the content side's critical path twice per
+// frame.  Same element arithmetic and the same summation order as cov_kernel / ns_init_kernel / ns_fill_kernel: bit-identical.
+__global__ __launch_bounds__(1024) void ns_prep_kernel(int C, int Cp, double n, const double* sum, const double* sumsq, double* res, double diag_add,
+                                                         double eps_rel, NsWs w, int maxit) {
+  __shared__ double red[1024];
+  __shared__ int sdead[512];
+  cov_by_block(C, n, sum, sumsq, res, diag_add, threadIdx.x, 1024);
+  __syncthreads();                   // the covariance (global memory, written by this workgroup) is visible to all its threads
+  ns_init_body(res, C, eps_rel, w, maxit, red, sdead);
+  __syncthreads();
+  const double s0 = w.scal[0], s1 = w.scal[1];
+  for (long e = threadIdx.x; e < (long)Cp * Cp; e += 1024) ns_fill_element(e, res, C, Cp, w, sdead, s0, s1);
 }
 
 // one 16x16 output tile per wave, 2x2 tiles per workgroup: D = P Q with the TRUE row-major operands.  (Reading P
@@ -340,14 +376,15 @@ __global__ __launch_bounds__(256) void ns_stage2_wide_kernel(NsWs w, int Cp, int
 }
 
 // F = Z / sqrt(s) (inverse) or Y * sqrt(s), dead rows/cols zeroed; ok = converged
-__global__ void ns_final_kernel(double* res, int C, int Cp, int inverse, NsWs w, int maxit, double zmax, int* info, const double* deflated) {
+__global__ void ns_final_kernel(double* res, int C, int Cp, int inverse, NsWs w, int maxit, double zmax, int* info, const double* deflated,
+                                int* ok_defer) {
   const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
   // n = executed iterations; the iterate lives in buffer n & 1.  resid[n-1] was measured on the iterate BEFORE the
   // last executed update, which squares it.
   const int n = *w.iters;
   bool ok = n >= 1 && n <= maxit && __longlong_as_double((long long)w.resid[n - 1]) < NS_TOL;
   if (ok && inverse && !deflated) ok = w.zfro[n] <= zmax * zmax;   // condition gate (NS_ZMAX)
-  if (e == 0) { *w.ok = ok ? 1 : 0; if (info && ok) *info = n; }
+  if (e == 0) { *w.ok = ok ? 1 : 0; if (ok_defer) *ok_defer = ok ? 1 : 0; if (info && ok) *info = n; }
   if (e >= (long)C * C || !ok) return;
   const int r = (int)(e / C), c = (int)(e % C);
   const double s = w.scal[0];
@@ -434,7 +471,8 @@ __device__ __forceinline__ f64x4 tile_gemm_lds(const double* P, const double* Q,
 
 template <int CP>
 __global__ __launch_bounds__((CP / 16) * (CP / 16) * 64) void ns_lds_kernel(double* res, int C, int inverse, double eps_rel,
-                                                                               int maxit, double zmax, int* ok_out, int* info) {
+                                                                               int maxit, double zmax, int* ok_out, int* info,
+                                                                               double npix, const double* sum, const double* sumsq, double diag_add) {
   constexpr int LD = CP + 2, TPR = CP / 16, NW = TPR * TPR, NT = NW * 64;
   extern __shared__ __attribute__((aligned(16))) char smem_ns[];
   double* Y = reinterpret_cast<double*>(smem_ns);
@@ -445,6 +483,9 @@ __global__ __launch_bounds__((CP / 16) * (CP / 16) * 64) void ns_lds_kernel(doub
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, kk = lane >> 4;
   const int i0 = (wave / TPR) * 16, j0 = (wave % TPR) * 16;
+  // covariance, means and eigenvalue floor from the raw moments first (cov_kernel's arithmetic; one launch less per solve)
+  cov_by_block(C, npix, sum, sumsq, res, diag_add, tid, NT);
+  __syncthreads();
   const double floor_ = res[(size_t)C * C + 2 * C];
   for (int j = tid; j < CP; j += NT) dead[j] = (j >= C) || !(res[(size_t)j * C + j] > floor_);   // padding = identity block too
   __syncthreads();
@@ -550,7 +591,7 @@ __device__ __forceinline__ double reduce_pair(double v) {
 //  * the kernel is bound by fp64 VALU issue on ONE CU: LPP lanes share a pair (each lane owns 2-row groups read as
 //    ds_read_b128), so the per-pair rotation arithmetic is amortised over 64/LPP pairs per wave instruction.
 template <int LPP>
-__global__ __launch_bounds__(64 * LPP) void jacobi_lds_kernel(double* res, int n_full, int* info, const int* ns_ok) {
+__global__ __launch_bounds__(64 * LPP) void jacobi_lds_kernel(double* res, int n_full, int* info, const int* ns_ok, double expo, double rel_thresh) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   if (*ns_ok) return;   // the Newton-Schulz path converged: nothing to do (uniform branch, before any barrier)
   __builtin_amdgcn_s_setprio(3);  // latency-critical single-CU kernel: win issue arbitration against co-resident conv waves
@@ -673,6 +714,25 @@ __global__ __launch_bounds__(64 * LPP) void jacobi_lds_kernel(double* res, int n
     Gg[(size_t)cj * n_full + live[r]] = G[cj * LD + r];  // column-major: column cj, full row index live[r]
   }
   if (tid == 0 && info) *info = 100 + sweep;   // 100 + sweeps: the Jacobi fallback ran
+  // F = SUM_{j live} lambda_j^(expo-2) G[:,j] G[:,j]^T -- sym_power_kernel's arithmetic and summation order, by this one workgroup
+  // (the fallback is the rare path: its second gated launch cost every solve 4 us + a launch gap for nothing)
+  __syncthreads();                    // G (global, column-major) and lambda as written above are visible to the workgroup
+  double* wj = G;                      // the LDS copy is no longer needed
+  double lmax = 0.;
+  for (int j = 0; j < n_full; ++j) lmax = fmax(lmax, lamg[j]);
+  const double thr = fmax(rel_thresh * lmax, floor_);
+  for (int j = tid; j < n_full; j += blockDim.x) {
+    const double l = lamg[j];
+    wj[j] = (l > thr && l > 0.) ? pow(l, expo - 2.0) : 0.;
+  }
+  __syncthreads();
+  double* out = res + eig_F_offset(n_full);
+  for (int e = tid; e < n_full * n_full; e += blockDim.x) {
+    const int a = e / n_full, b = e - a * n_full;
+    double sacc = 0.;
+    for (int j = 0; j < n_full; ++j) sacc += wj[j] * Gg[(size_t)j * n_full + a] * Gg[(size_t)j * n_full + b];
+    out[e] = sacc;
+  }
 }
 
 // ---- C > 128: columns stay in global memory (L2 resident); one launch per tournament round, one wave per pair.
@@ -762,14 +822,15 @@ size_t eig_workspace_bytes(int C) {
 }
 size_t assemble_workspace_bytes(int C) { return (size_t)C * C * sizeof(double); }
 
+bool eig_is_big(int C, bool wide_model) { return C > 128 || (wide_model && C > 64 && ns_pad(C) % 64 == 0); }
+
 hipError_t launch_eig(int C, double n, const double* sum, const double* sumsq, int inverse, double* res, int* info_dev,
-                      void* ws, size_t ws_bytes, hipStream_t s, double diag_add, bool wide_model) {
+                      void* ws, size_t ws_bytes, hipStream_t s, double diag_add, bool wide_model, int* ok_defer) {
   if (C < 2 || (C & 1) || C > 512 || n < 2) return hipErrorInvalidValue;  // unbiased covariance needs n >= 2
   if (ws_bytes < eig_workspace_bytes(C)) return hipErrorOutOfMemory;
   const size_t cc = (size_t)C * C;
   const int Cp = ns_pad(C);
   const size_t cp2 = (size_t)Cp * Cp;
-  hipLaunchKernelGGL(cov_kernel, dim3((unsigned)((cc + 255) / 256)), dim3(256), 0, s, C, n, sum, sumsq, res, diag_add);
   NsWs w;
   double* p = reinterpret_cast<double*>(ws);
   w.Y[0] = p; w.Y[1] = p + cp2; w.Z[0] = p + 2 * cp2; w.Z[1] = p + 3 * cp2; w.T = p + 4 * cp2;
@@ -779,7 +840,10 @@ hipError_t launch_eig(int C, double n, const double* sum, const double* sumsq, i
   w.iters = reinterpret_cast<int*>(w.zfro + NS_MAXIT_REG + 2);
   w.ok = w.iters + 1;
   w.dead = w.iters + 2;
-  const bool big = C > 128 || (wide_model && C > 64 && ns_pad(C) % 64 == 0);   // deflated, scaled iteration + host check of the outcome
+  const bool big = eig_is_big(C, wide_model);   // deflated, scaled iteration + host check of the outcome (or the caller's: ok_defer)
+  // the covariance: its own grid-wide launch only where one workgroup would be too slow (C > 128); the single-workgroup front
+  // ends below (ns_lds_kernel, ns_prep_kernel) start from the raw moments themselves
+  if (big) hipLaunchKernelGGL(cov_kernel, dim3((unsigned)((cc + 255) / 256)), dim3(256), 0, s, C, n, sum, sumsq, res, diag_add);
   static const int maxit_env = [] { const char* e = wct_debug_env("WCT_NS_MAXIT"); const int v = e ? atoi(e) : 0; return v < 1 ? 0 : (v > NS_MAXIT_REG ? NS_MAXIT_REG : v); }();
   // 64 < Cp <= 128 without deflation (the 128-channel levels of --mode 16x): the iteration is scaled with an ASSUMED lower
   // spectral bound 1e-5 (see the schedule below) -- a wrong guess costs iterations, never correctness (only the upper bound 1
@@ -797,14 +861,18 @@ hipError_t launch_eig(int C, double n, const double* sum, const double* sumsq, i
       const size_t lds = (size_t)3 * cp * (cp + 2) * sizeof(double) + (size_t)(nw + 2) * sizeof(double) + (size_t)cp * sizeof(int);
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return e;
-      hipLaunchKernelGGL(kern, dim3(1), dim3((unsigned)nw * 64), lds, s, res, C, inverse, 1e-15, maxit, NS_ZMAX, w.ok, info_dev);
+      hipLaunchKernelGGL(kern, dim3(1), dim3((unsigned)nw * 64), lds, s, res, C, inverse, 1e-15, maxit, NS_ZMAX, w.ok, info_dev, n, sum, sumsq, diag_add);
       return hipSuccess;
     };
     hipError_t e = Cp == 32 ? go(ns_lds_kernel<32>, 32) : go(ns_lds_kernel<64>, 64);
     if (e != hipSuccess) return e;
   } else {
-    hipLaunchKernelGGL(ns_init_kernel, dim3(1), dim3(1024), 0, s, res, C, big ? NS_DEFLATE : 1e-15, w, maxit);
-    hipLaunchKernelGGL(ns_fill_kernel, dim3((unsigned)((cp2 + 255) / 256)), dim3(256), 0, s, res, C, Cp, w);
+    if (big) {
+      hipLaunchKernelGGL(ns_init_kernel, dim3(1), dim3(1024), 0, s, res, C, NS_DEFLATE, w, maxit);
+      hipLaunchKernelGGL(ns_fill_kernel, dim3((unsigned)((cp2 + 255) / 256)), dim3(256), 0, s, res, C, Cp, w);
+    } else {
+      hipLaunchKernelGGL(ns_prep_kernel, dim3(1), dim3(1024), 0, s, C, Cp, n, sum, sumsq, res, diag_add, 1e-15, w, maxit);
+    }
     const dim3 g1(Cp / 32, Cp / 32, 1), g2(Cp / 32, Cp / 32, 2);
     // Deflated problem: every eigenvalue of Z Y = B/s starts in [l0, 1] with l0 = delta/s KNOWN, so the iteration can be
     // scaled optimally (T = mu (3I - mu^2 Z Y)/2 with mu^2 = 3/(1 + x + x^2), x = sqrt of the current lower bound: the cubic
@@ -866,8 +934,10 @@ hipError_t launch_eig(int C, double n, const double* sum, const double* sumsq, i
       gemm(wb[ip], Sb, Sa, nullptr, 1., nullptr, 0., 0.);             // P R S
       deflated = Sa;
     }
-    hipLaunchKernelGGL(ns_final_kernel, dim3((unsigned)((cc + 255) / 256)), dim3(256), 0, s, res, C, Cp, inverse, w, maxit, NS_ZMAX, info_dev, deflated);
+    hipLaunchKernelGGL(ns_final_kernel, dim3((unsigned)((cc + 255) / 256)), dim3(256), 0, s, res, C, Cp, inverse, w, maxit, NS_ZMAX, info_dev, deflated,
+                       big ? ok_defer : nullptr);
   }
+  if (big && ok_defer) return hipGetLastError();   // the caller reads *ok_defer after ITS synchronisation point and re-runs without deferral if it is 0
   if (big) {
     // C > 128 has no single-CU Jacobi: the deflated iteration above covers singular and ill-conditioned covariances, and the
     // slow global-memory Jacobi (one launch per tournament round) is the net under it -- the outcome of the iteration is read
@@ -906,13 +976,12 @@ hipError_t launch_eig(int C, double n, const double* sum, const double* sumsq, i
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return e;
       const unsigned threads = (unsigned)(((C / 2) * LPPv + 63) / 64 * 64);
-      hipLaunchKernelGGL(kern, dim3(1), dim3(threads), lds, s, res, C, info_dev, (const int*)w.ok);
+      hipLaunchKernelGGL(kern, dim3(1), dim3(threads), lds, s, res, C, info_dev, (const int*)w.ok, inverse ? -0.5 : 0.5, REL_THRESH);
       return hipSuccess;
     };
+    // ONE gated launch: Jacobi and the symmetric power of its result (it returns at once when the iteration converged)
     hipError_t e = lpp == 16 ? go(jacobi_lds_kernel<16>, 16) : lpp == 8 ? go(jacobi_lds_kernel<8>, 8) : go(jacobi_lds_kernel<4>, 4);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(sym_power_kernel, dim3((unsigned)((cc + 255) / 256)), dim3(256), 0, s, res, C, inverse ? -0.5 : 0.5, REL_THRESH,
-                       (const int*)w.ok);
   }
   return hipGetLastError();
 }

@@ -72,6 +72,8 @@ struct wct_ctx {
   Module mod[2][6];
   // workspace
   DevBuf featC, featS, tmpT, wsAsm, small, foldW, foldW16, eigC, eigS[6];
+  DevBuf foldS[6];    // per level: the style-side part of the fast fold (misc.hip fold_style_kernel), valid when fold_ready[level]
+  bool fold_ready[6] = {false, false, false, false, false, false};
   int cur_level = 0, cur_h = 0, cur_w = 0;  // content feature held in featC by wct_content_encode
   DevBuf u8c, u8s, u8o;   // fp32 planar staging of wct_stylize_u8 (content, style, result)
   DevBuf rsz_tmp;         // wct_resize_u8: uint8 image between the horizontal and the vertical pass
@@ -84,11 +86,18 @@ struct wct_ctx {
   int l1fuse = 1;     // 1: level 1 of the 16x cascade without materialising relu1_1 (level1.hip)
   int sp = 1;         // 1: intermediate activations of the f16x3 path in SP16 (split at the producer, DMA-staged consumers)
   int u8fuse = 1;     // 1: wct_stylize_u8 reads / writes uint8 inside the first / last kernel where one exists (reserved)
+  int fastfold = 1;   // 1: (W Ss) Wc fold without T = Ss Wc / M / b on the content side's critical path where the decoder allows (cin <= 128)
   int upconv = 1;     // 1: decoder layers behind an upsample run as per-parity 2x2 convolutions of the low-resolution map (4/9 of the products)
   int fuse = 1;       // 1: fused conv11+conv12+pool / conv12+conv11 kernels at the full-resolution ends of the 16x networks
   int overlap = 1;    // 1: style side on the side lane (overlaps the content side); 0: everything on the caller's stream
   int conv_mode = 1;  // 0: exact-fp32 MFMA everywhere; 1: split-f16 (f16x3) MFMA for all but the first conv
   unsigned* sat_dev = nullptr;   // saturation counter (conv_f16_dev.h SatTrack): threads that clamped an activation to +-65504 (saturating)
+  // --mode original (C > 128): outcomes of the deflated iterations of ONE API call, checked once at the call's end instead of one
+  // stream synchronisation per solve (launch_eig ok_defer)
+  int* ok_log = nullptr;         // device [64]
+  int* ok_host = nullptr;        // pinned [64]
+  int ok_n = 0;
+  bool defer_big = false;
   unsigned* sat_host = nullptr;  // pinned host mirror, refreshed asynchronously at the end of every compute entry point (wct_range_poll)
   // profiling
   bool prof = false;
@@ -601,9 +610,35 @@ int eig_impl(wct_ctx* ctx, Lane& ln, int C, double n, const double* sum, const d
   if (int rc = ensure(ctx, res, eig_result_bytes(C))) return rc;
   if (int rc = ensure(ctx, ln.wsEig, eig_workspace_bytes(C))) return rc;
   ProfScope ps(ctx, ln.stream, inverse ? "matfun_invsqrt" : "matfun_sqrt", 0, 0);
+  int* defer = nullptr;
+  if (ctx->defer_big && eig_is_big(C, ctx->wide_model) && ctx->ok_n < 64) defer = ctx->ok_log + ctx->ok_n++;
   HIPCHK(ctx, launch_eig(C, n, sum, sumsq, inverse, reinterpret_cast<double*>(res.p), info_dev, ln.wsEig.p, ln.wsEig.cap, ln.stream,
-                         (inverse && ctx->numpy_variant) ? 1.0 : 0.0, ctx->wide_model));
+                         (inverse && ctx->numpy_variant) ? 1.0 : 0.0, ctx->wide_model, defer));
   return WCT_OK;
+}
+
+// --mode original: run `body` with the C > 128 solves' outcomes deferred (no stream synchronisation inside the solves: the host
+// enqueues the whole call, so the style lane really overlaps the content lane), then ONE synchronisation and a look at the
+// outcomes; if an iteration did not converge (singular beyond the deflation, NaN) the call is repeated the synchronous way,
+// where each solve falls back to the global-memory Jacobi on the spot.  The 16x path (C <= 128) never synchronises.
+template <typename BODY>
+int with_deferred_solves(wct_ctx* ctx, bool wait_side, BODY&& body) {
+  if (!ctx->wide_model) return body();
+  ctx->defer_big = true;
+  ctx->ok_n = 0;
+  int rc = body();
+  ctx->defer_big = false;
+  const int n = ctx->ok_n;
+  ctx->ok_n = 0;
+  if (rc) return rc;
+  if (n == 0) return WCT_OK;
+  if (wait_side) HIPCHK(ctx, hipStreamSynchronize(ctx->side.stream));
+  HIPCHK(ctx, hipMemcpyAsync(ctx->ok_host, ctx->ok_log, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, ctx->main.stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->main.stream));
+  bool all = true;
+  for (int i = 0; i < n; ++i) all = all && ctx->ok_host[i] == 1;
+  if (all) return WCT_OK;
+  return body();     // defer_big is off: every solve checks (and repairs) itself
 }
 
 int assemble_impl(wct_ctx* ctx, int C, const DevBuf& eig_c, const DevBuf& eig_s, double alpha, double* M, double* b) {
@@ -651,6 +686,62 @@ int fold_impl(wct_ctx* ctx, int level, const double* M, const double* b, ConvDes
     }
   } else {
     HIPCHK(ctx, launch_fold_affine(l.w_oihw, l.bias_raw, l.d.cout, l.d.cin, l.d.cout_pad, M, b, wpk, bias, nullptr, st));
+  }
+  return WCT_OK;
+}
+
+// the style-side part of the fast fold for `level`, on `st`, from the style EigResult in ctx->eigS[level] (F = cov_s^(1/2), mu_s)
+bool fast_fold_level(const wct_ctx* ctx, int level) {
+  const Module& m = ctx->mod[WCT_KIND_DEC][level];
+  return ctx->fastfold && m.loaded && m.layers[0].w_oihw && fold_fast_capable(m.layers[0].d.cin);
+}
+
+int style_fold(wct_ctx* ctx, int level, hipStream_t st, const char* lane_tag) {
+  ctx->fold_ready[level] = false;
+  if (!fast_fold_level(ctx, level)) return WCT_OK;
+  const LayerDev& l = ctx->mod[WCT_KIND_DEC][level].layers[0];
+  const size_t C = l.d.cin, cc = C * C;
+  if (int rc = ensure(ctx, ctx->foldS[level], fold_style_doubles(l.d.cout, l.d.cin) * sizeof(double))) return rc;
+  const double* res = reinterpret_cast<const double*>(ctx->eigS[level].p);
+  (void)lane_tag;
+  ProfScope ps(ctx, st, "fold_style", 0, 0);
+  HIPCHK(ctx, launch_fold_style(l.w_oihw, l.d.cout, l.d.cin, res + eig_result_F_offset(C), res + cc + C, reinterpret_cast<double*>(ctx->foldS[level].p), st));
+  ctx->fold_ready[level] = true;
+  return WCT_OK;
+}
+
+// content side: cov_c^(-1/2) and mu_c (ctx->eigC) + the level's style-side part -> the folded first decoder conv, no M / b
+int fold_fast_impl(wct_ctx* ctx, int level, double alpha, ConvDesc& out) {
+  Module& m = ctx->mod[WCT_KIND_DEC][level];
+  const LayerDev& l = m.layers[0];
+  hipStream_t st = ctx->main.stream;
+  const size_t C = l.d.cin, cc = C * C;
+  const size_t wbytes = (size_t)l.d.cin_chunks * 36 * l.d.cout_pad * 4 * sizeof(float);
+  if (int rc = ensure(ctx, ctx->foldW, wbytes + l.d.cout_pad * sizeof(float))) return rc;
+  float* wpk = reinterpret_cast<float*>(ctx->foldW.p);
+  float* bias = wpk + wbytes / sizeof(float);
+  const int taps = l.d.cout_pad == 16 ? 10 : 9;
+  const size_t b16 = conv_f16_weight_bytes(l.d.cin, l.d.cout_pad, taps);
+  const bool phase = (l.d.flags & CONV_OUT_NCHW3) && l.d.cout_pad == 16 && l.d.cout == 3;
+  const size_t bph = phase ? conv_phase_weight_bytes(l.d.cin) : 0;
+  if (int rc = ensure(ctx, ctx->foldW16, b16 + 64 + bph + 512 * sizeof(unsigned))) return rc;
+  char* base = reinterpret_cast<char*>(ctx->foldW16.p);
+  float* inv = reinterpret_cast<float*>(base + b16);
+  unsigned* rowmax = reinterpret_cast<unsigned*>(base + b16 + 64 + bph);
+  const double* resc = reinterpret_cast<const double*>(ctx->eigC.p);
+  out = l.d;
+  out.wpk = wpk; out.bias = bias; out.wph16 = nullptr;
+  {
+    ProfScope ps(ctx, st, "fold_affine", 0, 0);
+    HIPCHK(ctx, launch_fold_fast(l.w_oihw, l.bias_raw, l.d.cout, l.d.cin, l.d.cout_pad, reinterpret_cast<const double*>(ctx->foldS[level].p),
+                                 resc + eig_result_F_offset(C), resc + cc + C, alpha, wpk, bias, rowmax, st));
+    HIPCHK(ctx, launch_split_pack(wpk, l.d.cin, l.d.cout_pad, taps, rowmax, base, inv, st, true, l.d.cout_pad));
+    out.wpk16 = base;
+    out.inv_scale_ptr = inv;
+    if (phase) {
+      HIPCHK(ctx, launch_split_pack_phase(wpk, l.d.cin, rowmax, base + b16 + 64, st, l.d.cout_pad));
+      out.wph16 = base + b16 + 64;
+    }
   }
   return WCT_OK;
 }
@@ -709,6 +800,7 @@ int style_side(wct_ctx* ctx, int level, const float* style, int Hs, int Ws) {
     if (int rc = moments_impl(ctx, ln, fS, C, hs, ws, 0, ws, sv.sum, sv.sumsq)) return rc;
   }
   if (int rc = eig_impl(ctx, ln, C, (double)hs * ws, sv.sum, sv.sumsq, 0, ctx->eigS[level], sv.info + 1)) return rc;
+  if (int rc = style_fold(ctx, level, ln.stream, "side")) return rc;      // (W Ss), off the content side's critical path
   HIPCHK(ctx, hipEventRecord(ctx->ev_style[level], ln.stream));
   return WCT_OK;
 }
@@ -746,10 +838,14 @@ int content_side(wct_ctx* ctx, int level, const float* content, int H, int W, fl
   if (int rc = eig_impl(ctx, ln, C, (double)h * w, sv.sum, sv.sumsq, 1, ctx->eigC, sv.info)) return rc;
   // csF = wct.transform(cF, sF, csF, alpha)                  (WCT.py:104) -- as an affine map
   HIPCHK(ctx, hipStreamWaitEvent(ln.stream, ctx->ev_style[level], 0));
-  if (int rc = assemble_impl(ctx, C, ctx->eigC, ctx->eigS[level], alpha, M, b)) return rc;
   // Img = decoder(csF)                                       (WCT.py:105) -- M, b folded into the first conv
   ConvDesc first;
-  if (int rc = fold_impl(ctx, level, M, b, first)) return rc;
+  if (ctx->conv_mode == 1 && ctx->fold_ready[level] && fast_fold_level(ctx, level)) {
+    if (int rc = fold_fast_impl(ctx, level, alpha, first)) return rc;      // straight from cov_c^(-1/2): no T, M, b on the critical path
+  } else {
+    if (int rc = assemble_impl(ctx, C, ctx->eigC, ctx->eigS[level], alpha, M, b)) return rc;
+    if (int rc = fold_impl(ctx, level, M, b, first)) return rc;
+  }
   if (l1) {
     if (int rc = l1_decode_impl(ctx, level, content, H, W, first, out)) return rc;
   } else {
@@ -786,6 +882,8 @@ int wct_create(int device, wct_ctx** out) {
   for (int l = 1; l <= 5 && ok; ++l) ok = hipEventCreateWithFlags(&c->ev_style[l], hipEventDisableTiming) == hipSuccess;
   ok = ok && hipMalloc(reinterpret_cast<void**>(&c->sat_dev), 256) == hipSuccess && hipMemset(c->sat_dev, 0, 256) == hipSuccess;
   ok = ok && hipHostMalloc(reinterpret_cast<void**>(&c->sat_host), 64, hipHostMallocDefault) == hipSuccess;
+  ok = ok && hipMalloc(reinterpret_cast<void**>(&c->ok_log), 64 * sizeof(int)) == hipSuccess;
+  ok = ok && hipHostMalloc(reinterpret_cast<void**>(&c->ok_host), 64 * sizeof(int), hipHostMallocDefault) == hipSuccess;
   if (ok) *c->sat_host = 0u;
   if (!ok) { wct_destroy(c); return WCT_ERR_HIP; }
   *out = c;
@@ -808,12 +906,15 @@ void wct_destroy(wct_ctx* ctx) {
   ctx->rsz_axes.clear();
   for (int l = 0; l < 6; ++l) {
     release(ctx->eigS[l]);
+    release(ctx->foldS[l]);
     if (ctx->ev_style[l]) (void)hipEventDestroy(ctx->ev_style[l]);
   }
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
   if (ctx->side.stream) (void)hipStreamDestroy(ctx->side.stream);
   if (ctx->sat_dev) (void)hipFree(ctx->sat_dev);
   if (ctx->sat_host) (void)hipHostFree(ctx->sat_host);
+  if (ctx->ok_log) (void)hipFree(ctx->ok_log);
+  if (ctx->ok_host) (void)hipHostFree(ctx->ok_host);
   }
   delete ctx;
 }
@@ -881,6 +982,7 @@ int wct_debug_set(wct_ctx* ctx, const char* key, double value) {
   else if (!strcmp(key, "l1fuse")) ctx->l1fuse = v;
   else if (!strcmp(key, "u8fuse")) ctx->u8fuse = v;
   else if (!strcmp(key, "upconv")) ctx->upconv = v;
+  else if (!strcmp(key, "fastfold")) ctx->fastfold = v;
   else if (!strcmp(key, "side_priority")) {
     // priority of the style-side stream relative to the default: 0 = default, 1 = lowest (style kernels only fill the
     // content cascade's gaps), -1 = highest
@@ -893,7 +995,7 @@ int wct_debug_set(wct_ctx* ctx, const char* key, double value) {
     ctx->side.stream = ns;
     return WCT_OK;
   }
-  else return fail(ctx, WCT_ERR_INVALID, "debug_set: unknown key '%s' (fuse, sp, l1fuse, u8fuse, upconv, side_priority)", key);
+  else return fail(ctx, WCT_ERR_INVALID, "debug_set: unknown key '%s' (fuse, sp, l1fuse, u8fuse, upconv, fastfold, side_priority)", key);
   HIPCHK(ctx, hipStreamSynchronize(ctx->side.stream));
   return WCT_OK;
 }
@@ -923,6 +1025,7 @@ int wct_load_module(wct_ctx* ctx, int kind, int level, int n_layers, const wct_l
   }
   Module& m = ctx->mod[kind][level];
   free_module(m);
+  ctx->fold_ready[level] = false;   // a style-side fold of the old decoder is stale
   m.layers.resize(n_layers);
   for (int i = 0; i < n_layers; ++i) {
     const wct_layer& L = layers[i];
@@ -1143,9 +1246,11 @@ int wct_style_transfer_level(wct_ctx* ctx, int level, const float* content, int 
   if (!ctx) return WCT_ERR_INVALID;
   WCT_GUARD(ctx);
   if (!valid_level(level) || !content || !style || !out) return fail(ctx, WCT_ERR_INVALID, "style_transfer_level: bad arguments");
-  if (int rc = fork_side(ctx)) return rc;
-  if (int rc = style_side(ctx, level, style, Hs, Ws)) return rc;
-  if (int rc = content_side(ctx, level, content, H, W, alpha, out, Ho, Wo)) return rc;
+  if (int rc = with_deferred_solves(ctx, false, [&]() -> int {
+        if (int rc = fork_side(ctx)) return rc;
+        if (int rc = style_side(ctx, level, style, Hs, Ws)) return rc;
+        return content_side(ctx, level, content, H, W, alpha, out, Ho, Wo);
+      })) return rc;
   return range_readback(ctx);
 }
 
@@ -1155,11 +1260,13 @@ int wct_style_prepare_levels(wct_ctx* ctx, const float* style, int Hs, int Ws, u
   if (!ctx) return WCT_ERR_INVALID;
   WCT_GUARD(ctx);
   if (!style) return fail(ctx, WCT_ERR_INVALID, "style_prepare: NULL style");
-  if (int rc = fork_side(ctx)) return rc;
-  for (int level = 5; level >= 1; --level)
-    if ((level_mask >> level & 1u) && ctx->mod[WCT_KIND_ENC][level].loaded)
-      if (int rc = style_side(ctx, level, style, Hs, Ws)) return rc;
-  return WCT_OK;
+  return with_deferred_solves(ctx, true, [&]() -> int {
+    if (int rc = fork_side(ctx)) return rc;
+    for (int level = 5; level >= 1; --level)
+      if ((level_mask >> level & 1u) && ctx->mod[WCT_KIND_ENC][level].loaded)
+        if (int rc = style_side(ctx, level, style, Hs, Ws)) return rc;
+    return WCT_OK;
+  });
 }
 
 int wct_style_prepare(wct_ctx* ctx, const float* style, int Hs, int Ws) { return wct_style_prepare_levels(ctx, style, Hs, Ws, 0x3eu); }
@@ -1201,6 +1308,7 @@ int wct_style_import(wct_ctx* ctx, int level, const double* stats) {
   hipStream_t st = ctx->main.stream;
   HIPCHK(ctx, hipMemcpyAsync(res + eig_result_F_offset(C), stats, cc * sizeof(double), hipMemcpyDeviceToDevice, st));
   HIPCHK(ctx, hipMemcpyAsync(res + cc + C, stats + cc, C * sizeof(double), hipMemcpyDeviceToDevice, st));
+  if (int rc = style_fold(ctx, level, st, "main")) return rc;
   HIPCHK(ctx, hipEventRecord(ctx->ev_style[level], st));   // what content_side / wct_content_solve wait for
   return WCT_OK;
 }
@@ -1297,10 +1405,12 @@ int wct_stylize(wct_ctx* ctx, const float* content, int H, int W, const float* s
   if (!content || !style || !out || num_run < 1) return fail(ctx, WCT_ERR_INVALID, "stylize: bad arguments");
   // style side of all five levels first, on the side lane: it only depends on the style image (the SAME image at
   // every level and every run, WCT.py:121-125), so it is computed once and overlaps the content cascade
-  if (int rc = fork_side(ctx)) return rc;
-  for (int level = 5; level >= 1; --level)
-    if (int rc = style_side(ctx, level, style, Hs, Ws)) return rc;
-  return cascade(ctx, content, H, W, alpha, num_run, out, Ho, Wo);
+  return with_deferred_solves(ctx, false, [&]() -> int {
+    if (int rc = fork_side(ctx)) return rc;
+    for (int level = 5; level >= 1; --level)
+      if (int rc = style_side(ctx, level, style, Hs, Ws)) return rc;
+    return cascade(ctx, content, H, W, alpha, num_run, out, Ho, Wo);
+  });
 }
 
 int wct_stylize_prepared(wct_ctx* ctx, const float* content, int H, int W, float alpha, int num_run, float* out, int* Ho,
@@ -1310,7 +1420,7 @@ int wct_stylize_prepared(wct_ctx* ctx, const float* content, int H, int W, float
   if (!content || !out || num_run < 1) return fail(ctx, WCT_ERR_INVALID, "stylize_prepared: bad arguments");
   for (int level = 5; level >= 1; --level)
     if (!ctx->eigS[level].p) return fail(ctx, WCT_ERR_STATE, "stylize_prepared: no style statistics for level %d (wct_style_prepare / wct_style_import)", level);
-  return cascade(ctx, content, H, W, alpha, num_run, out, Ho, Wo);
+  return with_deferred_solves(ctx, false, [&]() -> int { return cascade(ctx, content, H, W, alpha, num_run, out, Ho, Wo); });
 }
 
 int wct_u8_to_planar(wct_ctx* ctx, const uint8_t* hwc, int H, int W, float* planar) {
@@ -1476,7 +1586,10 @@ int wct_reserve(wct_ctx* ctx, int H, int W, int Hs, int Ws) {
     moms = std::max(moms, moments_workspace_bytes(C, (long)hs * ws));
     const LayerDev& l0 = d.layers[0];
     if (int rc = ensure(ctx, ctx->foldW, ((size_t)l0.d.cin_chunks * 36 * l0.d.cout_pad * 4 + l0.d.cout_pad) * sizeof(float))) return rc;
-    if (int rc = ensure(ctx, ctx->foldW16, conv_f16_weight_bytes(l0.d.cin, l0.d.cout_pad, l0.d.cout_pad == 16 ? 10 : 9) + 64 + conv_phase_weight_bytes(l0.d.cin))) return rc;
+    if (int rc = ensure(ctx, ctx->foldW16, conv_f16_weight_bytes(l0.d.cin, l0.d.cout_pad, l0.d.cout_pad == 16 ? 10 : 9) + 64 + conv_phase_weight_bytes(l0.d.cin) +
+                                                512 * sizeof(unsigned))) return rc;
+    if (fast_fold_level(ctx, level))
+      if (int rc = ensure(ctx, ctx->foldS[level], fold_style_doubles(l0.d.cout, l0.d.cin) * sizeof(double))) return rc;
     if (int rc = ensure(ctx, ctx->eigS[level], eig_result_bytes(C))) return rc;
   }
   if (int rc = ensure(ctx, ctx->main.actA, act)) return rc;

@@ -107,11 +107,12 @@ hipError_t launch_l1_moments(const ConvDesc& enc0, const float* img, int H, int 
                              void* workspace, size_t workspace_bytes, hipStream_t s);
 // fp32 packed weights (device) -> scaled split-f16 packed weights + inverse scale (device scalar)
 //   have_max: *maxbits_dev already holds max |w| (written by launch_fold_affine); otherwise it is computed here
+//   nmax > 1: maxbits_dev is an ARRAY of nmax partial maxima (launch_fold_fast's rowmax) that the kernel reduces itself
 hipError_t launch_split_pack(const float* wpk32, int cin, int cout_pad, int taps, unsigned* maxbits_dev, void* out,
-                             float* inv_scale_out, hipStream_t s, bool have_max = false);
+                             float* inv_scale_out, hipStream_t s, bool have_max = false, int nmax = 1);
 // the same weights (cout_pad 16, 3 real couts) in the block-packed layout; *maxbits_dev must hold max |w| (same scale as above)
 size_t conv_phase_weight_bytes(int cin);
-hipError_t launch_split_pack_phase(const float* wpk32, int cin, const unsigned* maxbits_dev, void* out, hipStream_t s);
+hipError_t launch_split_pack_phase(const float* wpk32, int cin, const unsigned* maxbits_dev, void* out, hipStream_t s, int nmax = 1);
 
 // ---- image edge: uint8 HWC <-> planar fp32 (ToTensor / save_image of the reference's harness)
 hipError_t launch_u8_to_planar(const uint8_t* hwc, long npix, float* planar, hipStream_t s);
@@ -143,8 +144,13 @@ size_t assemble_workspace_bytes(int C);
 //   diag_add is added to the covariance's diagonal (1.0 on the content side = the reference's `--numpy` variant)
 //   wide_model: the module set has feature maps wider than 128 channels (--mode original); its 128-channel level then takes the
 //   deflated iteration too (ill-conditioned there: the 26-iteration budget ran out and the 2 ms LDS Jacobi took over)
+//   ok_defer (device int, C > 128 path only -- eig_is_big): instead of reading the iteration's outcome back and synchronising the
+//   stream inside the call (to decide about the slow global-memory Jacobi net), the outcome is written there and the CALLER checks
+//   it at its own synchronisation point, re-running without deferral if it is 0
+bool eig_is_big(int C, bool wide_model);
 hipError_t launch_eig(int C, double n, const double* sum, const double* sumsq, int inverse, double* res, int* info_dev,
-                      void* workspace, size_t workspace_bytes, hipStream_t s, double diag_add = 0.0, bool wide_model = false);
+                      void* workspace, size_t workspace_bytes, hipStream_t s, double diag_add = 0.0, bool wide_model = false,
+                      int* ok_defer = nullptr);
 hipError_t launch_assemble(int C, const double* eig_c, const double* eig_s, double alpha, double rel_thresh,
                            double* M, double* b, void* workspace, size_t workspace_bytes, hipStream_t s);
 
@@ -154,6 +160,14 @@ hipError_t launch_assemble(int C, const double* eig_c, const double* eig_s, doub
 hipError_t launch_fold_affine(const float* w_oihw, const float* bias, int cout, int cin, int cout_pad,
                               const double* M, const double* b, float* wpk_out, float* bias_out,
                               unsigned* maxbits_dev, hipStream_t s);
+// The same fold without C x C products on the content side's critical path (misc.hip): style-side part once per style
+// (buf: fold_style_doubles(cout, cin) doubles), then Wc = cov_c^(-1/2), mu_c -> folded weights + bias + per-output-row max |W'|
+// (rowmax_dev: cout_pad words, consumed by launch_split_pack(..., nmax = cout_pad)); cin <= 128
+bool fold_fast_capable(int cin);
+size_t fold_style_doubles(int cout, int cin);
+hipError_t launch_fold_style(const float* w_oihw, int cout, int cin, const double* Ss, const double* mu_s, double* buf, hipStream_t s);
+hipError_t launch_fold_fast(const float* w_oihw, const float* bias, int cout, int cin, int cout_pad, const double* style_buf, const double* Wc,
+                            const double* mu_c, double alpha, float* wpk_out, float* bias_out, unsigned* rowmax_dev, hipStream_t s);
 // pack [cout][cin][3][3] (+ bias) into the conv kernel's layout (device side, used for the apply conv)
 hipError_t launch_pack_center_tap(const double* M, const double* b, int C, int cout_pad, float* wpk_out,
                                   float* bias_out, hipStream_t s);

@@ -14,9 +14,12 @@
  *     (layout 1, the reference's layout) as selected by `layout`.
  *   - a context is bound to one device and one HIP stream; calls are asynchronous on that stream.
  *     One context per GPU / rank; a context is not thread-safe.
- *     One exception: with feature maps wider than 128 channels (--mode original) each matrix-function solve reads back a
- *     4-byte "converged" flag (one stream synchronisation per solve, and one per sweep of the Jacobi fallback if that ever
- *     runs), so calls of that mode block the host and cannot be captured into a HIP graph; the 16x path never synchronises.
+ *     One exception: with feature maps wider than 128 channels (--mode original) the outcome of each matrix-function iteration
+ *     is read back (a slow global-memory Jacobi is the net under a non-converged one).  The cascade-type calls (wct_stylize*,
+ *     wct_style_transfer_level, wct_style_prepare*) enqueue everything, synchronise ONCE at their end, look at all outcomes and
+ *     repeat the call the synchronous way if one failed; the split-level calls (wct_solve, wct_content_solve, wct_transform)
+ *     synchronise once per solve.  Calls of that mode therefore block the host and cannot be captured into a HIP graph; the 16x
+ *     path never synchronises.
  *   - the caller owns every buffer it passes; the context owns weights and an internal workspace that
  *     grows on first use of a size (no allocation on later calls of the same or smaller size).
  */

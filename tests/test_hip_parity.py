@@ -179,6 +179,33 @@ def test_unfused_reference_sequence_matches_fused(torch_cuda, wct16, golden):
         assert rel_err(fused, unfused) < 2e-5, k
 
 
+def test_fast_fold_matches_the_map_based_fold(torch_cuda, weights16x, golden):
+    """The cascade folds csF = M cF + b into the decoder's first conv.  Default: (W Ss) Wc with the style-side product formed on
+    the side stream (misc.hip fold_style_kernel / fold_fast_kernel: no T = Ss Wc, no M, no b on the critical path); debug switch
+    "fastfold" 0: M and b first (launch_assemble), then W M (fold_row_kernel) -- the form the split-level API keeps.  Same fp64
+    arithmetic in another association -> fp32 round-off agreement per level, alpha = 1 and the alpha-blend, a constant content
+    (cov_c = 0: Wc = 0) included; and the profile shows that the default path really runs without launch_assemble."""
+    from wct_hip import WCT
+    torch = torch_cuda
+    g = golden("g4_cascade.npz")
+    c, s = cu(torch, g["b.content"])[None], cu(torch, g["b.style"])[None]
+    const = torch.full((1, 3, 64, 80), 0.3, device="cuda")
+    outs = {}
+    for ff in (1, 0):
+        w = WCT(types.SimpleNamespace(mode="16x", alpha=1.0), weights=weights16x)
+        w.debug_set("fastfold", ff)
+        w.profile_reset(); w.profile(True)
+        outs[ff] = [w.style_transfer_level(k, c, s, alpha).clone() for k in (5, 4, 3, 2, 1) for alpha in (1.0, 0.6)]
+        outs[ff] += [w.style_transfer_level(k, const, s).clone() for k in (3, 1)]
+        outs[ff].append(w.stylize(c, s).clone())
+        w.profile(False)
+        names = {e["name"] for e in w.profile_read()}
+        assert ("assemble_Mb" in names) == (ff == 0) and ("fold_style" in names) == (ff == 1), names
+    for a, b in zip(outs[1][:-1], outs[0][:-1]):
+        assert a.shape == b.shape and float((a - b).abs().max() / b.abs().max()) < 2e-6
+    assert float((outs[1][-1] - outs[0][-1]).abs().max() / outs[0][-1].abs().max()) < 1e-4     # five levels chained
+
+
 def test_fused_ends_match_unfused(torch_cuda, weights16x):
     """Fused ends vs the layer-by-layer path (odd sizes, image-border tiles).
     Decoder tail (conv12+conv11): conv12 has the unfused kernel's arithmetic; the final 16 -> 3 conv runs block-packed in the
