@@ -69,11 +69,12 @@ GOLD = os.path.join(REPO, "tests", "golden")
 
 
 def source_id():
-    """sha256 over the kernel sources: ties a committed PMC summary to the build it was taken from."""
+    """sha256 over the sources of the convolution / moments kernels (the ones with HBM traffic worth counting): ties a committed
+    PMC summary to the build it was taken from.  Same function in tools/pmc_summary.py."""
     h = hashlib.sha256()
     d = os.path.join(PKG, "csrc")
     for f in sorted(os.listdir(d)):
-        if f.endswith((".hip", ".h")):
+        if f.startswith(("conv", "level1", "moments", "wct_common")) and f.endswith((".hip", ".h")):
             h.update(f.encode())
             h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]

@@ -41,7 +41,14 @@ def main():
         import json
         js = {k: {"calls": n, "read_MB_per_launch": round(rd, 3), "write_MB_per_launch": round(wr, 3), "avg_us": round(us, 2)}
               for _, k, n, rd, wr, us in rows if not k.startswith(("void at::", "__amd"))}
-        json.dump({"note": "HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, KiB units, "
+        import hashlib, os
+        h = hashlib.sha256()     # the same id bench.py computes: ties this summary to the kernel sources it was taken from
+        d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "collaborative-distillation_amd", "csrc")
+        for fn in sorted(os.listdir(d)):
+            if fn.startswith(("conv", "level1", "moments", "wct_common")) and fn.endswith((".hip", ".h")):
+                h.update(fn.encode())
+                h.update(open(os.path.join(d, fn), "rb").read())
+        json.dump({"source_id": h.hexdigest()[:16], "note": "HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, KiB units, "
                            "FETCH doubled per MI355X_MICROARCH.md); bench.py reports the entry of its dominant kernel as roofline.traffic",
                    "kernels": js}, open(sys.argv[3].rsplit(".", 1)[0] + ".json", "w"), indent=1)
     print(out)
