@@ -284,6 +284,25 @@ __global__ __launch_bounds__(256) void ns_stage2_kernel(NsWs w, int Cp, int it) 
 //      of 32 bytes out of each).  The k order differs from tile_gemm's -- both are "true row-major operands".
 struct Acc32 { f64x4 t[4]; };   // MFMA tile (ri, cj) at t[2 ri + cj]: rows i0 + 16 ri + kk + 4 reg, cols j0 + 16 cj + li
 
+// One 16-block of k for the 2x2 MFMA tiles of a wave: 4 16-byte loads of P (two row groups), 8 8-byte loads of Q.
+struct KBlock { f64x2 a0l, a0h, a1l, a1h; double b0[4], b1[4]; };
+__device__ __forceinline__ void kblock_load(KBlock& b, const double* p0, const double* p1, const double* q0, int Cp, int k0) {
+  b.a0l = *reinterpret_cast<const f64x2*>(p0 + k0); b.a0h = *reinterpret_cast<const f64x2*>(p0 + k0 + 2);
+  b.a1l = *reinterpret_cast<const f64x2*>(p1 + k0); b.a1h = *reinterpret_cast<const f64x2*>(p1 + k0 + 2);
+#pragma unroll
+  for (int u = 0; u < 4; ++u) { b.b0[u] = q0[(size_t)(k0 + u) * Cp]; b.b1[u] = q0[(size_t)(k0 + u) * Cp + 16]; }
+}
+__device__ __forceinline__ void kblock_mfma(const KBlock& b, Acc32& acc) {
+  const double a0[4] = {b.a0l[0], b.a0l[1], b.a0h[0], b.a0h[1]}, a1[4] = {b.a1l[0], b.a1l[1], b.a1h[0], b.a1h[1]};
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    acc.t[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[u], b.b0[u], acc.t[0], 0, 0, 0);
+    acc.t[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[u], b.b1[u], acc.t[1], 0, 0, 0);
+    acc.t[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[u], b.b0[u], acc.t[2], 0, 0, 0);
+    acc.t[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[u], b.b1[u], acc.t[3], 0, 0, 0);
+  }
+}
+
 __device__ __forceinline__ void gemm32_splitk(const double* P, const double* Q, int Cp, int i0, int j0, int lane, int wave,
                                                double (*red)[16 * 64], Acc32& acc) {
   const int li = lane & 15, kk = lane >> 4;
@@ -293,22 +312,12 @@ __device__ __forceinline__ void gemm32_splitk(const double* P, const double* Q, 
   const double* p0 = P + (size_t)(i0 + li) * Cp + 4 * kk;
   const double* p1 = p0 + (size_t)16 * Cp;
   const double* q0 = Q + (size_t)(4 * kk) * Cp + j0 + li;
+  // (An explicit software pipeline over pairs of k-blocks -- the next pair's loads in flight during this pair's 32 MFMAs -- was
+  // measured in round 3: the C = 512 matrix functions got 6 % SLOWER, 3.08 -> 3.28 ms per cfg3 frame and side; the compiler's own
+  // schedule of the 2-unrolled loop stays.)
+  KBlock x;
 #pragma unroll 2
-  for (int k0 = kbeg; k0 < kend; k0 += 16) {
-    const f64x2 a0l = *reinterpret_cast<const f64x2*>(p0 + k0), a0h = *reinterpret_cast<const f64x2*>(p0 + k0 + 2);
-    const f64x2 a1l = *reinterpret_cast<const f64x2*>(p1 + k0), a1h = *reinterpret_cast<const f64x2*>(p1 + k0 + 2);
-    double b0[4], b1[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) { b0[u] = q0[(size_t)(k0 + u) * Cp]; b1[u] = q0[(size_t)(k0 + u) * Cp + 16]; }
-    const double a0[4] = {a0l[0], a0l[1], a0h[0], a0h[1]}, a1[4] = {a1l[0], a1l[1], a1h[0], a1h[1]};
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      acc.t[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[u], b0[u], acc.t[0], 0, 0, 0);
-      acc.t[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[u], b1[u], acc.t[1], 0, 0, 0);
-      acc.t[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[u], b0[u], acc.t[2], 0, 0, 0);
-      acc.t[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[u], b1[u], acc.t[3], 0, 0, 0);
-    }
-  }
+  for (int k0 = kbeg; k0 < kend; k0 += 16) { kblock_load(x, p0, p1, q0, Cp, k0); kblock_mfma(x, acc); }
   if (wave) {
 #pragma unroll
     for (int t = 0; t < 4; ++t)
