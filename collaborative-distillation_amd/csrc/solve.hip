@@ -303,10 +303,13 @@ __device__ __forceinline__ void kblock_mfma(const KBlock& b, Acc32& acc) {
   }
 }
 
+// NS = k slices = waves per workgroup: 4 (Cp = 128) or 8 (Cp >= 256: at one 4-wave workgroup per CU these launches are bound by
+// each wave's serial chain of k-blocks -- 8 at Cp = 512 -- not by the matrix cores; twice the waves halve the chain)
+template <int NS>
 __device__ __forceinline__ void gemm32_splitk(const double* P, const double* Q, int Cp, int i0, int j0, int lane, int wave,
                                                double (*red)[16 * 64], Acc32& acc) {
   const int li = lane & 15, kk = lane >> 4;
-  const int kq = Cp >> 2, kbeg = wave * kq, kend = kbeg + kq;
+  const int kq = Cp / NS, kbeg = wave * kq, kend = kbeg + kq;
 #pragma unroll
   for (int t = 0; t < 4; ++t) acc.t[t] = f64x4{0., 0., 0., 0.};
   const double* p0 = P + (size_t)(i0 + li) * Cp + 4 * kk;
@@ -331,18 +334,22 @@ __device__ __forceinline__ void gemm32_splitk(const double* P, const double* Q, 
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int at = (t * 4 + r) * 64 + lane;
-        acc.t[t][r] = ((acc.t[t][r] + red[0][at]) + red[1][at]) + red[2][at];
+        double v = acc.t[t][r];
+#pragma unroll
+        for (int q = 0; q < NS - 1; ++q) v += red[q][at];      // slice order: fixed, reproducible
+        acc.t[t][r] = v;
       }
   }
 }
 
-__global__ __launch_bounds__(256) void ns_stage1_wide_kernel(NsWs w, int Cp, int it, double ca, double cb) {
+template <int NS>
+__global__ __launch_bounds__(64 * NS) void ns_stage1_wide_kernel(NsWs w, int Cp, int it, double ca, double cb) {
   if (ns_converged(w, it)) return;
-  __shared__ double red[3][16 * 64];
+  __shared__ double red[NS - 1][16 * 64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i0 = blockIdx.y * 32, j0 = blockIdx.x * 32, cur = it & 1;
   Acc32 acc;
-  gemm32_splitk(w.Z[cur], w.Y[cur], Cp, i0, j0, lane, wave, red, acc);
+  gemm32_splitk<NS>(w.Z[cur], w.Y[cur], Cp, i0, j0, lane, wave, red, acc);
   if (wave) return;
   const int li = lane & 15, kk = lane >> 4;
   double m = 0.;
@@ -359,14 +366,15 @@ __global__ __launch_bounds__(256) void ns_stage1_wide_kernel(NsWs w, int Cp, int
   if (lane == 0) atomicMax(&w.resid[it], (unsigned long long)__double_as_longlong(m));
 }
 
-__global__ __launch_bounds__(256) void ns_stage2_wide_kernel(NsWs w, int Cp, int it) {
+template <int NS>
+__global__ __launch_bounds__(64 * NS) void ns_stage2_wide_kernel(NsWs w, int Cp, int it) {
   if (ns_converged(w, it)) return;
-  __shared__ double red[3][16 * 64];
+  __shared__ double red[NS - 1][16 * 64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i0 = blockIdx.y * 32, j0 = blockIdx.x * 32, cur = it & 1, nxt = cur ^ 1;
   const bool zside = blockIdx.z == 1;
   Acc32 acc;
-  gemm32_splitk(zside ? w.T : w.Y[cur], zside ? w.Z[cur] : w.T, Cp, i0, j0, lane, wave, red, acc);
+  gemm32_splitk<NS>(zside ? w.T : w.Y[cur], zside ? w.Z[cur] : w.T, Cp, i0, j0, lane, wave, red, acc);
   if (wave) return;
   double* out = zside ? w.Z[nxt] : w.Y[nxt];
   const int li = lane & 15, kk = lane >> 4;
@@ -419,13 +427,14 @@ __global__ void ns_final_kernel(double* res, int C, int Cp, int inverse, NsWs w,
 constexpr double NS_DEFLATE = 1e-12;
 
 // D = alpha P Q + beta R + gamma I ; optionally D2 = I - D
-__global__ __launch_bounds__(256) void ns_gemm_kernel(const double* P, const double* Q, double* D, double* D2, int Cp, double alpha,
-                                                       const double* R, double beta, double gamma) {
-  __shared__ double red[3][16 * 64];
+template <int NS>
+__global__ __launch_bounds__(64 * NS) void ns_gemm_kernel(const double* P, const double* Q, double* D, double* D2, int Cp, double alpha,
+                                                           const double* R, double beta, double gamma) {
+  __shared__ double red[NS - 1][16 * 64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
   Acc32 acc;
-  gemm32_splitk(P, Q, Cp, i0, j0, lane, wave, red, acc);
+  gemm32_splitk<NS>(P, Q, Cp, i0, j0, lane, wave, red, acc);
   if (wave) return;
   const int li = lane & 15, kk = lane >> 4;
 #pragma unroll
@@ -895,15 +904,20 @@ hipError_t launch_eig(int C, double n, const double* sum, const double* sumsq, i
       if (big) {
         const double mu = xlow <= 0.9 ? sqrt(3.0 / (1.0 + xlow + xlow * xlow)) : 1.0;
         xlow = mu * xlow * (3.0 - mu * mu * xlow * xlow) / 2.0;
-        hipLaunchKernelGGL(ns_stage1_wide_kernel, g1, dim3(256), 0, s, w, Cp, it, 1.5 * mu, 0.5 * mu * mu * mu);
-        hipLaunchKernelGGL(ns_stage2_wide_kernel, g2, dim3(256), 0, s, w, Cp, it);
+        if (Cp >= 256 && Cp % 128 == 0) {
+          hipLaunchKernelGGL(ns_stage1_wide_kernel<8>, g1, dim3(512), 0, s, w, Cp, it, 1.5 * mu, 0.5 * mu * mu * mu);
+          hipLaunchKernelGGL(ns_stage2_wide_kernel<8>, g2, dim3(512), 0, s, w, Cp, it);
+        } else {
+          hipLaunchKernelGGL(ns_stage1_wide_kernel<4>, g1, dim3(256), 0, s, w, Cp, it, 1.5 * mu, 0.5 * mu * mu * mu);
+          hipLaunchKernelGGL(ns_stage2_wide_kernel<4>, g2, dim3(256), 0, s, w, Cp, it);
+        }
       } else {
         const double mu = xlow <= 0.9 ? sqrt(3.0 / (1.0 + xlow + xlow * xlow)) : 1.0;
         xlow = mu * xlow * (3.0 - mu * mu * xlow * xlow) / 2.0;
         const double ca = 1.5 * mu, cb = 0.5 * mu * mu * mu;
         if (splitk128) {   // Cp = 128, adaptive iteration on the split-k tiles (2 k-blocks per wave instead of 8)
-          hipLaunchKernelGGL(ns_stage1_wide_kernel, g1, dim3(256), 0, s, w, Cp, it, ca, cb);
-          hipLaunchKernelGGL(ns_stage2_wide_kernel, g2, dim3(256), 0, s, w, Cp, it);
+          hipLaunchKernelGGL(ns_stage1_wide_kernel<4>, g1, dim3(256), 0, s, w, Cp, it, ca, cb);
+          hipLaunchKernelGGL(ns_stage2_wide_kernel<4>, g2, dim3(256), 0, s, w, Cp, it);
         } else {
           hipLaunchKernelGGL(ns_stage1_kernel, g1, dim3(256), 0, s, w, Cp, it, ca, cb);
           hipLaunchKernelGGL(ns_stage2_kernel, g2, dim3(256), 0, s, w, Cp, it);
@@ -915,7 +929,8 @@ hipError_t launch_eig(int C, double n, const double* sum, const double* sumsq, i
       const unsigned eb = (unsigned)((cp2 + 255) / 256);
       const double de = NS_DEFLATE / (1.0 + NS_DEFLATE);   // delta / s in the iteration's units
       auto gemm = [&](const double* P, const double* Q, double* D, double* D2, double alpha, const double* R, double beta, double gamma) {
-        hipLaunchKernelGGL(ns_gemm_kernel, g1, dim3(256), 0, s, P, Q, D, D2, Cp, alpha, R, beta, gamma);
+        if (Cp >= 256 && Cp % 128 == 0) hipLaunchKernelGGL(ns_gemm_kernel<8>, g1, dim3(512), 0, s, P, Q, D, D2, Cp, alpha, R, beta, gamma);
+        else hipLaunchKernelGGL(ns_gemm_kernel<4>, g1, dim3(256), 0, s, P, Q, D, D2, Cp, alpha, R, beta, gamma);
       };
       hipLaunchKernelGGL(ns_settle_kernel, dim3(eb), dim3(256), 0, s, w, Cp);
       const double* Rm = inverse ? w.Z[0] : w.Y[0];

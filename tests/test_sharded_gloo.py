@@ -166,7 +166,7 @@ def test_strip_bounds():
     assert ext_bounds((0, 1280), 10240, 272) == (0, 1552) and ext_bounds((8960, 10240), 10240, 272) == (8688, 10240)
     with pytest.raises(ValueError):
         strip_bounds(40, 4)
-    # FLOP overhead of the two halo modes (DESIGN 6): config 4 on 8 GPUs = 1280-wide strips
+    # FLOP overhead of the two halo modes (DESIGN 7): config 4 on 8 GPUs = 1280-wide strips
     from wct_hip.sharded import ShardedStylizer, halo_flop_overhead
     assert 0.25 < halo_flop_overhead(1280, "recompute") < 0.27 and 0.15 < halo_flop_overhead(1280, "exchange") < 0.16
     assert ShardedStylizer(None, None, 4096, 10240, 2048, 2048, rank=3, world=8).halo_mode == "exchange"
