@@ -429,10 +429,13 @@ def main():
                                          "relu4_1_encode_ms": round(ms4e, 3),
                                          "relu4_1_encode_frac_hbm_8TBs": round(364.0 * H4 * W4 / ms4e / 1e6 / PEAK_HBM_GBS, 4)}
             del o4
-            # one rank's share of the 8-GPU config-4 job (8 x 1280 columns, exchange-mode halos), timed on this GPU with its
-            # peers emulated (wct_hip/sharded.py LoopbackGroup): ranks 0 (edge strip, style level 5) and 3 (interior, level 2)
-            passes["cfg4_rank_sim"] = rank_sim(wct16, c4, style, ms4)
+            # one rank's share of the 8-GPU jobs, timed on this GPU with its peers emulated (wct_hip/sharded.py LoopbackGroup): ranks 0
+            # (edge strip, style level 5) and 3 (interior, level 2).  cfg4: ONE 10240x4096 frame in 8 x 1280 columns (exchange-mode
+            # halos, strong scaling); cfg2x8: the driver's default N = 8 workload, 8 x 3840 columns (recompute halos, weak scaling)
+            passes["cfg4_rank_sim"] = rank_sim(wct16, style, H4, W4, lambda a, b: c4[:, :, a:b].contiguous(), ms4, "strong")
             del c4
+            passes["cfg2x8_rank_sim"] = rank_sim(wct16, style, H, W * 8, lambda a, b: cu(frame_columns(a, b, "cfg2")), dt / args.steps * 1e3, "weak")
+            finish_rank_sims()
 
     if extra and rank == 0 and world == 1:
         # BASELINE configs[2]: --mode original, generated weights
@@ -537,12 +540,14 @@ def main():
         sys.exit(1)
 
 
-def rank_sim(wct, c4, style, ms_untiled, world=8, ranks=(0, 3), frames=4):
-    """What ONE rank of the `world`-GPU config-4 job executes (ShardedStylizer.stylize_strip on its strip + exchange-mode halos,
-    the style levels it owns, the per-level collectives as launches on a 1-rank RCCL communicator, the neighbour exchange as
-    device copies), timed on this GPU.  `host_enqueue_ms`: wall time until stylize_strip has returned for every frame (Python +
-    torch.distributed + ctypes orchestration, nothing waited for); `ms_per_frame`: the same frames with the final sync.  The
-    slowest rank bounds the N = 8 frame time: no link time, no skew -- the compute-only strong-scaling prediction."""
+def rank_sim(wct, style, Hf, Wf, strip_of, ms_one_gpu, scaling, world=8, ranks=(0, 3), frames=4):
+    """What ONE rank of the `world`-GPU job executes (ShardedStylizer.stylize_strip on its strip + halos, the style levels it
+    owns, the per-level collectives as launches on a 1-rank RCCL communicator, the neighbour exchange as device copies), timed
+    on this GPU.  `host_enqueue_ms`: wall time until stylize_strip has returned for every frame (Python + torch.distributed +
+    ctypes orchestration, nothing waited for); `ms_per_frame`: the same frames with the final sync.  The slowest rank bounds
+    the N-GPU frame time: no link time, no skew -- the compute-only scaling prediction.
+    strip_of(x0, x1) -> device tensor of content columns [x0, x1); scaling "strong": ms_one_gpu is the WHOLE frame on one GPU;
+    "weak": ms_one_gpu is one GPU's own 1/world of the frame (its N = 1 step)."""
     import torch.distributed as tdist
     from wct_hip.sharded import LoopbackGroup, ShardedStylizer
     real = None
@@ -560,15 +565,16 @@ def rank_sim(wct, c4, style, ms_untiled, world=8, ranks=(0, 3), frames=4):
     wct.style_prepare(style)
     stats = {L: wct.style_export(L).clone() for L in (5, 4, 3, 2, 1)}
     torch.cuda.synchronize()
-    res = {"world": world, "halo_mode": None, "collectives": note, "ranks": {}}
+    res = {"world": world, "frame": "%dx%d" % (Wf, Hf), "scaling": scaling, "halo_mode": None, "collectives": note, "ranks": {}}
     worst = 0.0
+    hs, ws = int(style.shape[-2]), int(style.shape[-1])
     for r in ranks:
         grp = LoopbackGroup(r, world, real)
         grp.style_stats = stats
-        sh = ShardedStylizer(wct, grp, H4, W4, HS, WS, halo_mode="auto")
+        sh = ShardedStylizer(wct, grp, Hf, Wf, hs, ws, halo_mode="auto")
         res["halo_mode"] = sh.halo_mode
         x0, x1 = sh.input_columns()
-        strip = c4[:, :, x0:x1].contiguous()
+        strip = strip_of(x0, x1)
         for _ in range(2):
             sh.stylize_strip(strip, style)
         torch.cuda.synchronize()
@@ -583,13 +589,22 @@ def rank_sim(wct, c4, style, ms_untiled, world=8, ranks=(0, 3), frames=4):
         worst = max(worst, ms)
         res["ranks"][str(r)] = {"columns_in": x1 - x0, "columns_owned": sh.own[1] - sh.own[0], "ms_per_frame": round(ms, 3),
                                 "host_enqueue_ms": round((t1 - t0) / frames * 1e3, 3)}
-    if real is not None and tdist.is_initialized():
-        tdist.destroy_process_group()
-    res["predicted_8gpu_ms_per_frame"] = round(worst, 3)
-    res["predicted_8gpu_MPs"] = round(H4 * W4 / 1e6 / worst * 1e3, 1)
-    res["predicted_speedup_vs_1gpu"] = round(ms_untiled / worst, 2)
+        del strip
+    res["predicted_ms_per_frame"] = round(worst, 3)
+    res["predicted_MPs"] = round(Hf * Wf / 1e6 / worst * 1e3, 1)
+    if scaling == "strong":
+        res["predicted_speedup_vs_1gpu"] = round(ms_one_gpu / worst, 2)
+        res["predicted_efficiency"] = round(ms_one_gpu / worst / world, 3)
+    else:
+        res["predicted_efficiency"] = round(ms_one_gpu / worst, 3)
     res["note"] = "compute + orchestration of the slowest simulated rank; xGMI transfer time (<= 3.5 MB per exchange, 132 KB per all-reduce) and rank skew not included"
     return res
+
+
+def finish_rank_sims():
+    import torch.distributed as tdist
+    if tdist.is_available() and tdist.is_initialized():
+        tdist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -174,6 +174,19 @@ class ShardedStylizer:
         e, dist = self.e, self.dist
         self.check_range(wait=False)     # the previous frame's node-wide flag, if it has landed
         range_flag = getattr(e, "range_flag", None)
+        # the engine's own per-call range check must not fire on ONE rank in the middle of a frame -- its peers would wait for it in
+        # the next collective for ever; the flag travels in the all-reduce instead and check_range() raises on every rank
+        strict = getattr(e, "strict_range", None)
+        if strict is not None:
+            e.strict_range = False
+        try:
+            return self._stylize_strip(content_ext, style, range_flag)
+        finally:
+            if strict is not None:
+                e.strict_range = strict
+
+    def _stylize_strip(self, content_ext, style, range_flag):
+        e, dist = self.e, self.dist
         flags = []
         img = content_ext if content_ext.dim() == 4 else content_ext[None]
         W_cur = self.W                       # width of the (virtual) full image at the current level

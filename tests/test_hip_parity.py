@@ -375,6 +375,41 @@ def test_mode_16x_kd2sd_uses_16x_graphs(torch_cuda, wct16, weights16x):
         WCT(types.SimpleNamespace(mode="16x_kd2sd", alpha=1.0))
 
 
+def test_wide_model_deferred_solves_fall_back(torch_cuda, tmp_path):
+    """--mode original: the C > 128 matrix functions no longer synchronise the host once per solve; the cascade-type calls enqueue
+    everything, synchronise once, look at the iterations' outcomes and repeat the call the synchronous way if one failed
+    (wct_api.hip with_deferred_solves).  Forced here: with an iteration budget of 3 (WCT_NS_MAXIT, honoured under WCT_DEBUG) no
+    deflated iteration can converge, so every call must come back through the synchronous path and its global-memory Jacobi net --
+    and agree with the normal run to the solvers' agreement (1e-5 of the output range; level 2, C = 128, takes the deflated path
+    in a wide model too).  A fresh process per setting: the budget is read once."""
+    import os
+    import subprocess
+    import sys
+    from tests.conftest import PKG, REPO
+    code = (
+        "import sys, types, numpy as np, torch\n"
+        "sys.path[:0] = [%r, %r]\n"
+        "from wct_hip import WCT, model_zoo\n"
+        "w = WCT(types.SimpleNamespace(mode='original', alpha=1.0), weights=model_zoo.synth_weights('original', 2024))\n"
+        "g = torch.Generator(device='cuda').manual_seed(5)\n"
+        "c, s = torch.rand((1, 3, 64, 80), device='cuda', generator=g), torch.rand((1, 3, 48, 64), device='cuda', generator=g)\n"
+        "outs = [w.style_transfer_level(k, c, s).cpu().numpy() for k in (5, 3, 2)] + [w.stylize(c, s).cpu().numpy()]\n"
+        "w.style_prepare(s); outs.append(w.stylize_prepared(c).cpu().numpy())\n"
+        "assert all(np.isfinite(o).all() for o in outs)\n"
+        "np.savez(sys.argv[1], *outs)\n" % (REPO, PKG))
+    res = {}
+    for tag, env in (("normal", {}), ("forced", {"WCT_DEBUG": "1", "WCT_NS_MAXIT": "3"})):
+        out = str(tmp_path / (tag + ".npz"))
+        r = subprocess.run([sys.executable, "-c", code, out], env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        with np.load(out) as z:
+            res[tag] = [z[k] for k in z.files]
+    for a, b in zip(res["forced"][:3], res["normal"][:3]):
+        assert a.shape == b.shape and rel_err(a, b) < 1e-5
+    assert np.array_equal(res["normal"][3], res["normal"][4])          # prepared-style cascade == stylize, bit for bit
+    assert rel_err(res["forced"][3], res["normal"][3]) < 1e-3           # five chained levels of random 512-channel stacks
+
+
 def test_replica_stylizer_single_rank(torch_cuda, wct16):
     """wct_hip/replicas.py with one rank is stylize(); the multi-rank exchange is covered on CPU (gloo, test_sharded_gloo.py)."""
     from wct_hip.replicas import ReplicaStylizer

@@ -128,6 +128,52 @@ def test_replicas_three_ranks_on_the_hip_engine(tmp_path):
         assert got.shape == ref.shape and np.array_equal(got, ref), rank
 
 
+def _range_worker(rank, world, port, out_dir):
+    for p in (REPO, PKG):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from wct_hip import WCT, model_zoo
+        from wct_hip.sharded import ShardedStylizer
+        wct = WCT(types.SimpleNamespace(mode="16x", alpha=1.0), weights=model_zoo.load_npz_weights(os.path.join(PKG, "weights", "16x.npz")))
+        g = torch.Generator(device="cuda").manual_seed(17)
+        H, W = 160, 2048
+        content = torch.rand((3, H, W), device="cuda", generator=g)
+        style = torch.rand((3, 200, 180), device="cuda", generator=g)
+        content[1, 80, 1900] = 3.0e6            # far inside rank 1's strip (and beyond rank 0's 272-column halo): only rank 1 clamps
+        sh = ShardedStylizer(wct, dist, H, W, 200, 180, halo_mode="recompute")
+        x0, x1 = sh.input_columns()
+        out = sh.stylize_strip(content[:, :, x0:x1].contiguous(), style)       # must complete on BOTH ranks (no rank raises mid-frame)
+        own_clamped = wct.saturation_count() > 0
+        try:
+            sh.check_range()
+            raised = False
+        except OverflowError:
+            raised = True
+        with open(os.path.join(out_dir, "r%d.txt" % rank), "w") as f:
+            f.write("%d %d %d" % (int(own_clamped), int(raised), int(bool(torch.isfinite(out).all()))))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_range_flag_travels_with_the_moments(tmp_path):
+    """A clamp of the f16x3 arithmetic on ONE rank (a 3e6 pixel in rank 1's strip) is seen by EVERY rank: each rank's saturation
+    counter rides as one more double in the all-reduce of the moments, ShardedStylizer.check_range() raises OverflowError on both,
+    and nobody raises in the middle of the frame (the engine's per-call check is suspended inside stylize_strip: a rank that
+    stopped there would leave its peers waiting in the next collective)."""
+    import torch.multiprocessing as mp
+    mp.spawn(_range_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r0 = [int(v) for v in open(str(tmp_path / "r0.txt")).read().split()]
+    r1 = [int(v) for v in open(str(tmp_path / "r1.txt")).read().split()]
+    assert r0 == [0, 1, 1], r0      # rank 0 did not clamp itself, raised all the same, finished its strip
+    assert r1 == [1, 1, 1], r1
+
+
 def _cfg5_worker(rank, world, port, out_dir):
     for p in (REPO, PKG):
         if p not in sys.path:
