@@ -98,6 +98,7 @@ struct wct_ctx {
   int* ok_host = nullptr;        // pinned [64]
   int ok_n = 0;
   bool defer_big = false;
+  unsigned sat_mark = 0;         // the saturation counter at the end of the last VERIFIED wide-model call (see with_deferred_solves)
   unsigned* sat_host = nullptr;  // pinned host mirror, refreshed asynchronously at the end of every compute entry point (wct_range_poll)
   // profiling
   bool prof = false;
@@ -634,10 +635,16 @@ int with_deferred_solves(wct_ctx* ctx, bool wait_side, BODY&& body) {
   if (n == 0) return WCT_OK;
   if (wait_side) HIPCHK(ctx, hipStreamSynchronize(ctx->side.stream));
   HIPCHK(ctx, hipMemcpyAsync(ctx->ok_host, ctx->ok_log, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, ctx->main.stream));
+  HIPCHK(ctx, hipMemcpyAsync(ctx->ok_host + 63, ctx->sat_dev, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->main.stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->main.stream));
   bool all = true;
   for (int i = 0; i < n; ++i) all = all && ctx->ok_host[i] == 1;
-  if (all) return WCT_OK;
+  if (all) { ctx->sat_mark = static_cast<unsigned>(ctx->ok_host[63]); return WCT_OK; }
+  // the optimistic pass ran its decoders on unconverged matrix functions: whatever it clamped says nothing about the real result --
+  // put the saturation counter back to where the last verified call left it before repeating the call
+  HIPCHK(ctx, hipStreamSynchronize(ctx->side.stream));
+  HIPCHK(ctx, hipMemcpy(ctx->sat_dev, &ctx->sat_mark, sizeof(unsigned), hipMemcpyHostToDevice));
+  if (ctx->sat_host) *ctx->sat_host = ctx->sat_mark;
   return body();     // defer_big is off: every solve checks (and repairs) itself
 }
 
@@ -939,6 +946,7 @@ int wct_sync(wct_ctx* ctx) {
     // reported ONCE and cleared: a later WCT_ERR_RANGE then means a later clamp, not a stale flag (the total stays readable
     // through wct_saturation_count until this point only)
     HIPCHK(ctx, hipMemset(ctx->sat_dev, 0, sizeof n));
+    ctx->sat_mark = 0;
     if (ctx->sat_host) *ctx->sat_host = 0u;
     return fail(ctx, WCT_ERR_RANGE, "%u thread(s) clamped an activation to the f16x3 range (|x| > 65504, or NaN) since the last report: results "
                 "deviate from the fp32 reference; use conv mode 0 (exact fp32) for these weights / inputs.  The flag is now cleared", n);
@@ -954,6 +962,7 @@ int wct_saturation_count(wct_ctx* ctx, int reset, unsigned long long* count) {
   unsigned n = 0;
   HIPCHK(ctx, hipMemcpy(&n, ctx->sat_dev, sizeof n, hipMemcpyDeviceToHost));
   if (reset && n) HIPCHK(ctx, hipMemset(ctx->sat_dev, 0, sizeof n));
+  if (reset) ctx->sat_mark = 0;
   if (ctx->sat_host) *ctx->sat_host = reset ? 0u : n;
   if (count) *count = n;
   return WCT_OK;
