@@ -6,7 +6,9 @@ import types
 
 import pytest
 
-from tests.conftest import REPO
+import numpy as np
+
+from tests.conftest import PKG, REPO
 
 
 def _build():
@@ -101,3 +103,23 @@ def test_debug_environment_is_gated():
         src += open(os.path.join(REPO, "collaborative-distillation_amd", "csrc", f)).read()
     raw = [m for m in re.findall(r'[^_a-z]getenv\("(WCT_[A-Z_0-9]+)"\)', src) if m not in ("WCT_DEBUG", "WCT_PROF_SHAPES")]
     assert raw == [], raw
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/trained_models/wct_se_16x_new"), reason="the reference checkout exists in the build container only")
+def test_weights_only_loader_reads_the_reference_checkpoints():
+    """wct_hip.wct._load_state un-pickles with weights_only=True (no arbitrary code from a checkpoint).  The reference's real files
+    -- {"epoch", "model": state_dict} for the encoders (with the unused conv{k}1_aux heads), bare or wrapped state_dicts for the
+    decoders (model_cd.py:712-718) -- must load that way, without WCT_ALLOW_UNSAFE_PICKLE, and equal the packaged blob that
+    tools/make_goldens.py converted from them."""
+    from wct_hip import model_zoo
+    from wct_hip.wct import _load_state
+    blob = model_zoo.load_npz_weights(os.path.join(PKG, "weights", "16x.npz"))
+    assert os.environ.get("WCT_ALLOW_UNSAFE_PICKLE") != "1"
+    for k in range(1, 6):
+        for key, path in (("e%d" % k, "/root/reference/trained_models/wct_se_16x_new/%dSE.pth" % k),
+                          ("d%d" % k, "/root/reference/trained_models/wct_se_16x_new_sd/%dSD.pth" % k)):
+            sd = _load_state(path)
+            mine = {n[len(key) + 1:]: v for n, v in blob.items() if n.startswith(key + ".")}
+            assert set(mine) <= set(sd) and all("aux" in n for n in set(sd) - set(mine)), key
+            for n, v in mine.items():
+                assert v.shape == sd[n].shape and np.array_equal(v, sd[n]), (key, n)
