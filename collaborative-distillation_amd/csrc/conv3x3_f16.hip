@@ -566,6 +566,230 @@ __global__ __launch_bounds__(32 * TH, HeadGeo<TH>::PER_CU) void enc_head_kernel(
 #endif
 }
 
+// ---- the fused head with TWO ROLES per workgroup (round 3).
+// enc_head_kernel above fits an ADDITIVE model: per SIMD and tile trip ~3 k cycles of VALU issue + ~4 k cycles of matrix pipe, and
+// ~82 % of their SUM is what a trip takes.  A probe (tools/experiments/valu_mfma_overlap.hip) shows that VALU work and MFMA work
+// overlap almost perfectly when they come from DIFFERENT waves of a SIMD (388 ns against 247 / 353 ns alone), while waves that
+// each alternate a VALU-heavy and an MFMA-heavy section fall into lockstep and get ~10 % (579 against 260 + 386) -- and there two
+// barriers per tile put all twelve waves into the same section by construction.  Here the sections are roles:
+//   producer waves 0..NWA-1        image window -> conv11 (4 MFMAs per 16 halo pixels) -> scale, bias, ReLU, split (VALU) -> act[t + 1]
+//   consumer waves NWA..NWA+TH/2-1 act[t] -> conv12 (60 MFMAs per wave) -> pool, bias, ReLU (+ split) -> global
+// on tiles t + 1 and t at the same time: the conv11 intermediate and the split image window are double-buffered in LDS and ONE
+// barrier per tile hands a finished intermediate to the consumers and a committed window to the producers.  CFETCH: the consumers
+// (matrix-bound, idle VALU) fetch and split the image window instead of the producers.  The arithmetic per pixel is that of
+// enc_head_kernel (same device functions): bit-identical results.
+// (Also measured: all twelve waves of a 32 x 24 tile doing both sections, double-buffered, one barrier, waves 4-7 taking the
+// sections in the opposite order -- every wave's work as in enc_head_kernel<24>: 5 % SLOWER than enc_head_kernel<24>.)
+template <int TH, int NWA_>
+struct HeadRolesGeo {
+  static constexpr int NWA = NWA_, NWB = TH / 2, NT = 64 * (NWA + NWB), NTA = 64 * NWA, NTB = 64 * NWB;
+  static constexpr int NPH = nph(TH), NPP = npp(TH), NGRP = (NPH + 15) / 16, NG = (NGRP + NWA - 1) / NWA;
+  static constexpr int NPI = I2W * (TH + 4), IMGE = NPI + 4;
+  static constexpr size_t lds = (size_t)2 * 2 * IMGE * 8 + (size_t)2 * 4 * NPP * 16 + 640 * 16;             // 113.4 KB at TH = 16
+};
+
+template <int TH, int NWA, bool CFETCH>
+__global__ __launch_bounds__(64 * (NWA + TH / 2), 1) void enc_head_roles_kernel(HeadArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  using G = HeadRolesGeo<TH, NWA>;
+  constexpr int NT = G::NT, NTA = G::NTA, NTB = G::NTB, NPP = G::NPP, NPH = G::NPH, NG = G::NG, NPI = G::NPI, IMGE = G::IMGE;
+  constexpr int NTF = CFETCH ? NTB : NTA, SL = (NPI + NTF - 1) / NTF;     // threads that stage the image window, pixels per thread
+  u32x2* img0 = reinterpret_cast<u32x2*>(smem);                // [2 buffers][hi | lo][IMGE]
+  u32x4* act0 = reinterpret_cast<u32x4*>(img0 + 4 * IMGE);    // [2 buffers][4][NPP]
+  u32x4* wgt = act0 + 2 * 4 * NPP;                             // [10][2][2][16]
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, kq = lane >> 4;
+  const int ntiles = a.tiles_x * a.tiles_y;
+  for (int e = tid; e < 40 * 16; e += NT) wgt[e] = a.w12[e];
+  if (tid < 16) { const int b = tid >> 3, pl = (tid >> 2) & 1, k = tid & 3; img0[(b * 2 + pl) * IMGE + NPI + k] = u32x2{0u, 0u}; }
+  const int Hp = a.H >> 1, Wp = a.W >> 1;
+  SatTrack sat;
+  int v = blockIdx.x;
+  const int grid = gridDim.x;
+  const bool producer = wave < NWA;
+  // image-window staging (by the producers, or by the consumers with CFETCH)
+  const int ftid = CFETCH ? tid - NTA : tid;
+  int soff[SL];
+#pragma unroll
+  for (int k = 0; k < SL; ++k) {
+    int e = ftid + NTF * k;
+    e = (e >= 0 && e < NPI) ? e : NPI - 1;
+    soff[k] = (e / I2W) * a.W + e % I2W;
+  }
+  float pxr[SL][3];
+  auto origin = [&](int tile, int& ty0, int& tx0) {
+    int tr, tc;
+    tile_rc(xcd_swizzle(tile, ntiles), a.tiles_x, a.tx_magic, tr, tc);
+    ty0 = tr * TH; tx0 = tc * FTW;
+  };
+  auto fetch = [&](int tile) {
+    int ty0, tx0;
+    origin(tile, ty0, tx0);
+    const size_t plane = (size_t)a.H * a.W;
+    if (tile_interior_h(ty0, tx0, a.H, a.W, TH)) {
+      const float* base = a.img + (size_t)(ty0 - 2) * a.W + (tx0 - 2);
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int k = 0; k < SL; ++k) pxr[k][c] = (base + c * plane)[(unsigned)soff[k]];
+    } else {
+#pragma unroll
+      for (int k = 0; k < SL; ++k) {
+        int e = ftid + NTF * k;
+        e = e < NPI ? e : NPI - 1;
+        const int py = e / I2W, px = e - py * I2W;
+        const size_t off = (size_t)reflect_clamp(ty0 - 2 + py, a.H) * a.W + reflect_clamp(tx0 - 2 + px, a.W);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) pxr[k][c] = a.img[c * plane + off];
+      }
+    }
+  };
+  auto commit = [&](u32x2* imgH) {     // imgL = imgH + IMGE
+#pragma unroll
+    for (int k = 0; k < SL; ++k)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) asm volatile("" : "+v"(pxr[k][c]));      // head_pin: the conversions stay behind this trip's MFMAs
+#pragma unroll
+    for (int k = 0; k < SL; ++k) {
+      const int e = ftid + NTF * k;
+      if (e < NPI) {
+        u32x2 h, l;
+        { const HiLo t_ = split2(clamp_pm(pxr[k][0]), clamp_pm(pxr[k][1])); h[0] = t_.hi; l[0] = t_.lo; }
+        { const HiLo t_ = split2(clamp_pm(pxr[k][2]), 0.f); h[1] = t_.hi; l[1] = t_.lo; }
+        sat.note_hi(h[0], h[1], false);
+        imgH[e] = h;
+        imgH[IMGE + e] = l;
+      }
+    }
+  };
+  const bool stager = CFETCH ? !producer : producer;
+  int vn = v + grid;
+
+  if (producer) {
+    f16x8 a11[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) a11[s] = __builtin_bit_cast(f16x8, a.w11[(s * 4 + kq) * 16 + li]);
+    const f32x4 bias11 = *reinterpret_cast<const f32x4*>(a.b11 + 4 * kq);
+    int boff[4][2];
+    l1_lane_offsets(kq, IMGE, boff);
+    // the wave's NG 16-pixel groups of the 34 x (TH + 2) halo: store slot, and the window base of an interior tile
+    int gpix[NG], gbase[NG];
+#pragma unroll
+    for (int u = 0; u < NG; ++u) {
+      const int pixr = (wave + NWA * u) * 16 + li;
+      const bool ok = pixr < NPH;
+      const int pc = ok ? pixr : NPH - 1;
+      const int py = pc / FHW, px = pc - py * FHW;
+      gbase[u] = py * I2W + px;
+      gpix[u] = ok ? pixr : NPP - 1;      // a lane without a pixel stores to a slot nobody reads: no exec masking around the stores
+    }
+    static_assert(NPP > NPH, "a spare slot behind the halo");
+    auto conv11 = [&](int tile, const u32x2* imgH, u32x4* act) {
+      int ty0, tx0;
+      origin(tile, ty0, tx0);
+      const bool interior = tile_interior_h(ty0, tx0, a.H, a.W, TH);
+#pragma unroll
+      for (int i = 0; i < NG; i += 3) {
+        f32x4 acc[3];
+        f16x8 bs[3][4];
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+          if (i + u >= NG) continue;
+          int base = gbase[i + u];
+          if (!interior) {
+            const int gpy = base / I2W, gpx = base - gpy * I2W;
+            const int iy = reflect_clamp(ty0 - 1 + gpy, a.H) - (ty0 - 2), ix = reflect_clamp(tx0 - 1 + gpx, a.W) - (tx0 - 2);
+            base = (iy - 1) * I2W + ix - 1;
+          }
+          acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+          const char* bp = reinterpret_cast<const char*>(imgH) + base * 8;
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            const u32x2 r0 = *reinterpret_cast<const u32x2*>(bp + boff[s][0]), r1 = *reinterpret_cast<const u32x2*>(bp + boff[s][1]);
+            bs[u][s] = __builtin_bit_cast(f16x8, u32x4{r0[0], r0[1], r1[0], r1[1]});
+          }
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int u = 0; u < 3; ++u)
+            if (i + u < NG) acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a11[s], bs[u][s], acc[u], 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+          if (i + u >= NG) continue;
+          store_split4<true>(act, NPP, gpix[i + u], kq, fma4(acc[u], a.inv11, bias11), sat);
+        }
+      }
+    };
+    // prologue: window of the first tile, its intermediate, window of the second tile
+    if (stager && v < ntiles) { fetch(v); commit(img0); }
+    __syncthreads();
+    if (v < ntiles) conv11(v, img0, act0);
+    if (stager && vn < ntiles) { fetch(vn); commit(img0 + 2 * IMGE); }
+    settle_preloop_loads();
+    __syncthreads();
+    for (int it = 0; v < ntiles; v = vn, vn += grid, ++it) {
+      // act[it & 1] holds tile v (the consumers are on it), img[(it + 1) & 1] holds the window of tile vn
+      const int vnn = vn + grid, cur = it & 1, nxt = cur ^ 1;
+      if (stager && vnn < ntiles) fetch(vnn);
+      if (vn < ntiles) conv11(vn, img0 + nxt * 2 * IMGE, act0 + nxt * 4 * NPP);
+      if (stager && vnn < ntiles) commit(img0 + cur * 2 * IMGE);
+      __syncthreads();
+    }
+  } else {
+    const int bw = wave - NWA;
+    const f32x4 bias12 = *reinterpret_cast<const f32x4*>(a.b12 + 4 * kq);
+    const int out_lane = a.out_sp ? (li >> 1) * 64 + (kq >> 1) * 32 + (kq & 1) * 8 : ((li >> 1) * 16 + 4 * kq) * 4;
+    if (stager && v < ntiles) { fetch(v); commit(img0); }
+    __syncthreads();
+    if (stager && vn < ntiles) { fetch(vn); commit(img0 + 2 * IMGE); }
+    settle_preloop_loads();
+    __syncthreads();
+    for (int it = 0; v < ntiles; v = vn, vn += grid, ++it) {
+      const int vnn = vn + grid, cur = it & 1;
+      if (stager && vnn < ntiles) fetch(vnn);
+      int ty0, tx0;
+      origin(v, ty0, tx0);
+      const u32x4* act = act0 + cur * 4 * NPP;
+      f32x4 acc[2][2];
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) acc[r][h] = f32x4{0.f, 0.f, 0.f, 0.f};
+      c16_compute<NPP>(act, wgt, bw, li, kq, acc);
+      const int oy = (ty0 >> 1) + bw;                                   // uniform
+      char* orow = reinterpret_cast<char*>(a.out) + ((size_t)oy * Wp + (tx0 >> 1)) * 64;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        f32x4 m;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float x = fmaxf(acc[0][h][r], acc[1][h][r]);
+          m[r] = fmaxf(x, lane_xor1(x));
+        }
+        m = fma4(m, a.inv12, bias12);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) m[r] = fmaxf(m[r], 0.f);
+        const int ox = (tx0 >> 1) + h * 8 + (li >> 1);
+        if (!(li & 1) && oy < Hp && ox < Wp) {
+          char* dst = orow + h * 8 * 64 + out_lane;
+          if (a.out_sp) {
+            u32x2 hi, lo;
+            split4(m, hi, lo, sat, true);
+            *reinterpret_cast<u32x2*>(dst) = hi;
+            *reinterpret_cast<u32x2*>(dst + 16) = lo;
+          } else {
+            *reinterpret_cast<f32x4*>(dst) = m;
+          }
+        }
+      }
+      if (stager && vnn < ntiles) commit(img0 + cur * 2 * IMGE);
+      __syncthreads();
+    }
+  }
+  sat.commit(a.sat);
+}
+
 struct TailArgs {   // conv12 (16->16 on the nearest-x2 upsampled input) + ReLU -> conv11 (16->3) + ReLU -> planar image
   const float* in; float* out;
   const u32x4* w12; const float* b12; float inv12; const float* inv12_ptr;
@@ -1037,6 +1261,24 @@ hipError_t launch_enc_head(const ConvDesc& d0, const ConvDesc& d1, const float* 
   // 32 x 24 tiles (12 waves, one workgroup per CU: the same three waves per SIMD, conv11's halo recompute 1.15 instead of 1.33:
   // -2.6 %) once they still give every CU four tiles; results do not depend on the tile shape
   const int th = th_env ? th_env : (((H + 23) / 24) * a.tiles_x >= 4 * num_cus() ? 24 : 8);
+  // two roles per workgroup (producer waves: conv11, consumer waves: conv12 + pool; 32 x 16 tiles).  WCT_HEAD_ROLES: 0 = off,
+  // 1 = 4 producers staging the window themselves, 2 = 4 producers, consumers stage, 3 / 4 = the same with 8 producers (16 waves)
+  static const int roles_env = [] { const char* e = wct_debug_env("WCT_HEAD_ROLES"); return e ? atoi(e) : 1; }();
+  if (roles_env && !th_env && ((H + 15) / 16) * a.tiles_x >= 4 * num_cus()) {
+    a.tiles_y = (H + 15) / 16;
+    const int ntiles = a.tiles_x * a.tiles_y, grid = ntiles < num_cus() ? ntiles : num_cus();
+    auto gor = [&](auto kern, auto geo) -> hipError_t {
+      using G = decltype(geo);
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::lds);
+      if (e != hipSuccess) return e;
+      hipLaunchKernelGGL(kern, dim3(grid), dim3(G::NT), G::lds, s, a);
+      return hipGetLastError();
+    };
+    if (roles_env == 2) return gor(enc_head_roles_kernel<16, 4, true>, HeadRolesGeo<16, 4>{});
+    if (roles_env == 3) return gor(enc_head_roles_kernel<16, 8, false>, HeadRolesGeo<16, 8>{});
+    if (roles_env == 4) return gor(enc_head_roles_kernel<16, 8, true>, HeadRolesGeo<16, 8>{});
+    return gor(enc_head_roles_kernel<16, 4, false>, HeadRolesGeo<16, 4>{});
+  }
   if (th == 24) return go(enc_head_kernel<24>, HeadGeo<24>{}, 24);
   return go(enc_head_kernel<8>, HeadGeo<8>{}, 8);
 }

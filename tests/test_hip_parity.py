@@ -229,6 +229,37 @@ def test_fused_ends_match_unfused(torch_cuda, weights16x):
         assert a.shape == b.shape and float((a - b).abs().max() / b.abs().max()) < 3e-6
 
 
+def test_head_with_two_roles_is_bitwise_the_single_role_head(torch_cuda, tmp_path):
+    """Large images take the fused head in its two-role form (conv3x3_f16.hip enc_head_roles_kernel: producer waves run conv11 of
+    tile t + 1 while consumer waves run conv12 + pool of tile t, double-buffered through LDS); WCT_HEAD_ROLES=0 (under WCT_DEBUG)
+    selects enc_head_kernel<24>.  Same device functions per pixel -> the encoders' outputs must agree BIT FOR BIT: sizes with
+    ragged right / bottom tiles and image-border (reflecting) tiles, SP16 and fp32 outputs behind the head (levels 5 and 2)."""
+    import hashlib
+    import os
+    import subprocess
+    import sys
+    from tests.conftest import PKG, REPO
+    code = (
+        "import sys, types, hashlib, torch\n"
+        "sys.path[:0] = [%r, %r]\n"
+        "from wct_hip import WCT, model_zoo\n"
+        "import os\n"
+        "wct = WCT(types.SimpleNamespace(mode='16x', alpha=1.0), weights=model_zoo.load_npz_weights(os.path.join(%r, 'weights', '16x.npz')))\n"
+        "g = torch.Generator(device='cuda').manual_seed(3)\n"
+        "for (H, W) in ((1100, 1950), (1030, 4100), (2160, 3840)):\n"
+        "    c = torch.rand((1, 3, H, W), device='cuda', generator=g)\n"
+        "    for L in (5, 2):\n"
+        "        y = wct.encode(L, c)\n"
+        "        assert bool(torch.isfinite(y).all())\n"
+        "        print(H, W, L, hashlib.sha256(y.cpu().numpy().tobytes()).hexdigest())\n" % (REPO, PKG, PKG))
+    outs = []
+    for env in ({}, {"WCT_DEBUG": "1", "WCT_HEAD_ROLES": "0"}):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        outs.append([ln for ln in r.stdout.splitlines() if ln and ln[0].isdigit()])
+    assert len(outs[0]) == 6 and outs[0] == outs[1]
+
+
 def test_sp16_dma_path_bitwise_equals_fp32_activations(torch_cuda, weights16x):
     """SP16 intermediates + DMA-staged kernels (default) vs fp32 NHWC intermediates + register-staged kernels
     (debug_set("sp", 0)): the split hi/lo values and every accumulation order are the same, so whole encoders / decoders agree bit
