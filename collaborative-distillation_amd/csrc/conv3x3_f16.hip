@@ -588,7 +588,7 @@ struct HeadRolesGeo {
   static constexpr size_t lds = (size_t)2 * 2 * IMGE * 8 + (size_t)2 * 4 * NPP * 16 + 640 * 16;             // 113.4 KB at TH = 16
 };
 
-template <int TH, int NWA, bool CFETCH>
+template <int TH, int NWA, bool CFETCH, bool WREG = true>
 __global__ __launch_bounds__(64 * (NWA + TH / 2), 1) void enc_head_roles_kernel(HeadArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using G = HeadRolesGeo<TH, NWA>;
@@ -740,6 +740,8 @@ __global__ __launch_bounds__(64 * (NWA + TH / 2), 1) void enc_head_roles_kernel(
     const int bw = wave - NWA;
     const f32x4 bias12 = *reinterpret_cast<const f32x4*>(a.b12 + 4 * kq);
     const int out_lane = a.out_sp ? (li >> 1) * 64 + (kq >> 1) * 32 + (kq & 1) * 8 : ((li >> 1) * 16 + 4 * kq) * 4;
+    C16Weights cw;       // WREG: conv12's weight operands stay in registers (the consumers have them to spare)
+    if constexpr (WREG) c16_load_weights(a.w12, li, kq, cw);
     if (stager && v < ntiles) { fetch(v); commit(img0); }
     __syncthreads();
     if (stager && vn < ntiles) { fetch(vn); commit(img0 + 2 * IMGE); }
@@ -756,7 +758,8 @@ __global__ __launch_bounds__(64 * (NWA + TH / 2), 1) void enc_head_roles_kernel(
       for (int r = 0; r < 2; ++r)
 #pragma unroll
         for (int h = 0; h < 2; ++h) acc[r][h] = f32x4{0.f, 0.f, 0.f, 0.f};
-      c16_compute<NPP>(act, wgt, bw, li, kq, acc);
+      if constexpr (WREG) c16_compute_w<NPP>(act, cw, bw, li, kq, acc);
+      else c16_compute<NPP>(act, wgt, bw, li, kq, acc);
       const int oy = (ty0 >> 1) + bw;                                   // uniform
       char* orow = reinterpret_cast<char*>(a.out) + ((size_t)oy * Wp + (tx0 >> 1)) * 64;
 #pragma unroll
@@ -1274,6 +1277,7 @@ hipError_t launch_enc_head(const ConvDesc& d0, const ConvDesc& d1, const float* 
       hipLaunchKernelGGL(kern, dim3(grid), dim3(G::NT), G::lds, s, a);
       return hipGetLastError();
     };
+    if (roles_env == 5) return gor(enc_head_roles_kernel<16, 4, false, false>, HeadRolesGeo<16, 4>{});     // weights from LDS (the first form)
     if (roles_env == 2) return gor(enc_head_roles_kernel<16, 4, true>, HeadRolesGeo<16, 4>{});
     if (roles_env == 3) return gor(enc_head_roles_kernel<16, 8, false>, HeadRolesGeo<16, 8>{});
     if (roles_env == 4) return gor(enc_head_roles_kernel<16, 8, true>, HeadRolesGeo<16, 8>{});

@@ -319,6 +319,46 @@ __device__ __forceinline__ void c16_compute(const u32x4* act, const u32x4* wgt, 
   }
 }
 
+// the same with the wave's ten weight operands resident in registers (40 VGPRs): 40 instead of 50 LDS reads per 60 MFMAs -- for
+// kernels whose conv12 waves have the registers to spare (the consumer role of enc_head_roles_kernel).  Same MFMA order:
+// bit-identical to c16_compute.
+struct C16Weights { f16x8 ah[5], al[5]; };
+__device__ __forceinline__ void c16_load_weights(const u32x4* w /* global or LDS, [10][2][2][16] */, int li, int kq, C16Weights& cw) {
+  const int kh = kq & 1, ts = kq >> 1;
+#pragma unroll
+  for (int s = 0; s < 5; ++s) {
+    const int tap = 2 * s + ts;
+    cw.ah[s] = __builtin_bit_cast(f16x8, w[((tap * 2 + 0) * 2 + kh) * 16 + li]);
+    cw.al[s] = __builtin_bit_cast(f16x8, w[((tap * 2 + 1) * 2 + kh) * 16 + li]);
+  }
+}
+template <int NPP = npp(8)>
+__device__ __forceinline__ void c16_compute_w(const u32x4* act, const C16Weights& cw, int wave, int li, int kq, f32x4 (&acc)[2][2]) {
+  const int kh = kq & 1, ts = kq >> 1;
+#pragma unroll
+  for (int s = 0; s < 5; ++s) {
+    const int tap = 2 * s + ts;
+    const int tc = tap > 8 ? 8 : tap;
+    const int dy = tc / 3, dx = tc - dy * 3;
+    f16x8 bh[2][2], bl[2][2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int pix = (wave * 2 + r + dy) * FHW + h * 16 + li + dx;
+        bh[r][h] = __builtin_bit_cast(f16x8, act[(0 * 2 + kh) * NPP + pix]);
+        bl[r][h] = __builtin_bit_cast(f16x8, act[(1 * 2 + kh) * NPP + pix]);
+      }
+#pragma unroll
+    for (int term = 0; term < 3; ++term)
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+          acc[r][h] = __builtin_amdgcn_mfma_f32_16x16x32_f16(term == 2 ? cw.al[s] : cw.ah[s], term == 1 ? bl[r][h] : bh[r][h], acc[r][h], 0, 0, 0);
+  }
+}
+
 // ---- "block-packed" 16 -> 3 convolution: the LAST decoder conv inside the fused tails (dec_tail kernels, l1_decode_kernel).
 // With 3 real couts the 16-row M dimension of a 16x16x32 MFMA is 81 % padding.  Here one N column is a 2 x 2 BLOCK of output
 // pixels and M = 4 * phase + cout (phase = 2 py + px: which pixel of the block; 12 of 16 rows carry results).  K walks the 4 x 4
