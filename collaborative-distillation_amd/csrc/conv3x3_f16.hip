@@ -666,6 +666,9 @@ __global__ __launch_bounds__(64 * (NWA + TH / 2), 1) void enc_head_roles_kernel(
   int vn = v + grid;
 
   if (producer) {
+#ifdef WCT_HEAD_PRIO
+    __builtin_amdgcn_s_setprio(WCT_HEAD_PRIO);     // experiment: the producer wave of a SIMD wins issue arbitration
+#endif
     f16x8 a11[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) a11[s] = __builtin_bit_cast(f16x8, a.w11[(s * 4 + kq) * 16 + li]);
