@@ -95,7 +95,7 @@ struct wct_ctx {
   // --mode original (C > 128): outcomes of the deflated iterations of ONE API call, checked once at the call's end instead of one
   // stream synchronisation per solve (launch_eig ok_defer)
   int* ok_log = nullptr;         // device [64]
-  int* ok_host = nullptr;        // pinned [64]
+  int* ok_host = nullptr;        // pinned [64]: outcomes [0, OK_SLOTS), the saturation counter read with them at [OK_SLOTS]
   int ok_n = 0;
   bool defer_big = false;
   unsigned sat_mark = 0;         // the saturation counter at the end of the last VERIFIED wide-model call (see with_deferred_solves)
@@ -175,6 +175,8 @@ int pad_cout(int c) {
 }
 
 bool valid_level(int l) { return l >= 1 && l <= 5; }
+
+constexpr int OK_SLOTS = 63;   // deferred solve outcomes per API call (a cascade has at most 4 C > 128 levels x 2 sides x num_run); see with_deferred_solves
 
 // ---- profiling wrapper -----------------------------------------------------------------------------
 struct ProfScope {
@@ -612,7 +614,7 @@ int eig_impl(wct_ctx* ctx, Lane& ln, int C, double n, const double* sum, const d
   if (int rc = ensure(ctx, ln.wsEig, eig_workspace_bytes(C))) return rc;
   ProfScope ps(ctx, ln.stream, inverse ? "matfun_invsqrt" : "matfun_sqrt", 0, 0);
   int* defer = nullptr;
-  if (ctx->defer_big && eig_is_big(C, ctx->wide_model) && ctx->ok_n < 64) defer = ctx->ok_log + ctx->ok_n++;
+  if (ctx->defer_big && eig_is_big(C, ctx->wide_model) && ctx->ok_n < OK_SLOTS) defer = ctx->ok_log + ctx->ok_n++;
   HIPCHK(ctx, launch_eig(C, n, sum, sumsq, inverse, reinterpret_cast<double*>(res.p), info_dev, ln.wsEig.p, ln.wsEig.cap, ln.stream,
                          (inverse && ctx->numpy_variant) ? 1.0 : 0.0, ctx->wide_model, defer));
   return WCT_OK;
@@ -635,11 +637,11 @@ int with_deferred_solves(wct_ctx* ctx, bool wait_side, BODY&& body) {
   if (n == 0) return WCT_OK;
   if (wait_side) HIPCHK(ctx, hipStreamSynchronize(ctx->side.stream));
   HIPCHK(ctx, hipMemcpyAsync(ctx->ok_host, ctx->ok_log, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, ctx->main.stream));
-  HIPCHK(ctx, hipMemcpyAsync(ctx->ok_host + 63, ctx->sat_dev, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->main.stream));
+  HIPCHK(ctx, hipMemcpyAsync(ctx->ok_host + OK_SLOTS, ctx->sat_dev, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->main.stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->main.stream));
   bool all = true;
   for (int i = 0; i < n; ++i) all = all && ctx->ok_host[i] == 1;
-  if (all) { ctx->sat_mark = static_cast<unsigned>(ctx->ok_host[63]); return WCT_OK; }
+  if (all) { ctx->sat_mark = static_cast<unsigned>(ctx->ok_host[OK_SLOTS]); return WCT_OK; }
   // the optimistic pass ran its decoders on unconverged matrix functions: whatever it clamped says nothing about the real result --
   // put the saturation counter back to where the last verified call left it before repeating the call
   HIPCHK(ctx, hipStreamSynchronize(ctx->side.stream));
@@ -703,14 +705,13 @@ bool fast_fold_level(const wct_ctx* ctx, int level) {
   return ctx->fastfold && m.loaded && m.layers[0].w_oihw && fold_fast_capable(m.layers[0].d.cin);
 }
 
-int style_fold(wct_ctx* ctx, int level, hipStream_t st, const char* lane_tag) {
+int style_fold(wct_ctx* ctx, int level, hipStream_t st) {
   ctx->fold_ready[level] = false;
   if (!fast_fold_level(ctx, level)) return WCT_OK;
   const LayerDev& l = ctx->mod[WCT_KIND_DEC][level].layers[0];
   const size_t C = l.d.cin, cc = C * C;
   if (int rc = ensure(ctx, ctx->foldS[level], fold_style_doubles(l.d.cout, l.d.cin) * sizeof(double))) return rc;
   const double* res = reinterpret_cast<const double*>(ctx->eigS[level].p);
-  (void)lane_tag;
   ProfScope ps(ctx, st, "fold_style", 0, 0);
   HIPCHK(ctx, launch_fold_style(l.w_oihw, l.d.cout, l.d.cin, res + eig_result_F_offset(C), res + cc + C, reinterpret_cast<double*>(ctx->foldS[level].p), st));
   ctx->fold_ready[level] = true;
@@ -807,7 +808,7 @@ int style_side(wct_ctx* ctx, int level, const float* style, int Hs, int Ws) {
     if (int rc = moments_impl(ctx, ln, fS, C, hs, ws, 0, ws, sv.sum, sv.sumsq)) return rc;
   }
   if (int rc = eig_impl(ctx, ln, C, (double)hs * ws, sv.sum, sv.sumsq, 0, ctx->eigS[level], sv.info + 1)) return rc;
-  if (int rc = style_fold(ctx, level, ln.stream, "side")) return rc;      // (W Ss), off the content side's critical path
+  if (int rc = style_fold(ctx, level, ln.stream)) return rc;      // (W Ss), off the content side's critical path
   HIPCHK(ctx, hipEventRecord(ctx->ev_style[level], ln.stream));
   return WCT_OK;
 }
@@ -1317,7 +1318,7 @@ int wct_style_import(wct_ctx* ctx, int level, const double* stats) {
   hipStream_t st = ctx->main.stream;
   HIPCHK(ctx, hipMemcpyAsync(res + eig_result_F_offset(C), stats, cc * sizeof(double), hipMemcpyDeviceToDevice, st));
   HIPCHK(ctx, hipMemcpyAsync(res + cc + C, stats + cc, C * sizeof(double), hipMemcpyDeviceToDevice, st));
-  if (int rc = style_fold(ctx, level, st, "main")) return rc;
+  if (int rc = style_fold(ctx, level, st)) return rc;
   HIPCHK(ctx, hipEventRecord(ctx->ev_style[level], st));   // what content_side / wct_content_solve wait for
   return WCT_OK;
 }
