@@ -308,6 +308,27 @@ def test_bench_two_ranks_on_one_gpu(extra, name):
     assert line["roofline"]["frac"] > 0
 
 
+@pytest.mark.parametrize("cfg,name,total", [("cfg3", "cfg3", "1920x1080"), ("cfg2", "cfg2", "3840x2160")])
+def test_bench_single_gpu_line_contract(cfg, name, total):
+    """bench.py on one GPU, short (--steps-only leaves out the CPU oracle, the parity leg and the extra passes): exactly ONE line on
+    stdout -- whatever RCCL or the runtime print goes to stderr -- with the fields the driver reads, for the default configuration
+    and for --config cfg3 (--mode original, generated weights)."""
+    cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--steps", "2", "--warmup", "1", "--steps-only", "--no-cpu-baseline", "--config", cfg]
+    r = subprocess.run(cmd, cwd=REPO, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout[-2000:]
+    line = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+                "roofline", "cpu_baseline"):
+        assert key in line, key
+    assert line["n_gpus"] == 1 and line["steps"] == 2 and line["unit"] == "MP/s" and line["value"] > 0 and line["vs_baseline"] is None
+    assert line["config"]["name"] == name and line["config"]["content_total"] == total and "workload" in line["config"]
+    roof = line["roofline"]
+    assert roof["bound"] in ("mfma", "hbm") and 0 < roof["frac"] < 1 and roof["achieved"] > 0 and roof["peak"] > 0 and "traffic" in roof
+    assert abs(line["value"] - float(total.split("x")[0]) * float(total.split("x")[1]) / 1e6 / line["ms_per_step"] * 1e3) < 0.02 * line["value"]
+
+
 def test_strip_halos_exact_with_level_margins(tmp_path):
     """halo_mode "exchange" relies on: a strip fed own +- LEVEL_HALO[L] columns reproduces the untiled level BITWISE on its
     owned columns (same (M, b)) -- edge strips, an interior strip, and a width that floor pooling shrinks (2005 -> 2000)."""
