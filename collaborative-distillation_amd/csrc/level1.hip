@@ -88,6 +88,104 @@ __global__ __launch_bounds__(256, 3) void l1_encode_kernel(L1EncArgs a) {
   sat.commit(a.sat);
 }
 
+// ---- the 3 -> 64 first convolution of the un-pruned encoders (--mode original: model_original.py conv1_1 with conv0 folded in), f16x3.
+// It used to run as exact-fp32 MFMA (conv3x3.hip: 9 x 32 issue cycles per 16 pixels and cout tile, 197 us per 1920x1080 launch =
+// 2.7 TB/s of its 256 B/px output); here it is l1_encode_kernel's structure with FOUR cout tiles from one set of operand reads
+// (K = 27 singles concatenated: 4 MFMAs of 16 cycles per 16 pixels and cout tile), fp32 NHWC or SP16 out -- a write stream.
+struct In3WideArgs {
+  const float* img; void* out;               // out: NHWC fp32 [H*W][64], or SP16 (four 16-channel chunk planes)
+  const u32x4* w; const float* b; float inv; // [4 cout tiles][4 K-steps][4 kq][16] x 8 halfs; bias [64]
+  int H, W, tiles_x, tiles_y, out_sp;
+  unsigned* sat;
+};
+
+__global__ __launch_bounds__(256, 2) void in3_wide_kernel(In3WideArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  u32x2* imgH = reinterpret_cast<u32x2*>(smem);
+  u32x2* imgL = imgH + IMG_E;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, kq = lane >> 4;
+  const int ntiles = a.tiles_x * a.tiles_y;
+  const unsigned txm = tile_div_magic(a.tiles_x);
+  if (tid < 4) { imgH[NPI2 + tid] = u32x2{0u, 0u}; imgL[NPI2 + tid] = u32x2{0u, 0u}; }
+  f16x8 wa[4][4];
+  f32x4 bias[4];
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) wa[ct][s] = __builtin_bit_cast(f16x8, a.w[((ct * 4 + s) * 4 + kq) * 16 + li]);
+    bias[ct] = *reinterpret_cast<const f32x4*>(a.b + ct * 16 + 4 * kq);
+  }
+  int boff[4][2];
+  l1_lane_offsets(kq, IMG_E, boff);
+  int soff[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    int e = tid + 256 * k;
+    e = e < NPI2 ? e : NPI2 - 1;
+    soff[k] = (e / I2W) * a.W + e % I2W;
+  }
+  float pxr[2][3];
+  SatTrack sat;
+  const size_t plane = sp16_plane_bytes(a.H, a.W);
+  int v = blockIdx.x;
+  if (v < ntiles) {
+    head_fetch(a.img, a.H, a.W, a.tiles_x, txm, pxr, soff, xcd_swizzle(v, ntiles), tid);
+    head_commit(pxr, imgH, imgL, tid, sat);
+  }
+  settle_preloop_loads();
+  for (; v < ntiles; v += gridDim.x) {
+    const int tile = xcd_swizzle(v, ntiles);
+    int trow_, tcol_;
+    tile_rc(tile, a.tiles_x, txm, trow_, tcol_);
+    const int ty0 = trow_ * 8, tx0 = tcol_ * FTW;
+    __syncthreads();
+    const int vn = v + gridDim.x;
+    if (vn < ntiles) head_fetch(a.img, a.H, a.W, a.tiles_x, txm, pxr, soff, xcd_swizzle(vn, ntiles), tid);
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int py = wave * 2 + r, px = h * 16 + li;
+        const int base = (py + 1) * I2W + px + 1;   // top-left of the 3x3 window in the 36 x 12 tile (origin -2, -2)
+        const int gy = ty0 + py, gx = tx0 + px;
+        f32x4 acc[4];
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const char* bp = reinterpret_cast<const char*>(imgH) + base * 8;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const u32x2 r0 = *reinterpret_cast<const u32x2*>(bp + boff[s][0]), r1 = *reinterpret_cast<const u32x2*>(bp + boff[s][1]);
+          const f16x8 b = __builtin_bit_cast(f16x8, u32x4{r0[0], r0[1], r1[0], r1[1]});
+#pragma unroll
+          for (int ct = 0; ct < 4; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[ct][s], b, acc[ct], 0, 0, 0);
+        }
+        const bool ok = gy < a.H && gx < a.W;
+        const size_t pix = (size_t)gy * a.W + gx;
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+          f32x4 x = fma4(acc[ct], a.inv, bias[ct]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) x[e] = fmaxf(x[e], 0.f);
+          if (a.out_sp) {
+            u32x2 hi, lo;
+            split4(x, hi, lo, sat, true);
+            if (ok) {
+              char* g = reinterpret_cast<char*>(a.out) + ct * plane + pix * 64 + (kq >> 1) * 32 + (kq & 1) * 8;
+              *reinterpret_cast<u32x2*>(g) = hi;
+              *reinterpret_cast<u32x2*>(g + 16) = lo;
+            }
+          } else if (ok) {
+            *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.out) + pix * 64 + ct * 16 + 4 * kq) = x;
+          }
+        }
+      }
+    __syncthreads();
+    if (vn < ntiles) { head_pin(pxr); head_commit(pxr, imgH, imgL, tid, sat); }
+  }
+  sat.commit(a.sat);
+}
+
 // image -> relu1_1 on the 34 x (TH + 2) halo (LDS, split f16) -> folded decoder conv (24 -> 3) + ReLU -> planar image.
 // TH = 8: 4 waves, two workgroups per CU; TH = 16: 8 waves, one workgroup per CU, halo recompute 1.20 instead of 1.33.
 template <int TH>
@@ -197,6 +295,23 @@ hipError_t launch_l1_encode(const ConvDesc& e, const float* img, float* out, int
   const size_t lds = (size_t)2 * IMG_E * 8;
   const int ntiles = a.tiles_x * a.tiles_y, grid = ntiles < 3 * num_cus() ? ntiles : 3 * num_cus();
   hipLaunchKernelGGL(l1_encode_kernel, dim3(grid), dim3(256), lds, s, a);
+  return hipGetLastError();
+}
+
+bool in3_wide_capable(const ConvDesc& enc0) {
+  return (enc0.flags & CONV_IN_NCHW3) && !(enc0.flags & (CONV_POOL_OUT | CONV_NO_RELU)) && enc0.l1w16 && enc0.cout == 64 && enc0.cout_pad == 64;
+}
+
+hipError_t launch_in3_wide(const ConvDesc& e, const float* img, void* out, int H, int W, bool out_sp, hipStream_t s) {
+  if (!in3_wide_capable(e) || H < 2 || W < 2) return hipErrorInvalidValue;
+  In3WideArgs a;
+  a.img = img; a.out = out;
+  a.w = reinterpret_cast<const u32x4*>(e.l1w16); a.b = e.l1bias; a.inv = e.l1inv;
+  a.H = H; a.W = W; a.tiles_x = (W + FTW - 1) / FTW; a.tiles_y = (H + 7) / 8; a.out_sp = out_sp ? 1 : 0;
+  a.sat = e.sat;
+  const size_t lds = (size_t)2 * IMG_E * 8;
+  const int ntiles = a.tiles_x * a.tiles_y, grid = ntiles < 2 * num_cus() ? ntiles : 2 * num_cus();
+  hipLaunchKernelGGL(in3_wide_kernel, dim3(grid), dim3(256), lds, s, a);
   return hipGetLastError();
 }
 

@@ -526,6 +526,15 @@ int encode_impl(wct_ctx* ctx, Lane& ln, int level, const float* img, int H, int 
     const bool out_sp = (conv_runs_f16(ctx, d) || img_in) && wants_sp(i);
     if (cur_sp) d.flags |= CONV_IN_SP16;
     if (out_sp) d.flags |= CONV_OUT_SP16;
+    if (i == 0 && ctx->conv_mode == 1 && ctx->fuse && in3_wide_capable(d)) {
+      // 3 -> 64 first conv of the un-pruned encoders: f16x3 with four cout tiles per operand read instead of exact-fp32 MFMA
+      const double px = (double)h * w;
+      ProfScope ps(ctx, ln.stream, "conv3x3_f16x3<co=64,in3>", 2.0 * 27.0 * 64 * px, 4.0 * (3 + 64) * px);
+      HIPCHK(ctx, launch_in3_wide(d, cur, dst, h, w, out_sp, ln.stream));
+      cur = dst;
+      cur_sp = out_sp;
+      continue;
+    }
     if (int rc = run_conv(ctx, ln, d, cur, dst, h, w)) return rc;
     if (l.pool_after) { h /= 2; w /= 2; }
     cur = dst;
@@ -1062,6 +1071,14 @@ int wct_load_module(wct_ctx* ctx, int kind, int level, int n_layers, const wct_l
       std::vector<float> b32(32, 0.f);
       for (int o = 0; o < ld.d.cout_pad && o < 32; ++o) b32[o] = bias[o];
       if (int rc = upload(ctx, &ld.l1bias, b32)) return rc;
+      ld.d.l1w16 = ld.l1w16; ld.d.l1bias = ld.l1bias;
+    }
+    if (in3 && ld.d.cout_pad == 64 && L.cout == 64) {   // un-pruned encoders: four cout tiles for level1.hip in3_wide_kernel
+      std::vector<_Float16> w16;
+      ld.d.l1inv = pack_head_f16(wpk, ld.d.cout_pad, 4, w16);
+      HIPCHK(ctx, hipMalloc(&ld.l1w16, w16.size() * sizeof(_Float16)));
+      HIPCHK(ctx, hipMemcpy(ld.l1w16, w16.data(), w16.size() * sizeof(_Float16), hipMemcpyHostToDevice));
+      if (int rc = upload(ctx, &ld.l1bias, bias)) return rc;
       ld.d.l1w16 = ld.l1w16; ld.d.l1bias = ld.l1bias;
     }
     if (in3 && ld.d.cout_pad == 16) {
