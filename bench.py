@@ -80,17 +80,67 @@ def source_id():
     return h.hexdigest()[:16]
 
 
-def pmc_traffic(family):
-    """HBM bytes per launch of the kernel behind a profile family, from the committed rocprofv3 PMC passes
-    (profiles/hbm_traffic_latest.json, regenerated by tools/profile_round.sh; counters cannot be read from inside this process).
-    `stale` says whether the kernel sources changed since that profile was taken."""
+def live_pmc(config, timeout=180):
+    """The two PMC passes of MI355X_MICROARCH.md's HBM recipe, taken NOW: counters cannot be read from inside this process, so a
+    bounded copy of this very command (`--steps-only`, 1 warm-up + 2 steps, kernels one at a time) runs twice as a child under
+    `rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `... WRITE_SIZE` (separate passes, nothing else traced) while this process idles,
+    and tools/pmc_summary.py turns the two counter tables into bytes per launch.  -> path of the summary json, or None (no
+    rocprofv3, a failed or overlong pass: the caller then falls back to the committed profile and says so)."""
+    import shutil
+    import subprocess
+    import tempfile
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        return None
+    tmp = tempfile.mkdtemp(prefix="wct_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp", WCT_OVERLAP="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    csvs = []
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, counter)
+            cmd = [rocprof, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "pmc", "--",
+                   sys.executable, os.path.abspath(__file__), "--config", config, "--steps", "2", "--warmup", "1",
+                   "--no-cpu-baseline", "--steps-only"]
+            r = subprocess.run(cmd, cwd="/tmp", env=env, timeout=timeout, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+            found = [os.path.join(d, f) for d, _, fs in os.walk(out) for f in fs if f.endswith("counter_collection.csv")]
+            if r.returncode != 0 or not found:
+                sys.stderr.write("live PMC pass %s failed (rc %d): %s\n" % (counter, r.returncode, r.stderr.decode(errors="replace")[-400:]))
+                return None
+            csvs.append(found[0])
+        sys.path.insert(0, os.path.join(REPO, "tools"))
+        import pmc_summary
+        argv, sys.argv = sys.argv, ["pmc_summary.py", csvs[0], csvs[1], os.path.join(tmp, "hbm_traffic.txt")]
+        try:
+            pmc_summary.main()
+        finally:
+            sys.argv = argv
+        return os.path.join(tmp, "hbm_traffic.json")
+    except Exception as e:   # noqa: BLE001 -- measurement garnish: never take the bench line down with it
+        sys.stderr.write("live PMC collection failed: %r\n" % (e,))
+        return None
+    finally:
+        for c in csvs:       # the raw per-dispatch tables are tens of MB
+            try:
+                os.remove(c)
+            except OSError:
+                pass
+
+
+def pmc_traffic(family, live=None):
+    """HBM bytes per launch of the kernel behind a profile family from rocprofv3 PMC passes: `live` (live_pmc() of this run) or
+    the committed profiles/hbm_traffic_latest.json (tools/profile_round.sh), whose `stale` says whether the kernel sources
+    changed since it was taken."""
     import re
-    path = os.path.join(REPO, "profiles", "hbm_traffic_latest.json")
+    path = live or os.path.join(REPO, "profiles", "hbm_traffic_latest.json")
     if not os.path.exists(path):
         return None
     doc = json.load(open(path))
     ks = doc["kernels"]
     src = {"file": "profiles/hbm_traffic_latest.json", "profiled_source_id": doc.get("source_id"), "source_id": source_id()}
+    if live:
+        src["file"] = "live: rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE around `bench.py --steps-only --steps 2` children of this run"
     src["stale"] = src["profiled_source_id"] != src["source_id"]
     m = re.match(r"conv3x3_f16x3<co=(\d+)(,pool)?(,out3)?(,dma)?>", family)
     if not m:
@@ -186,6 +236,8 @@ def main():
     ap.add_argument("--halo-mode", choices=["auto", "recompute", "exchange"], default="auto")
     ap.add_argument("--debug-set", action="append", default=[], metavar="KEY=VALUE", help="wct_debug_set switches for A/B runs")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle run (the parity gate then has no oracle arm)")
+    ap.add_argument("--no-live-pmc", action="store_true", help="roofline.traffic from the committed profile instead of two rocprofv3 "
+                                                               "--pmc child runs of this command (~1 min)")
     ap.add_argument("--steps-only", action="store_true",
                     help="skip the extra passes and the parity leg: every launch then belongs to a stylise step, so a rocprofv3 "
                          "--stats summary of the run averages the same launch mix as `roofline`")
@@ -333,7 +385,9 @@ def main():
     # ---- roofline leg (rank 0 records; every rank runs the steps: they contain collectives)
     profile, roof, _ = kernel_profile(wct, step, record=(rank == 0))
     if rank == 0:
-        pm = pmc_traffic(roof["kernel"])     # HBM bytes per launch from the committed rocprofv3 PMC passes (a number, or null)
+        # HBM bytes per launch: PMC passes taken now (N = 1 default run), else the committed profile (a number, or null)
+        live = live_pmc(args.config) if (world == 1 and not args.steps_only and not args.no_live_pmc) else None
+        pm = pmc_traffic(roof["kernel"], live) or pmc_traffic(roof["kernel"])
         roof["traffic"], roof["traffic_source"] = (pm[0], pm[1]) if pm else (None, None)
     del step
 

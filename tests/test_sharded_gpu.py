@@ -354,3 +354,17 @@ def test_strip_halos_exact_with_level_margins(tmp_path):
             o = wct.decode_affine(L, f, M, b)
             a, e = own[0], min(Wn, own[1])
             assert torch.equal(o[..., a - lo:e - lo], full[..., a:e]), (L, own)
+
+
+def test_bench_collects_hbm_traffic_live():
+    """roofline.traffic of the default bench run: two rocprofv3 --pmc child runs (FETCH_SIZE, WRITE_SIZE) of the bench command,
+    summarised per launch -- from this build's kernels (source ids equal), and close to the dominant kernel's algorithmic bytes
+    (SP16 activations are read once apart from tile halos, written once)."""
+    sys.path.insert(0, REPO)
+    import bench
+    live = bench.live_pmc("cfg2")
+    assert live and os.path.exists(live), "rocprofv3 PMC passes failed (stderr has the reason)"
+    traffic, src = bench.pmc_traffic("conv3x3_f16x3<co=64,dma>", live)
+    assert src["stale"] is False and src["file"].startswith("live")
+    # 19 launches per step: 64 -> 64 at 960x540 / 1024x1024 and 128 -> 64, 64 -> 64 behind an upsample ...: 100 .. 400 MB each
+    assert 5e7 < traffic < 6e8, traffic
