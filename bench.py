@@ -502,6 +502,10 @@ def main():
         ms3 = ev_ms(step3, n=5, warm=2)
         sat3 = eng3.saturation_count()
         rows3, roof3, ksum3 = kernel_profile(eng3, step3)
+        if args.config != "cfg3" and not args.no_live_pmc:   # (as the timed configuration it already has its counters above)
+            live3 = live_pmc("cfg3")
+            pm3 = pmc_traffic(roof3["kernel"], live3) if live3 else None
+            roof3["traffic"], roof3["traffic_source"] = (pm3[0], pm3[1]) if pm3 else (None, None)
         got3 = step3().cpu().numpy()[0]
         p3 = {"weights": "GENERATED (model_zoo.synth_weights('original', 3)); the torch7 checkpoints are absent: real-weight parity unpinned",
               "f16x3_saturated_threads": int(sat3)}
