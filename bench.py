@@ -280,7 +280,10 @@ def main():
         wct16.debug_set(kv.split("=")[0], float(kv.split("=")[1]))
 
     def original_engine():
-        return WCT(types.SimpleNamespace(mode="original", alpha=1.0), weights=model_zoo.synth_weights("original", 3))
+        eng = WCT(types.SimpleNamespace(mode="original", alpha=1.0), weights=model_zoo.synth_weights("original", 3))
+        for kv in args.debug_set:
+            eng.debug_set(kv.split("=")[0], float(kv.split("=")[1]))
+        return eng
 
     wct = original_engine() if args.config == "cfg3" else wct16
     cu = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).cuda()   # noqa: E731

@@ -484,6 +484,7 @@ inline int num_cus() {
   static int n = [] {
     int dev = 0, v = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v < 1) v = 256;
+    if (const char* e = getenv("WCT_CU_RESERVE")) { const int r = atoi(e); if (r > 0 && r < v - 8) v -= r; }
     return v;
   }();
   return n;

@@ -34,6 +34,7 @@
 namespace {
 
 typedef double f64x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int MAX_SWEEPS = 40;
 constexpr double ROT_TOL = 1e-12;  // relative off-diagonal; quadratic convergence overshoots this by far
@@ -83,13 +84,16 @@ __device__ __forceinline__ void cov_floor(int C, double n, const double* sumsq, 
   for (int o = 32; o > 0; o >>= 1) ex2 = fmax(ex2, __shfl_xor(ex2, o));
   if (lane == 0) res[(size_t)C * C + 2 * C] = ABS_FLOOR * ex2 / n;
 }
-__device__ __forceinline__ void cov_element(long e, int C, double n, const double* sum, const double* sumsq, double* res, double diag_add) {
-  const int r = (int)(e / C), c = (int)(e % C);
+__device__ __forceinline__ double cov_value(int r, int c, int C, double n, const double* sum, const double* sumsq, double diag_add) {
   const double mr = sum[r] / n, mc = sum[c] / n;
   // symmetric by construction: use the (min,max) entry for both halves
   const int lo = r < c ? r : c, hi = r < c ? c : r;
-  res[e] = (sumsq[(size_t)lo * C + hi] - n * mr * mc) / (n - 1.0) + (r == c ? diag_add : 0.0);   // diag_add: `--numpy` (+ I)
-  if (c == 0) res[(size_t)C * C + C + r] = mr;  // mu
+  return (sumsq[(size_t)lo * C + hi] - n * mr * mc) / (n - 1.0) + (r == c ? diag_add : 0.0);   // diag_add: `--numpy` (+ I)
+}
+__device__ __forceinline__ void cov_element(long e, int C, double n, const double* sum, const double* sumsq, double* res, double diag_add) {
+  const int r = (int)(e / C), c = (int)(e % C);
+  res[e] = cov_value(r, c, C, n, sum, sumsq, diag_add);
+  if (c == 0) res[(size_t)C * C + C + r] = sum[r] / n;  // mu
 }
 
 __global__ void cov_kernel(int C, double n, const double* sum, const double* sumsq, double* res, double diag_add) {
@@ -136,6 +140,8 @@ struct NsWs {           // carved from the eig workspace
   double* zfro;         // [maxit + 1] ||Z_k||_F^2 of the iterate entering iteration k (live block), for the condition gate
   int* iters;           // iterations actually executed
   int* ok;              // 1: F holds the Newton-Schulz result
+  unsigned* coop;       // single-launch iteration (ns_coop128_kernel), the lane's own 64 bytes: [0] barrier arrivals, [1] abort flag,
+                        // [2] XCC id + 1 of participant 0; all zero between solves (the gated Jacobi launch behind every solve resets them)
 };
 
 __device__ __forceinline__ void ns_init_body(const double* res, int C, double eps_rel, const NsWs& w, int maxit, double* red, int* sdead) {
@@ -392,6 +398,260 @@ __global__ __launch_bounds__(64 * NS) void ns_stage2_wide_kernel(NsWs w, int Cp,
   if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) *w.iters = it + 1;
 }
 
+// ---- Cp = 128 (the 128-channel levels of --mode 16x): covariance, scaling, the whole iteration and the result in ONE launch.
+// Alone on the GPU the 1 + 2 x 16 + 1 launches above take ~0.13 ms.  In a stylise call they never are alone: the other lane runs
+// persistent convolution kernels whose workgroups own a CU each (all of its LDS and registers) for the kernel's lifetime, so
+// every one of the dependent launches queues for a CU again -- measured with HIP events in an overlapped 4K step
+// (tools/experiments/lane_timeline.py): 0.59 / 0.32 ms for the two content-lane solves, 0.76 / 0.71 ms for the style-lane ones,
+// and what the content lane waits there is step time.  One launch queues once.
+// The 32 workgroups that the dispatcher places on ONE XCD (workgroup b -> XCD b mod 8; every participant compares its XCC_ID with
+// participant 0's) work inside the kernel:
+//   front end   every participant derives dead flags, Frobenius scale (ns_init_body's summation order, on its own) from the raw
+//               moments, and writes ITS four rows of the covariance, of Y0 and of Z0
+//   iteration   16 participants form T (stage 1), all 32 form Y' and Z' (stage 2); a software barrier on an agent-scope counter
+//               after each stage; the iterates travel through that XCD's L2 with sc1 (L1-bypassing) buffer loads / stores
+//   back end    ns_final_kernel's scaling of ITS four rows of the result
+// Element arithmetic, tile products, k split over the four waves, every summation order: the multi-launch path's -- the result is
+// that path's bit for bit (tools/experiments/ns_coop_probe.hip; tests/test_hip_parity.py).
+// It cannot hang: a participant that waits 0.25 s at a barrier (or finds itself on another XCD) raises the abort flag and everyone
+// leaves; the gated Jacobi launch behind every solve looks at that flag as well as at `ok`, does the solve, and zeroes the state.
+constexpr int COOP_NW = 32, COOP_MAXIT = 32;
+struct NsSched { double ca[COOP_MAXIT], cb[COOP_MAXIT]; };
+struct CoopArgs {
+  int C; double n; const double* sum; const double* sumsq; double* res; double diag_add, eps_rel;
+  NsWs w; int maxit, inverse; double zmax; int* info; int xcd;
+};
+constexpr int BUF_SC1 = 16;   // buffer cache policy: agent scope (never served from this CU's L1)
+__device__ __forceinline__ unsigned xcc_id() { unsigned v; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v)); return v & 0xf; }
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t coop_rsrc(const void* p) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 128 * 128 * 8, 0x00020000);
+}
+__device__ __forceinline__ f64x2 coop_ld2(__amdgpu_buffer_rsrc_t r, int elem) {
+  return __builtin_bit_cast(f64x2, __builtin_amdgcn_raw_buffer_load_b128(r, elem * 8, 0, BUF_SC1));
+}
+__device__ __forceinline__ double coop_ld1(__amdgpu_buffer_rsrc_t r, int elem) {
+  return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, elem * 8, 0, BUF_SC1));
+}
+__device__ __forceinline__ void coop_st1(__amdgpu_buffer_rsrc_t r, int elem, double v) {
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, elem * 8, 0, BUF_SC1);
+}
+// gemm32_splitk<4> at Cp = 128 (two k-blocks per wave, both in flight), operands through sc1 buffer loads
+__device__ __forceinline__ void gemm32_coop(const double* P, const double* Q, int i0, int j0, int lane, int wave, double (*red)[16 * 64], Acc32& acc) {
+  constexpr int CP = 128;
+  const int li = lane & 15, kk = lane >> 4, kbeg = wave * (CP / 4);
+  const __amdgpu_buffer_rsrc_t rp = coop_rsrc(P), rq = coop_rsrc(Q);
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc.t[t] = f64x4{0., 0., 0., 0.};
+  const int p0 = (i0 + li) * CP + 4 * kk, p1 = p0 + 16 * CP, q0 = (4 * kk) * CP + j0 + li;
+  KBlock x[2];
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    const int k0 = kbeg + 16 * b;
+    x[b].a0l = coop_ld2(rp, p0 + k0); x[b].a0h = coop_ld2(rp, p0 + k0 + 2);
+    x[b].a1l = coop_ld2(rp, p1 + k0); x[b].a1h = coop_ld2(rp, p1 + k0 + 2);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { x[b].b0[u] = coop_ld1(rq, q0 + (k0 + u) * CP); x[b].b1[u] = coop_ld1(rq, q0 + (k0 + u) * CP + 16); }
+  }
+  kblock_mfma(x[0], acc);
+  kblock_mfma(x[1], acc);
+  if (wave) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[wave - 1][(t * 4 + r) * 64 + lane] = acc.t[t][r];
+  }
+  __syncthreads();
+  if (!wave) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int at = (t * 4 + r) * 64 + lane;
+        acc.t[t][r] = ((acc.t[t][r] + red[0][at]) + red[1][at]) + red[2][at];
+      }
+  }
+  __syncthreads();     // red is reused by the next product
+}
+// all of this workgroup's stores have reached L2, then: arrive, wait for the other participants (or for the abort flag)
+__device__ __forceinline__ bool coop_barrier(const NsWs& w, unsigned& target, int* ok_s) {
+  __builtin_amdgcn_s_waitcnt(0);
+  __syncthreads();
+  target += COOP_NW;
+  if (threadIdx.x == 0) {
+    __hip_atomic_fetch_add(&w.coop[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const long long t0 = wall_clock64();     // 100 MHz
+    bool ok = true;
+    while (__hip_atomic_load(&w.coop[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      if (wall_clock64() - t0 > 25000000ll || __hip_atomic_load(&w.coop[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+        __hip_atomic_fetch_or(&w.coop[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ok = false;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    *ok_s = ok;
+  }
+  __syncthreads();
+  return *ok_s != 0;
+}
+
+__global__ __launch_bounds__(256) void ns_coop128_kernel(CoopArgs a, NsSched sc) {
+  const bool inject = (a.xcd & 16) != 0;             // debug key "nscoop" = 2: behave as if a participant sat on another XCD
+  if ((int)(blockIdx.x & 7) != (a.xcd & 7)) return;  // the workgroups the dispatcher places on one XCD
+  constexpr int CP = 128;
+  __shared__ double red[3][16 * 64];                  // the front end's 1024 partial sums, then the k-slice sums of the products
+  __shared__ int sdead[CP];
+  __shared__ int ok_s;
+  const NsWs& w = a.w;
+  const int C = a.C, tid = threadIdx.x, me = blockIdx.x >> 3;
+  const int lane = tid & 63, wave = tid >> 6, li = lane & 15, kk = lane >> 4;
+  const double n = a.n;
+  // ---- front end (ns_prep_kernel's arithmetic; nothing here reads what another participant writes)
+  if (me == 0) {
+    if (tid < 64) cov_floor(C, n, a.sumsq, a.res, tid);
+    for (int k = tid; k <= a.maxit; k += 256) { w.resid[k] = 0ull; w.zfro[k] = 0.; }   // atomic targets of the iteration (first touched after the barriers below)
+    if (tid == 0) { *w.iters = 0; *w.ok = 0; __hip_atomic_store(&w.coop[2], xcc_id() + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+  }
+  {
+    double ex2 = 0.;                                  // cov_floor's value, by every participant for itself
+    for (int j = lane; j < C; j += 64) ex2 = fmax(ex2, a.sumsq[(size_t)j * C + j]);
+    for (int o = 32; o > 0; o >>= 1) ex2 = fmax(ex2, __shfl_xor(ex2, o));
+    const double floor_ = ABS_FLOOR * ex2 / n;
+    for (int j = tid; j < CP; j += 256) {
+      const int d = j < C ? !(cov_value(j, j, C, n, a.sum, a.sumsq, a.diag_add) > floor_) : 1;
+      sdead[j] = d;
+      if (me == 0 && j < C) w.dead[j] = d;
+    }
+  }
+  __syncthreads();
+  double* part = &red[0][0];
+  {
+    // ||A_live||_F: ns_init_body's partition over 1024 threads and its tree, four of those threads per thread here
+    const int nrg = 1024 / C > 0 ? 1024 / C : 1;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int vt = tid + 256 * v, grp = vt / C, c = vt - grp * C;
+      const bool live_c = grp < nrg && !sdead[c];
+      double s0 = 0., s1 = 0., s2 = 0., s3 = 0.;
+      for (int r = 4 * grp; r < C; r += 4 * nrg) {
+        double v0 = 0., v1 = 0., v2 = 0., v3 = 0.;
+        if (live_c) {
+          v0 = cov_value(r, c, C, n, a.sum, a.sumsq, a.diag_add);
+          if (r + 1 < C) v1 = cov_value(r + 1, c, C, n, a.sum, a.sumsq, a.diag_add);
+          if (r + 2 < C) v2 = cov_value(r + 2, c, C, n, a.sum, a.sumsq, a.diag_add);
+          if (r + 3 < C) v3 = cov_value(r + 3, c, C, n, a.sum, a.sumsq, a.diag_add);
+        }
+        if (!sdead[r]) s0 += v0 * v0;
+        if (r + 1 < C && !sdead[r + 1]) s1 += v1 * v1;
+        if (r + 2 < C && !sdead[r + 2]) s2 += v2 * v2;
+        if (r + 3 < C && !sdead[r + 3]) s3 += v3 * v3;
+      }
+      part[vt] = (s0 + s1) + (s2 + s3);
+    }
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) {
+      for (int i = tid; i < o; i += 256) part[i] += part[i + o];
+      __syncthreads();
+    }
+  }
+  double fro = sqrt(part[0]);
+  if (!(fro > 0.)) fro = 1.;
+  const double s0 = fro * (1.0 + a.eps_rel), s1 = a.eps_rel * fro;
+  if (me == 0 && tid == 0) { w.scal[0] = s0; w.scal[1] = s1; }
+  __syncthreads();       // part[] (red) is free again
+  {
+    // rows 4 me .. 4 me + 3: covariance + mean for whoever reads `res` later; Y0 = (A + eps f I) / s, Z0 = I (ns_fill_element)
+    const __amdgpu_buffer_rsrc_t ry = coop_rsrc(w.Y[0]), rz = coop_rsrc(w.Z[0]);
+    for (int e = tid; e < 4 * CP; e += 256) {
+      const int r = 4 * me + e / CP, c = e % CP;
+      double y = r == c ? 1.0 : 0.0;
+      if (r < C && c < C) {
+        const double cv = cov_value(r, c, C, n, a.sum, a.sumsq, a.diag_add);
+        a.res[(size_t)r * C + c] = cv;
+        if (c == 0) a.res[(size_t)C * C + C + r] = a.sum[r] / n;
+        if (!sdead[r] && !sdead[c]) y = (cv + (r == c ? s1 : 0.0)) / s0;
+      }
+      coop_st1(ry, r * CP + c, y);
+      coop_st1(rz, r * CP + c, r == c ? 1.0 : 0.0);
+    }
+  }
+  unsigned target = 0;
+  if (!coop_barrier(w, target, &ok_s)) return;
+  // the iterates travel through ONE L2: every participant must sit on participant 0's XCD
+  if (tid == 0 && (__hip_atomic_load(&w.coop[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != xcc_id() + 1u || (inject && me == 7)))
+    __hip_atomic_fetch_or(&w.coop[1], 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (!coop_barrier(w, target, &ok_s)) return;
+  if (__hip_atomic_load(&w.coop[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+  // ---- iteration
+  const int tile = me & 15, zside = me >> 4;         // stage 1: tiles by participants 0..15; stage 2: Y' by 0..15, Z' by 16..31
+  const int i0 = (tile >> 2) * 32, j0 = (tile & 3) * 32;
+  int nit = 0;
+  for (int it = 0; it < a.maxit; ++it) {
+    if (it > 0 && __longlong_as_double((long long)__hip_atomic_load(&w.resid[it - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < NS_TOL) break;
+    const int cur = it & 1, nxt = cur ^ 1;
+    if (!zside) {       // ns_stage1_wide_kernel
+      Acc32 acc;
+      gemm32_coop(w.Z[cur], w.Y[cur], i0, j0, lane, wave, red, acc);
+      if (!wave) {
+        const __amdgpu_buffer_rsrc_t rt = coop_rsrc(w.T);
+        const double ca = sc.ca[it], cb = sc.cb[it];
+        double m = 0.;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = i0 + 16 * (t >> 1) + kk + 4 * r, col = j0 + 16 * (t & 1) + li;
+            const double zy = acc.t[t][r], d = zy - (row == col ? 1.0 : 0.0);
+            m = (d == d) ? fmax(m, fabs(d)) : __longlong_as_double(0x7ff0000000000000ll);
+            coop_st1(rt, row * CP + col, (row == col ? ca : 0.0) - cb * zy);
+          }
+        for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o));
+        if (lane == 0) atomicMax(&w.resid[it], (unsigned long long)__double_as_longlong(m));
+      }
+    }
+    if (!coop_barrier(w, target, &ok_s)) return;
+    {                   // ns_stage2_wide_kernel
+      Acc32 acc;
+      gemm32_coop(zside ? w.T : w.Y[cur], zside ? w.Z[cur] : w.T, i0, j0, lane, wave, red, acc);
+      if (!wave) {
+        const __amdgpu_buffer_rsrc_t ro = coop_rsrc(zside ? w.Z[nxt] : w.Y[nxt]);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) coop_st1(ro, (i0 + 16 * (t >> 1) + kk + 4 * r) * CP + j0 + 16 * (t & 1) + li, acc.t[t][r]);
+        if (zside) {   // ||Z'||_F^2 for the condition gate
+          double q = 0.;
+#pragma unroll
+          for (int t = 0; t < 4; ++t) q += acc.t[t][0] * acc.t[t][0] + acc.t[t][1] * acc.t[t][1] + acc.t[t][2] * acc.t[t][2] + acc.t[t][3] * acc.t[t][3];
+          for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+          if (lane == 0) atomicAdd(&w.zfro[it + 1], q);
+        }
+      }
+    }
+    if (!coop_barrier(w, target, &ok_s)) return;
+    nit = it + 1;
+  }
+  // ---- back end (ns_final_kernel): every participant reaches the same verdict from the same counters
+  bool ok = nit >= 1 && __longlong_as_double((long long)__hip_atomic_load(&w.resid[nit - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < NS_TOL;
+  if (ok && a.inverse) {
+    const unsigned long long zb = __hip_atomic_load(reinterpret_cast<unsigned long long*>(&w.zfro[nit]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    ok = __longlong_as_double((long long)zb) <= a.zmax * a.zmax;   // condition gate (NS_ZMAX)
+  }
+  if (me == 0 && tid == 0) { *w.iters = nit; *w.ok = ok ? 1 : 0; if (a.info && ok) *a.info = nit; }
+  if (!ok) return;
+  {
+    const __amdgpu_buffer_rsrc_t rf = coop_rsrc(a.inverse ? w.Z[nit & 1] : w.Y[nit & 1]);
+    const double sc_out = a.inverse ? rsqrt(s0) : sqrt(s0);
+    for (int e = tid; e < 4 * CP; e += 256) {
+      const int r = 4 * me + e / CP, c = e % CP;
+      if (r >= C || c >= C) continue;
+      double v = 0.;
+      if (!sdead[r] && !sdead[c]) v = coop_ld1(rf, r * CP + c) * sc_out;
+      a.res[eig_F_offset(C) + (size_t)r * C + c] = v;
+    }
+  }
+}
+
 // F = Z / sqrt(s) (inverse) or Y * sqrt(s), dead rows/cols zeroed; ok = converged
 __global__ void ns_final_kernel(double* res, int C, int Cp, int inverse, NsWs w, int maxit, double zmax, int* info, const double* deflated,
                                 int* ok_defer) {
@@ -609,9 +869,17 @@ __device__ __forceinline__ double reduce_pair(double v) {
 //  * the kernel is bound by fp64 VALU issue on ONE CU: LPP lanes share a pair (each lane owns 2-row groups read as
 //    ds_read_b128), so the per-pair rotation arithmetic is amortised over 64/LPP pairs per wave instruction.
 template <int LPP>
-__global__ __launch_bounds__(64 * LPP) void jacobi_lds_kernel(double* res, int n_full, int* info, const int* ns_ok, double expo, double rel_thresh) {
+__global__ __launch_bounds__(64 * LPP) void jacobi_lds_kernel(double* res, int n_full, int* info, const int* ns_ok, double expo, double rel_thresh, unsigned* coop) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  if (*ns_ok) return;   // the Newton-Schulz path converged: nothing to do (uniform branch, before any barrier)
+  // the Newton-Schulz path converged: nothing to do (uniform branch).  `coop` (the single-launch iteration's state, or null):
+  // an aborted iteration never wrote `ok`, so its abort flag counts as "not converged"; and the state is zeroed for the next solve
+  bool done = *ns_ok != 0;
+  if (coop) {
+    done = done && coop[1] == 0u;
+    __syncthreads();
+    if (threadIdx.x < 4) coop[threadIdx.x] = 0u;
+  }
+  if (done) return;
   __builtin_amdgcn_s_setprio(3);  // latency-critical single-CU kernel: win issue arbitration against co-resident conv waves
   const int tid = threadIdx.x;
   double* Gg = res;
@@ -843,7 +1111,7 @@ size_t assemble_workspace_bytes(int C) { return (size_t)C * C * sizeof(double); 
 bool eig_is_big(int C, bool wide_model) { return C > 128 || (wide_model && C > 64 && ns_pad(C) % 64 == 0); }
 
 hipError_t launch_eig(int C, double n, const double* sum, const double* sumsq, int inverse, double* res, int* info_dev,
-                      void* ws, size_t ws_bytes, hipStream_t s, double diag_add, bool wide_model, int* ok_defer) {
+                      void* ws, size_t ws_bytes, hipStream_t s, double diag_add, bool wide_model, int* ok_defer, int coop_xcd, unsigned* coop_state) {
   if (C < 2 || (C & 1) || C > 512 || n < 2) return hipErrorInvalidValue;  // unbiased covariance needs n >= 2
   if (ws_bytes < eig_workspace_bytes(C)) return hipErrorOutOfMemory;
   const size_t cc = (size_t)C * C;
@@ -857,6 +1125,7 @@ hipError_t launch_eig(int C, double n, const double* sum, const double* sumsq, i
   w.zfro = reinterpret_cast<double*>(w.resid + NS_MAXIT_REG + 2);
   w.iters = reinterpret_cast<int*>(w.zfro + NS_MAXIT_REG + 2);
   w.ok = w.iters + 1;
+  w.coop = coop_state;
   w.dead = w.iters + 2;
   const bool big = eig_is_big(C, wide_model);   // deflated, scaled iteration + host check of the outcome (or the caller's: ok_defer)
   // the covariance: its own grid-wide launch only where one workgroup would be too slow (C > 128); the single-workgroup front
@@ -872,6 +1141,7 @@ hipError_t launch_eig(int C, double n, const double* sum, const double* sumsq, i
   const double guess = big || Cp <= 64 ? 0.0 : (guess_env >= 0. ? guess_env : 1e-5);
   // C > 128 (original mode): the deflated, optimally scaled iteration takes 19-20 iterations whatever the matrix
   const int maxit = maxit_env ? maxit_env : (C > 128 ? 24 : (guess > 0. ? 16 : NS_MAXIT));
+  bool coop_used = false;
   if (Cp <= 64) {
     // one workgroup, iterates in LDS (see ns_lds_kernel)
     auto go = [&](auto kern, int cp) -> hipError_t {
@@ -885,10 +1155,14 @@ hipError_t launch_eig(int C, double n, const double* sum, const double* sumsq, i
     hipError_t e = Cp == 32 ? go(ns_lds_kernel<32>, 32) : go(ns_lds_kernel<64>, 64);
     if (e != hipSuccess) return e;
   } else {
+    static const bool sk_env = [] { const char* e = wct_debug_env("WCT_NS_SPLITK"); return e ? atoi(e) != 0 : true; }();
+    const bool splitk128 = sk_env && Cp % 64 == 0;
+    const bool coop = !big && Cp == 128 && splitk128 && coop_xcd >= 0 && coop_state && maxit <= COOP_MAXIT;
+    coop_used = coop;
     if (big) {
       hipLaunchKernelGGL(ns_init_kernel, dim3(1), dim3(1024), 0, s, res, C, NS_DEFLATE, w, maxit);
       hipLaunchKernelGGL(ns_fill_kernel, dim3((unsigned)((cp2 + 255) / 256)), dim3(256), 0, s, res, C, Cp, w);
-    } else {
+    } else if (!coop) {
       hipLaunchKernelGGL(ns_prep_kernel, dim3(1), dim3(1024), 0, s, C, Cp, n, sum, sumsq, res, diag_add, 1e-15, w, maxit);
     }
     const dim3 g1(Cp / 32, Cp / 32, 1), g2(Cp / 32, Cp / 32, 2);
@@ -898,9 +1172,19 @@ hipError_t launch_eig(int C, double n, const double* sum, const double* sumsq, i
     // whole spectrum arrives together: 19 iterations for ANY matrix instead of 15 (cond 1e3) .. 39 (singular).  The schedule
     // depends on l0 alone, so it is computed here; numpy prototype: same accuracy as the plain iteration.
     double xlow = big ? sqrt(NS_DEFLATE / (1.0 + NS_DEFLATE)) : (guess > 0. ? sqrt(guess) : 1.0);
-    static const bool sk_env = [] { const char* e = wct_debug_env("WCT_NS_SPLITK"); return e ? atoi(e) != 0 : true; }();
-    const bool splitk128 = sk_env && Cp % 64 == 0;
-    for (int it = 0; it < maxit; ++it) {
+    if (coop) {   // front end, the whole iteration and the scaled result in one launch (ns_coop128_kernel); same schedule, same arithmetic
+      NsSched sc;
+      for (int it = 0; it < maxit; ++it) {
+        const double mu = xlow <= 0.9 ? sqrt(3.0 / (1.0 + xlow + xlow * xlow)) : 1.0;
+        xlow = mu * xlow * (3.0 - mu * mu * xlow * xlow) / 2.0;
+        sc.ca[it] = 1.5 * mu; sc.cb[it] = 0.5 * mu * mu * mu;
+      }
+      CoopArgs ca;
+      ca.C = C; ca.n = n; ca.sum = sum; ca.sumsq = sumsq; ca.res = res; ca.diag_add = diag_add; ca.eps_rel = 1e-15;
+      ca.w = w; ca.maxit = maxit; ca.inverse = inverse; ca.zmax = NS_ZMAX; ca.info = info_dev; ca.xcd = coop_xcd & 23;
+      hipLaunchKernelGGL(ns_coop128_kernel, dim3(8 * COOP_NW), dim3(256), 0, s, ca, sc);
+    }
+    for (int it = 0; it < (coop ? 0 : maxit); ++it) {
       if (big) {
         const double mu = xlow <= 0.9 ? sqrt(3.0 / (1.0 + xlow + xlow * xlow)) : 1.0;
         xlow = mu * xlow * (3.0 - mu * mu * xlow * xlow) / 2.0;
@@ -958,8 +1242,9 @@ hipError_t launch_eig(int C, double n, const double* sum, const double* sumsq, i
       gemm(wb[ip], Sb, Sa, nullptr, 1., nullptr, 0., 0.);             // P R S
       deflated = Sa;
     }
-    hipLaunchKernelGGL(ns_final_kernel, dim3((unsigned)((cc + 255) / 256)), dim3(256), 0, s, res, C, Cp, inverse, w, maxit, NS_ZMAX, info_dev, deflated,
-                       big ? ok_defer : nullptr);
+    if (!coop)
+      hipLaunchKernelGGL(ns_final_kernel, dim3((unsigned)((cc + 255) / 256)), dim3(256), 0, s, res, C, Cp, inverse, w, maxit, NS_ZMAX, info_dev, deflated,
+                         big ? ok_defer : nullptr);
   }
   if (big && ok_defer) return hipGetLastError();   // the caller reads *ok_defer after ITS synchronisation point and re-runs without deferral if it is 0
   if (big) {
@@ -1000,7 +1285,8 @@ hipError_t launch_eig(int C, double n, const double* sum, const double* sumsq, i
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return e;
       const unsigned threads = (unsigned)(((C / 2) * LPPv + 63) / 64 * 64);
-      hipLaunchKernelGGL(kern, dim3(1), dim3(threads), lds, s, res, C, info_dev, (const int*)w.ok, inverse ? -0.5 : 0.5, REL_THRESH);
+      hipLaunchKernelGGL(kern, dim3(1), dim3(threads), lds, s, res, C, info_dev, (const int*)w.ok, inverse ? -0.5 : 0.5, REL_THRESH,
+                         coop_used ? coop_state : (unsigned*)nullptr);
       return hipSuccess;
     };
     // ONE gated launch: Jacobi and the symmetric power of its result (it returns at once when the iteration converged)

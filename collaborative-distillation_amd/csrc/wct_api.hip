@@ -8,6 +8,7 @@
 #include <cstdarg>
 #include <cstdlib>
 #include <cstdio>
+#include <atomic>
 #include <cstring>
 #include <map>
 #include <string>
@@ -52,6 +53,7 @@ struct ProfRec {
   hipEvent_t e0, e1;
   std::string name;
   double flops, bytes;
+  bool side = false;   // recorded on the side lane's stream
 };
 
 }  // namespace
@@ -62,12 +64,18 @@ struct ProfRec {
 struct Lane {
   hipStream_t stream = nullptr;
   DevBuf actA, actB, wsMom, wsEig, sums;  // sums: sum[512] | sumsq[512*512] (doubles) | info (ints)
+  int xcd = 0;   // where this lane's single-launch Newton-Schulz iterations run (launch_eig coop_xcd): one XCD per lane, process-wide round robin
+  unsigned* coop = nullptr;   // ... and their 64 bytes of barrier state (zero between solves)
 };
 
 struct wct_ctx {
   int device = 0;
   Lane main, side;
   hipEvent_t ev_fork = nullptr, ev_style[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev_smom = nullptr, ev_cmom = nullptr;   // wct_stylize's lane stagger: the style / content moments of a level are done
+  int eig_skip = 0, eig_calls = 0;
+  int nscoop = 1;     // 1: the Newton-Schulz iteration of a 128-channel level (--mode 16x) is ONE launch (debug key "nscoop")
+  int stagger = 0;    // 1: wct_stylize hands the side lane its encoders one level at a time (debug key "stagger"; measured SLOWER, see wct_stylize)
   std::string err;
   Module mod[2][6];
   // workspace
@@ -186,7 +194,7 @@ struct ProfScope {
   ProfRec r;
   ProfScope(wct_ctx* c, hipStream_t stream, const char* name, double flops, double bytes) : ctx(c), st(stream), on(c->prof) {
     if (!on) return;
-    r.name = name; r.flops = flops; r.bytes = bytes;
+    r.name = name; r.flops = flops; r.bytes = bytes; r.side = stream == c->side.stream;
     (void)hipEventCreate(&r.e0); (void)hipEventCreate(&r.e1);
     (void)hipEventRecord(r.e0, st);
   }
@@ -201,14 +209,25 @@ void prof_collect(wct_ctx* ctx) {
   if (ctx->recs.empty()) return;
   (void)hipStreamSynchronize(ctx->main.stream);
   (void)hipStreamSynchronize(ctx->side.stream);
+  // WCT_TIMELINE=<file>: every record as "name lane start_ms end_ms" relative to the first one (tools/experiments/lane_timeline.py:
+  // what the two lanes do in an OVERLAPPED step -- event timestamps are device time, comparable across streams)
+  FILE* tl = nullptr;
+  if (const char* path = wct_debug_env("WCT_TIMELINE")) tl = fopen(path, "a");
+  if (tl) fprintf(tl, "# collect %zu records\n", ctx->recs.size());
   for (auto& r : ctx->recs) {
     float ms = 0.f;
     (void)hipEventElapsedTime(&ms, r.e0, r.e1);
+    if (tl) {
+      float t0 = 0.f;
+      (void)hipEventElapsedTime(&t0, ctx->recs.front().e0, r.e0);
+      fprintf(tl, "%s %s %.4f %.4f\n", r.name.c_str(), r.side ? "side" : "main", t0, t0 + ms);
+    }
     auto& e = ctx->prof_acc[r.name];
     if (e.launches == 0) { memset(&e, 0, sizeof e); snprintf(e.name, sizeof e.name, "%s", r.name.c_str()); }
     e.ms += ms; e.flops += r.flops; e.bytes += r.bytes; e.launches += 1;
-    (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1);
   }
+  for (auto& r : ctx->recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+  if (tl) fclose(tl);
   ctx->recs.clear();
 }
 
@@ -621,11 +640,15 @@ int eig_impl(wct_ctx* ctx, Lane& ln, int C, double n, const double* sum, const d
   if (n < 2) return fail(ctx, WCT_ERR_INVALID, "solve: unbiased covariance needs >= 2 pixels (n=%g)", n);
   if (int rc = ensure(ctx, res, eig_result_bytes(C))) return rc;
   if (int rc = ensure(ctx, ln.wsEig, eig_workspace_bytes(C))) return rc;
+  // timing experiment (debug key "eig_skip" = N): after N solves the launches are left out and `res` keeps what the last solve
+  // of this lane / level left there -- on repeated identical frames the same numbers, so the step's wall time minus the matrix
+  // functions' exposed time can be read off (tools/experiments/ab_eig_skip.sh)
+  if (ctx->eig_skip > 0 && ++ctx->eig_calls > ctx->eig_skip) return WCT_OK;
   ProfScope ps(ctx, ln.stream, inverse ? "matfun_invsqrt" : "matfun_sqrt", 0, 0);
   int* defer = nullptr;
   if (ctx->defer_big && eig_is_big(C, ctx->wide_model) && ctx->ok_n < OK_SLOTS) defer = ctx->ok_log + ctx->ok_n++;
   HIPCHK(ctx, launch_eig(C, n, sum, sumsq, inverse, reinterpret_cast<double*>(res.p), info_dev, ln.wsEig.p, ln.wsEig.cap, ln.stream,
-                         (inverse && ctx->numpy_variant) ? 1.0 : 0.0, ctx->wide_model, defer));
+                         (inverse && ctx->numpy_variant) ? 1.0 : 0.0, ctx->wide_model, defer, ctx->nscoop ? (ln.xcd | (ctx->nscoop == 2 ? 16 : 0)) : -1, ln.coop));
   return WCT_OK;
 }
 
@@ -799,7 +822,7 @@ int l1_decode_impl(wct_ctx* ctx, int level, const float* img, int H, int W, cons
 
 // style side of one level on the SIDE lane: sF = encoder(styleImg) (WCT.py:100), its moments and eigen-decomposition.
 // Independent of the content, so it is enqueued first and overlaps the content side.  Leaves eigS[level] + ev_style[level].
-int style_side(wct_ctx* ctx, int level, const float* style, int Hs, int Ws) {
+int style_side(wct_ctx* ctx, int level, const float* style, int Hs, int Ws, hipEvent_t after_moments = nullptr) {
   Module& me = ctx->mod[WCT_KIND_ENC][level];
   if (!me.loaded) return fail(ctx, WCT_ERR_STATE, "encoder %d not loaded", level);
   const int C = me.layers.back().d.cout;
@@ -816,6 +839,7 @@ int style_side(wct_ctx* ctx, int level, const float* style, int Hs, int Ws) {
     if (int rc = encode_impl(ctx, ln, level, style, Hs, Ws, fS, nullptr, nullptr)) return rc;
     if (int rc = moments_impl(ctx, ln, fS, C, hs, ws, 0, ws, sv.sum, sv.sumsq)) return rc;
   }
+  if (after_moments) HIPCHK(ctx, hipEventRecord(after_moments, ln.stream));
   if (int rc = eig_impl(ctx, ln, C, (double)hs * ws, sv.sum, sv.sumsq, 0, ctx->eigS[level], sv.info + 1)) return rc;
   if (int rc = style_fold(ctx, level, ln.stream)) return rc;      // (W Ss), off the content side's critical path
   HIPCHK(ctx, hipEventRecord(ctx->ev_style[level], ln.stream));
@@ -831,7 +855,9 @@ int fork_side(wct_ctx* ctx) {
 }
 
 // content side of one level on the MAIN lane; expects style_side(level) to have been enqueued
-int content_side(wct_ctx* ctx, int level, const float* content, int H, int W, float alpha, float* out, int* Ho, int* Wo) {
+// `after_moments` (wct_stylize's lane stagger) is called once the encoder and the moments are enqueued, before the matrix function
+template <typename HOOK>
+int content_side(wct_ctx* ctx, int level, const float* content, int H, int W, float alpha, float* out, int* Ho, int* Wo, HOOK&& after_moments) {
   Module& me = ctx->mod[WCT_KIND_ENC][level];
   if (!me.loaded) return fail(ctx, WCT_ERR_STATE, "encoder %d not loaded", level);
   const int C = me.layers.back().d.cout;
@@ -852,6 +878,7 @@ int content_side(wct_ctx* ctx, int level, const float* content, int H, int W, fl
     if (int rc = encode_impl(ctx, ln, level, content, H, W, fC, nullptr, nullptr)) return rc;
     if (int rc = moments_impl(ctx, ln, fC, C, h, w, 0, w, sv.sum, sv.sumsq)) return rc;
   }
+  if (int rc = after_moments()) return rc;
   if (int rc = eig_impl(ctx, ln, C, (double)h * w, sv.sum, sv.sumsq, 1, ctx->eigC, sv.info)) return rc;
   // csF = wct.transform(cF, sF, csF, alpha)                  (WCT.py:104) -- as an affine map
   HIPCHK(ctx, hipStreamWaitEvent(ln.stream, ctx->ev_style[level], 0));
@@ -871,6 +898,10 @@ int content_side(wct_ctx* ctx, int level, const float* content, int H, int W, fl
   if (Ho) *Ho = h << (level - 1);
   if (Wo) *Wo = w << (level - 1);
   return WCT_OK;
+}
+
+int content_side(wct_ctx* ctx, int level, const float* content, int H, int W, float alpha, float* out, int* Ho, int* Wo) {
+  return content_side(ctx, level, content, H, W, alpha, out, Ho, Wo, []() -> int { return WCT_OK; });
 }
 
 }  // namespace
@@ -894,9 +925,16 @@ int wct_create(int device, wct_ctx** out) {
   if (const char* m = wct_debug_env("WCT_FUSE")) c->fuse = m[0] != '0';
   if (const char* m = wct_debug_env("WCT_SP")) c->sp = m[0] != '0';
   if (const char* m = wct_debug_env("WCT_L1FUSE")) c->l1fuse = m[0] != '0';
+  static std::atomic<int> next_xcd{0};
+  c->main.xcd = next_xcd.fetch_add(2) & 7;
+  c->side.xcd = (c->main.xcd + 1) & 7;
   bool ok = hipStreamCreateWithFlags(&c->side.stream, hipStreamNonBlocking) == hipSuccess;
+  for (Lane* ln : {&c->main, &c->side})
+    ok = ok && hipMalloc(reinterpret_cast<void**>(&ln->coop), 64) == hipSuccess && hipMemset(ln->coop, 0, 64) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess;
   for (int l = 1; l <= 5 && ok; ++l) ok = hipEventCreateWithFlags(&c->ev_style[l], hipEventDisableTiming) == hipSuccess;
+  ok = ok && hipEventCreateWithFlags(&c->ev_smom, hipEventDisableTiming) == hipSuccess;
+  ok = ok && hipEventCreateWithFlags(&c->ev_cmom, hipEventDisableTiming) == hipSuccess;
   ok = ok && hipMalloc(reinterpret_cast<void**>(&c->sat_dev), 256) == hipSuccess && hipMemset(c->sat_dev, 0, 256) == hipSuccess;
   ok = ok && hipHostMalloc(reinterpret_cast<void**>(&c->sat_host), 64, hipHostMallocDefault) == hipSuccess;
   ok = ok && hipMalloc(reinterpret_cast<void**>(&c->ok_log), 64 * sizeof(int)) == hipSuccess;
@@ -916,8 +954,11 @@ void wct_destroy(wct_ctx* ctx) {
   prof_collect(ctx);
   for (int k = 0; k < 2; ++k)
     for (int l = 0; l < 6; ++l) free_module(ctx->mod[k][l]);
-  for (Lane* ln : {&ctx->main, &ctx->side})
+  for (Lane* ln : {&ctx->main, &ctx->side}) {
     for (DevBuf* b : {&ln->actA, &ln->actB, &ln->wsMom, &ln->wsEig, &ln->sums}) release(*b);
+    if (ln->coop) (void)hipFree(ln->coop);
+    ln->coop = nullptr;
+  }
   for (DevBuf* b : {&ctx->featC, &ctx->featS, &ctx->tmpT, &ctx->wsAsm, &ctx->small, &ctx->foldW, &ctx->foldW16, &ctx->eigC, &ctx->l1img, &ctx->u8c, &ctx->u8s, &ctx->u8o, &ctx->rsz_tmp}) release(*b);
   for (ResizeAxis& a : ctx->rsz_axes) (void)hipFree(a.bounds);
   ctx->rsz_axes.clear();
@@ -927,6 +968,8 @@ void wct_destroy(wct_ctx* ctx) {
     if (ctx->ev_style[l]) (void)hipEventDestroy(ctx->ev_style[l]);
   }
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+  if (ctx->ev_smom) (void)hipEventDestroy(ctx->ev_smom);
+  if (ctx->ev_cmom) (void)hipEventDestroy(ctx->ev_cmom);
   if (ctx->side.stream) (void)hipStreamDestroy(ctx->side.stream);
   if (ctx->sat_dev) (void)hipFree(ctx->sat_dev);
   if (ctx->sat_host) (void)hipHostFree(ctx->sat_host);
@@ -1002,6 +1045,9 @@ int wct_debug_set(wct_ctx* ctx, const char* key, double value) {
   else if (!strcmp(key, "u8fuse")) ctx->u8fuse = v;
   else if (!strcmp(key, "upconv")) ctx->upconv = v;
   else if (!strcmp(key, "fastfold")) ctx->fastfold = v;
+  else if (!strcmp(key, "stagger")) ctx->stagger = v;
+  else if (!strcmp(key, "nscoop")) ctx->nscoop = (int)value;      // 0: multi-launch, 1: single launch, 2: single launch with an injected placement fault
+  else if (!strcmp(key, "eig_skip")) { ctx->eig_skip = (int)value; ctx->eig_calls = 0; }
   else if (!strcmp(key, "side_priority")) {
     // priority of the style-side stream relative to the default: 0 = default, 1 = lowest (style kernels only fill the
     // content cascade's gaps), -1 = highest
@@ -1404,7 +1450,9 @@ int wct_content_decode(wct_ctx* ctx, int level, const double* M, const double* b
 
 namespace {
 // the content cascade of WCT.py:120-125 against the style statistics already in the context
-int cascade(wct_ctx* ctx, const float* content, int H, int W, float alpha, int num_run, float* out, int* Ho, int* Wo) {
+// `style` (wct_stylize with the lane stagger): the style side of level L - 1 is enqueued from inside level L of the first run
+int cascade(wct_ctx* ctx, const float* content, int H, int W, float alpha, int num_run, float* out, int* Ho, int* Wo,
+            const float* style = nullptr, int Hs = 0, int Ws = 0) {
   // `out` doubles as the running image: level L reads one buffer and writes the other (ping-pong with tmpT)
   const size_t img_bytes = (size_t)3 * H * W * sizeof(float);
   if (int rc = ensure(ctx, ctx->tmpT, img_bytes)) return rc;
@@ -1415,7 +1463,13 @@ int cascade(wct_ctx* ctx, const float* content, int H, int W, float alpha, int n
     for (int level = 5; level >= 1; --level) {
       int ho, wo;
       float* dst = bufs[which];
-      if (int rc = content_side(ctx, level, cur, h, w, alpha, dst, &ho, &wo)) return rc;
+      if (int rc = content_side(ctx, level, cur, h, w, alpha, dst, &ho, &wo, [&]() -> int {
+            if (!style || run > 0 || level == 1) return WCT_OK;
+            // the main lane is about to sit in a matrix function (a few workgroups): the side lane gets its next encoder NOW
+            HIPCHK(ctx, hipEventRecord(ctx->ev_cmom, ctx->main.stream));
+            HIPCHK(ctx, hipStreamWaitEvent(ctx->side.stream, ctx->ev_cmom, 0));
+            return style_side(ctx, level - 1, style, Hs, Ws);
+          })) return rc;
       cur = dst; h = ho; w = wo; which ^= 1;
     }
   if (cur != out) HIPCHK(ctx, hipMemcpyAsync(out, cur, (size_t)3 * h * w * sizeof(float), hipMemcpyDeviceToDevice, ctx->main.stream));
@@ -1434,9 +1488,22 @@ int wct_stylize(wct_ctx* ctx, const float* content, int H, int W, const float* s
   // every level and every run, WCT.py:121-125), so it is computed once and overlaps the content cascade
   return with_deferred_solves(ctx, false, [&]() -> int {
     if (int rc = fork_side(ctx)) return rc;
-    for (int level = 5; level >= 1; --level)
-      if (int rc = style_side(ctx, level, style, Hs, Ws)) return rc;
-    return cascade(ctx, content, H, W, alpha, num_run, out, Ho, Wo);
+    if (!ctx->stagger || !ctx->overlap) {   // (one lane: its moments buffer holds ONE level's sums at a time -- nothing to interleave)
+      for (int level = 5; level >= 1; --level)
+        if (int rc = style_side(ctx, level, style, Hs, Ws)) return rc;
+      return cascade(ctx, content, H, W, alpha, num_run, out, Ho, Wo);
+    }
+    // Lane stagger (an experiment that stays switchable, OFF by default).  The matrix functions occupy a handful of workgroups;
+    // enqueued all at once, the style side runs ahead and is finished when the content lane reaches its third matrix function.
+    // Staggered, the content encoder of level 5 starts when the style moments of level 5 are done, and the style side of level
+    // L - 1 starts when the content moments of level L are done (its encoder under the content inverse square root, its own
+    // square root under the content decoder).  Same kernels, same results -- and measured slower on every box
+    // (tools/experiments/ab_stagger.sh: config 2 +0.2 ms, config 3 +0.8 ms): two big kernels that overlap finish sooner than
+    // the same two in sequence (one's tail and epilogue stalls fill with the other's workgroups), and the stagger trades 1.5 ms
+    // of such overlap for 0.3 ms of matrix functions under an encoder (tools/experiments/lane_timeline.py).
+    if (int rc = style_side(ctx, 5, style, Hs, Ws, ctx->ev_smom)) return rc;
+    HIPCHK(ctx, hipStreamWaitEvent(ctx->main.stream, ctx->ev_smom, 0));
+    return cascade(ctx, content, H, W, alpha, num_run, out, Ho, Wo, style, Hs, Ws);
   });
 }
 

@@ -147,6 +147,45 @@ def test_solve_ill_conditioned_and_singular(torch_cuda, wct16, oracle, C, lmin, 
     assert rel_err(M.cpu().numpy(), Mr) < tol and rel_err(b.cpu().numpy(), br) < tol, (info, rel_err(M.cpu().numpy(), Mr))
 
 
+def test_single_launch_newton_schulz_is_the_multi_launch_one(torch_cuda, weights16x, oracle):
+    """C = 128 (levels 5 and 4 of --mode 16x): the coupled iteration as ONE launch on one XCD (solve.hip ns_coop128_kernel, software
+    barrier, iterates through that XCD's L2) against the 2 x 16 stage launches (debug key "nscoop" 0): the same tile products in
+    the same order -> (M, b) and the iteration counts bit for bit, for a well-conditioned and an ill-conditioned pair, alone and
+    while the other lane keeps the GPU busy (a whole overlapped cascade, bitwise).  And its safety net: with a participant
+    reported on the wrong XCD ("nscoop" 2) everyone leaves, the outcome says "not converged" and the gated Jacobi launch solves."""
+    from wct_hip import WCT
+    torch = torch_cuda
+    C = 128
+    rng = np.random.default_rng(5)
+    def spd(lo, scale):
+        Q, _ = np.linalg.qr(rng.standard_normal((C, C)))
+        return (Q * (scale * np.exp(np.linspace(0.0, np.log(lo), C)))) @ Q.T
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float64)).cuda()
+    raw = lambda n, mu, cov: (n, dev(n * mu), dev((n - 1) * (cov + cov.T) / 2 + n * np.outer(mu, mu)))
+    cases = [(spd(1e-3, 5.0), spd(1e-2, 2.0), rng.random(C), rng.random(C)), (spd(1e-6, 40.0), spd(1e-5, 3.0), rng.random(C), rng.random(C))]
+    gen = torch.Generator(device="cuda").manual_seed(9)
+    c = torch.rand((1, 3, 1024, 1536), device="cuda", generator=gen)
+    s = torch.rand((1, 3, 768, 1024), device="cuda", generator=gen)
+    res = {}
+    for mode in (1, 0, 2):
+        w = WCT(types.SimpleNamespace(mode="16x", alpha=1.0), weights=weights16x)
+        w.debug_set("nscoop", mode)
+        out = []
+        for cov_c, cov_s, mu_c, mu_s in cases:
+            M, b, info = w.solve(*raw(50000.0, mu_c, cov_c), *raw(20000.0, mu_s, cov_s), alpha=1.0, want_info=True)
+            Mr, br = oracle.affine_from_moments(mu_c, (cov_c + cov_c.T) / 2, mu_s, (cov_s + cov_s.T) / 2, 1.0)
+            assert rel_err(M.cpu().numpy(), Mr) < 1e-6 and rel_err(b.cpu().numpy(), br) < 1e-6, (mode, info)
+            out.append((M.clone(), b.clone(), info))
+        out.append(w.stylize(c, s).clone())
+        res[mode] = out
+    for (M1, b1, i1), (M0, b0, i0), (M2, b2, i2) in zip(res[1][:2], res[0][:2], res[2][:2]):
+        assert torch.equal(M1, M0) and torch.equal(b1, b0) and i1 == i0 and all(0 < i < 40 for i in i1), (i1, i0)
+        assert all(100 < i < 140 for i in i2), i2        # the Jacobi net ran (100 + sweeps) ...
+        assert rel_err(M2.cpu().numpy(), M1.cpu().numpy()) < 1e-6   # ... and found the same map
+    assert torch.equal(res[1][2], res[0][2])
+    assert float((res[2][2] - res[1][2]).abs().max() / res[1][2].abs().max()) < 1e-3
+
+
 # --------------------------------------------------------------------------- G4 cascade
 @pytest.mark.parametrize("tag", ["a", "b"])
 def test_g4_cascade(torch_cuda, wct16, golden, tag):
@@ -204,6 +243,30 @@ def test_fast_fold_matches_the_map_based_fold(torch_cuda, weights16x, golden):
     for a, b in zip(outs[1][:-1], outs[0][:-1]):
         assert a.shape == b.shape and float((a - b).abs().max() / b.abs().max()) < 2e-6
     assert float((outs[1][-1] - outs[0][-1]).abs().max() / outs[0][-1].abs().max()) < 1e-4     # five levels chained
+
+
+def test_lane_stagger_changes_the_schedule_not_the_result(torch_cuda, weights16x):
+    """Debug switch "stagger" 1: wct_stylize hands the style lane its encoders one level at a time, each when the content lane
+    enters a matrix function (wct_api.hip; default 0 = the whole style side enqueued up front, which measures faster).  Only the
+    order in time of independent kernels changes: bitwise the same image, with two runs (the style side belongs to the first), in
+    both model widths, through the uint8 entry and with the side lane switched off."""
+    from wct_hip import WCT, model_zoo
+    torch = torch_cuda
+    gen = torch.Generator(device="cuda").manual_seed(21)
+    c = torch.rand((1, 3, 208, 272), device="cuda", generator=gen)
+    s = torch.rand((1, 3, 176, 240), device="cuda", generator=gen)
+    c8 = (c[0].permute(1, 2, 0) * 255).round().to(torch.uint8).contiguous()
+    s8 = (s[0].permute(1, 2, 0) * 255).round().to(torch.uint8).contiguous()
+    for mode, weights in (("16x", weights16x), ("original", model_zoo.synth_weights("original", 7))):
+        outs = []
+        for stagger, overlap in ((1, True), (0, True), (1, False)):
+            w = WCT(types.SimpleNamespace(mode=mode, alpha=1.0), weights=weights)
+            w.debug_set("stagger", stagger)
+            w.set_overlap(overlap)
+            outs.append((w.stylize(c, s).clone(), w.stylize(c, s, num_run=2).clone(), w.stylize_u8(c8, s8).clone()))
+        for k, other in enumerate(outs[1:]):
+            for j, (a, b) in enumerate(zip(outs[0], other)):
+                assert torch.equal(a, b), (mode, k, j, float((a.float() - b.float()).abs().max()))
 
 
 def test_fused_ends_match_unfused(torch_cuda, weights16x):
