@@ -72,10 +72,9 @@ struct wct_ctx {
   int device = 0;
   Lane main, side;
   hipEvent_t ev_fork = nullptr, ev_style[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  hipEvent_t ev_smom = nullptr, ev_cmom = nullptr;   // wct_stylize's lane stagger: the style / content moments of a level are done
   int eig_skip = 0, eig_calls = 0;
   int nscoop = 1;     // 1: the Newton-Schulz iteration of a 128-channel level (--mode 16x) is ONE launch (debug key "nscoop")
-  int stagger = 0;    // 1: wct_stylize hands the side lane its encoders one level at a time (debug key "stagger"; measured SLOWER, see wct_stylize)
+  int interleave = 1; // 1: wct_stylize enqueues the style side of level L - 1 behind the content side of level L (debug key "interleave"; 0: all five up front)
   std::string err;
   Module mod[2][6];
   // workspace
@@ -822,7 +821,7 @@ int l1_decode_impl(wct_ctx* ctx, int level, const float* img, int H, int W, cons
 
 // style side of one level on the SIDE lane: sF = encoder(styleImg) (WCT.py:100), its moments and eigen-decomposition.
 // Independent of the content, so it is enqueued first and overlaps the content side.  Leaves eigS[level] + ev_style[level].
-int style_side(wct_ctx* ctx, int level, const float* style, int Hs, int Ws, hipEvent_t after_moments = nullptr) {
+int style_side(wct_ctx* ctx, int level, const float* style, int Hs, int Ws) {
   Module& me = ctx->mod[WCT_KIND_ENC][level];
   if (!me.loaded) return fail(ctx, WCT_ERR_STATE, "encoder %d not loaded", level);
   const int C = me.layers.back().d.cout;
@@ -839,7 +838,6 @@ int style_side(wct_ctx* ctx, int level, const float* style, int Hs, int Ws, hipE
     if (int rc = encode_impl(ctx, ln, level, style, Hs, Ws, fS, nullptr, nullptr)) return rc;
     if (int rc = moments_impl(ctx, ln, fS, C, hs, ws, 0, ws, sv.sum, sv.sumsq)) return rc;
   }
-  if (after_moments) HIPCHK(ctx, hipEventRecord(after_moments, ln.stream));
   if (int rc = eig_impl(ctx, ln, C, (double)hs * ws, sv.sum, sv.sumsq, 0, ctx->eigS[level], sv.info + 1)) return rc;
   if (int rc = style_fold(ctx, level, ln.stream)) return rc;      // (W Ss), off the content side's critical path
   HIPCHK(ctx, hipEventRecord(ctx->ev_style[level], ln.stream));
@@ -855,9 +853,7 @@ int fork_side(wct_ctx* ctx) {
 }
 
 // content side of one level on the MAIN lane; expects style_side(level) to have been enqueued
-// `after_moments` (wct_stylize's lane stagger) is called once the encoder and the moments are enqueued, before the matrix function
-template <typename HOOK>
-int content_side(wct_ctx* ctx, int level, const float* content, int H, int W, float alpha, float* out, int* Ho, int* Wo, HOOK&& after_moments) {
+int content_side(wct_ctx* ctx, int level, const float* content, int H, int W, float alpha, float* out, int* Ho, int* Wo) {
   Module& me = ctx->mod[WCT_KIND_ENC][level];
   if (!me.loaded) return fail(ctx, WCT_ERR_STATE, "encoder %d not loaded", level);
   const int C = me.layers.back().d.cout;
@@ -878,7 +874,6 @@ int content_side(wct_ctx* ctx, int level, const float* content, int H, int W, fl
     if (int rc = encode_impl(ctx, ln, level, content, H, W, fC, nullptr, nullptr)) return rc;
     if (int rc = moments_impl(ctx, ln, fC, C, h, w, 0, w, sv.sum, sv.sumsq)) return rc;
   }
-  if (int rc = after_moments()) return rc;
   if (int rc = eig_impl(ctx, ln, C, (double)h * w, sv.sum, sv.sumsq, 1, ctx->eigC, sv.info)) return rc;
   // csF = wct.transform(cF, sF, csF, alpha)                  (WCT.py:104) -- as an affine map
   HIPCHK(ctx, hipStreamWaitEvent(ln.stream, ctx->ev_style[level], 0));
@@ -898,10 +893,6 @@ int content_side(wct_ctx* ctx, int level, const float* content, int H, int W, fl
   if (Ho) *Ho = h << (level - 1);
   if (Wo) *Wo = w << (level - 1);
   return WCT_OK;
-}
-
-int content_side(wct_ctx* ctx, int level, const float* content, int H, int W, float alpha, float* out, int* Ho, int* Wo) {
-  return content_side(ctx, level, content, H, W, alpha, out, Ho, Wo, []() -> int { return WCT_OK; });
 }
 
 }  // namespace
@@ -933,8 +924,6 @@ int wct_create(int device, wct_ctx** out) {
     ok = ok && hipMalloc(reinterpret_cast<void**>(&ln->coop), 64) == hipSuccess && hipMemset(ln->coop, 0, 64) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess;
   for (int l = 1; l <= 5 && ok; ++l) ok = hipEventCreateWithFlags(&c->ev_style[l], hipEventDisableTiming) == hipSuccess;
-  ok = ok && hipEventCreateWithFlags(&c->ev_smom, hipEventDisableTiming) == hipSuccess;
-  ok = ok && hipEventCreateWithFlags(&c->ev_cmom, hipEventDisableTiming) == hipSuccess;
   ok = ok && hipMalloc(reinterpret_cast<void**>(&c->sat_dev), 256) == hipSuccess && hipMemset(c->sat_dev, 0, 256) == hipSuccess;
   ok = ok && hipHostMalloc(reinterpret_cast<void**>(&c->sat_host), 64, hipHostMallocDefault) == hipSuccess;
   ok = ok && hipMalloc(reinterpret_cast<void**>(&c->ok_log), 64 * sizeof(int)) == hipSuccess;
@@ -968,8 +957,7 @@ void wct_destroy(wct_ctx* ctx) {
     if (ctx->ev_style[l]) (void)hipEventDestroy(ctx->ev_style[l]);
   }
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
-  if (ctx->ev_smom) (void)hipEventDestroy(ctx->ev_smom);
-  if (ctx->ev_cmom) (void)hipEventDestroy(ctx->ev_cmom);
+
   if (ctx->side.stream) (void)hipStreamDestroy(ctx->side.stream);
   if (ctx->sat_dev) (void)hipFree(ctx->sat_dev);
   if (ctx->sat_host) (void)hipHostFree(ctx->sat_host);
@@ -1045,7 +1033,7 @@ int wct_debug_set(wct_ctx* ctx, const char* key, double value) {
   else if (!strcmp(key, "u8fuse")) ctx->u8fuse = v;
   else if (!strcmp(key, "upconv")) ctx->upconv = v;
   else if (!strcmp(key, "fastfold")) ctx->fastfold = v;
-  else if (!strcmp(key, "stagger")) ctx->stagger = v;
+  else if (!strcmp(key, "interleave")) ctx->interleave = v;
   else if (!strcmp(key, "nscoop")) ctx->nscoop = (int)value;      // 0: multi-launch, 1: single launch, 2: single launch with an injected placement fault
   else if (!strcmp(key, "eig_skip")) { ctx->eig_skip = (int)value; ctx->eig_calls = 0; }
   else if (!strcmp(key, "side_priority")) {
@@ -1450,7 +1438,7 @@ int wct_content_decode(wct_ctx* ctx, int level, const double* M, const double* b
 
 namespace {
 // the content cascade of WCT.py:120-125 against the style statistics already in the context
-// `style` (wct_stylize with the lane stagger): the style side of level L - 1 is enqueued from inside level L of the first run
+// `style` (wct_stylize): the style side of level L - 1 is enqueued behind the content side of level L of the first run
 int cascade(wct_ctx* ctx, const float* content, int H, int W, float alpha, int num_run, float* out, int* Ho, int* Wo,
             const float* style = nullptr, int Hs = 0, int Ws = 0) {
   // `out` doubles as the running image: level L reads one buffer and writes the other (ping-pong with tmpT)
@@ -1463,13 +1451,9 @@ int cascade(wct_ctx* ctx, const float* content, int H, int W, float alpha, int n
     for (int level = 5; level >= 1; --level) {
       int ho, wo;
       float* dst = bufs[which];
-      if (int rc = content_side(ctx, level, cur, h, w, alpha, dst, &ho, &wo, [&]() -> int {
-            if (!style || run > 0 || level == 1) return WCT_OK;
-            // the main lane is about to sit in a matrix function (a few workgroups): the side lane gets its next encoder NOW
-            HIPCHK(ctx, hipEventRecord(ctx->ev_cmom, ctx->main.stream));
-            HIPCHK(ctx, hipStreamWaitEvent(ctx->side.stream, ctx->ev_cmom, 0));
-            return style_side(ctx, level - 1, style, Hs, Ws);
-          })) return rc;
+      if (int rc = content_side(ctx, level, cur, h, w, alpha, dst, &ho, &wo)) return rc;
+      if (style && run == 0 && level > 1)
+        if (int rc = style_side(ctx, level - 1, style, Hs, Ws)) return rc;
       cur = dst; h = ho; w = wo; which ^= 1;
     }
   if (cur != out) HIPCHK(ctx, hipMemcpyAsync(out, cur, (size_t)3 * h * w * sizeof(float), hipMemcpyDeviceToDevice, ctx->main.stream));
@@ -1488,21 +1472,19 @@ int wct_stylize(wct_ctx* ctx, const float* content, int H, int W, const float* s
   // every level and every run, WCT.py:121-125), so it is computed once and overlaps the content cascade
   return with_deferred_solves(ctx, false, [&]() -> int {
     if (int rc = fork_side(ctx)) return rc;
-    if (!ctx->stagger || !ctx->overlap) {   // (one lane: its moments buffer holds ONE level's sums at a time -- nothing to interleave)
+    if (!ctx->interleave || !ctx->overlap) {   // (one lane: its moments buffer holds ONE level's sums at a time -- nothing to interleave)
       for (int level = 5; level >= 1; --level)
         if (int rc = style_side(ctx, level, style, Hs, Ws)) return rc;
       return cascade(ctx, content, H, W, alpha, num_run, out, Ho, Wo);
     }
-    // Lane stagger (an experiment that stays switchable, OFF by default).  The matrix functions occupy a handful of workgroups;
-    // enqueued all at once, the style side runs ahead and is finished when the content lane reaches its third matrix function.
-    // Staggered, the content encoder of level 5 starts when the style moments of level 5 are done, and the style side of level
-    // L - 1 starts when the content moments of level L are done (its encoder under the content inverse square root, its own
-    // square root under the content decoder).  Same kernels, same results -- and measured slower on every box
-    // (tools/experiments/ab_stagger.sh: config 2 +0.2 ms, config 3 +0.8 ms): two big kernels that overlap finish sooner than
-    // the same two in sequence (one's tail and epilogue stalls fill with the other's workgroups), and the stagger trades 1.5 ms
-    // of such overlap for 0.3 ms of matrix functions under an encoder (tools/experiments/lane_timeline.py).
-    if (int rc = style_side(ctx, 5, style, Hs, Ws, ctx->ev_smom)) return rc;
-    HIPCHK(ctx, hipStreamWaitEvent(ctx->main.stream, ctx->ev_smom, 0));
+    // Host order: S5, C5, S4, C4, ... -- on the GPU the lanes run exactly as if everything were queued (the host is ~10x ahead of
+    // the kernels), but the FIRST content kernel of a cold call no longer waits for ~400 style-side launches to be enqueued
+    // (tools/experiments/lane_timeline.py: the content lane of a lone 4K call started 0.53 ms late, of a lone --mode original
+    // call 1.5 ms).  What was also tried here and measured slower on every box: GATING the style side of level L - 1 on the
+    // content lane's progress (start it when the content moments of level L are done, or when its matrix function is) so
+    // that content-lane matrix functions never share the GPU with a style encoder -- config 2 +0.2 ms, config 3 +0..0.8 ms:
+    // two big kernels that overlap finish sooner than the same two in sequence, and the gates trade that overlap away.
+    if (int rc = style_side(ctx, 5, style, Hs, Ws)) return rc;
     return cascade(ctx, content, H, W, alpha, num_run, out, Ho, Wo, style, Hs, Ws);
   });
 }

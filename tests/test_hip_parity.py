@@ -245,11 +245,11 @@ def test_fast_fold_matches_the_map_based_fold(torch_cuda, weights16x, golden):
     assert float((outs[1][-1] - outs[0][-1]).abs().max() / outs[0][-1].abs().max()) < 1e-4     # five levels chained
 
 
-def test_lane_stagger_changes_the_schedule_not_the_result(torch_cuda, weights16x):
-    """Debug switch "stagger" 1: wct_stylize hands the style lane its encoders one level at a time, each when the content lane
-    enters a matrix function (wct_api.hip; default 0 = the whole style side enqueued up front, which measures faster).  Only the
-    order in time of independent kernels changes: bitwise the same image, with two runs (the style side belongs to the first), in
-    both model widths, through the uint8 entry and with the side lane switched off."""
+def test_interleaved_enqueue_changes_the_schedule_not_the_result(torch_cuda, weights16x):
+    """wct_stylize enqueues the style side of level L - 1 behind the content side of level L (so that a cold call's first content
+    kernel is not queued behind ~400 style-side launches); debug switch "interleave" 0 = all five style sides up front.  Only the
+    order in which independent kernels are ENQUEUED changes: bitwise the same image, with two runs (the style side belongs to the
+    first), in both model widths, through the uint8 entry and with the side lane switched off."""
     from wct_hip import WCT, model_zoo
     torch = torch_cuda
     gen = torch.Generator(device="cuda").manual_seed(21)
@@ -259,9 +259,9 @@ def test_lane_stagger_changes_the_schedule_not_the_result(torch_cuda, weights16x
     s8 = (s[0].permute(1, 2, 0) * 255).round().to(torch.uint8).contiguous()
     for mode, weights in (("16x", weights16x), ("original", model_zoo.synth_weights("original", 7))):
         outs = []
-        for stagger, overlap in ((1, True), (0, True), (1, False)):
+        for interleave, overlap in ((1, True), (0, True), (1, False)):
             w = WCT(types.SimpleNamespace(mode=mode, alpha=1.0), weights=weights)
-            w.debug_set("stagger", stagger)
+            w.debug_set("interleave", interleave)
             w.set_overlap(overlap)
             outs.append((w.stylize(c, s).clone(), w.stylize(c, s, num_run=2).clone(), w.stylize_u8(c8, s8).clone()))
         for k, other in enumerate(outs[1:]):

@@ -2,7 +2,7 @@
 """What the two lanes do during ONE overlapped stylise call: HIP-event timestamps of every profile scope (WCT_TIMELINE, wct_api.hip
 prof_collect), printed as a merged timeline plus: wall, per-lane busy time, time with both / one / no lane inside a scope, and the
 time in which ONLY matrix functions (or other tiny launches) were running.
-usage (GPU box): python tools/experiments/lane_timeline.py [cfg2|cfg3] [stagger]  -> gpurun_out/lane_timeline_<cfg>_<stagger>.txt"""
+usage (GPU box): python tools/experiments/lane_timeline.py [cfg2|cfg3] [interleave 1|0]  -> gpurun_out/lane_timeline_<cfg>_<interleave>.txt"""
 import os
 import sys
 import types
@@ -11,9 +11,9 @@ REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, os.path.join(REPO, "collaborative-distillation_amd"))
 sys.path.insert(0, os.path.join(REPO, "tests"))
 cfg = sys.argv[1] if len(sys.argv) > 1 else "cfg2"
-stagger = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+interleave = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
-raw = os.path.join(REPO, "gpurun_out", "lane_timeline_%s_%d.raw" % (cfg, stagger))
+raw = os.path.join(REPO, "gpurun_out", "lane_timeline_%s_%d.raw" % (cfg, interleave))
 if os.path.exists(raw):
     os.remove(raw)
 os.environ["WCT_DEBUG"] = "1"
@@ -28,7 +28,7 @@ if cfg == "cfg3":
 else:
     w = WCT(types.SimpleNamespace(mode="16x", alpha=1.0), weights=model_zoo.load_npz_weights(os.path.join(REPO, "collaborative-distillation_amd", "weights", "16x.npz")))
     c, s = cfg2_frames()
-w.debug_set("stagger", stagger)
+w.debug_set("interleave", interleave)
 c, s = torch.from_numpy(c).cuda(), torch.from_numpy(s).cuda()
 out = torch.empty_like(c)
 for _ in range(3):
@@ -49,7 +49,7 @@ for ln in open(raw):
 recs.sort()
 small = lambda n: n.startswith(("matfun", "fold", "assemble", "split"))  # noqa: E731
 T0, T1 = min(r[0] for r in recs), max(r[1] for r in recs)
-lines = ["# %s stagger=%d: %d scopes, wall %.3f ms" % (cfg, stagger, len(recs), T1 - T0)]
+lines = ["# %s interleave=%d: %d scopes, wall %.3f ms (ONE cold call: synchronised before it)" % (cfg, interleave, len(recs), T1 - T0)]
 # sweep
 pts = sorted({r[0] for r in recs} | {r[1] for r in recs})
 acc = {"both_big": 0.0, "one_big": 0.0, "only_small": 0.0, "idle": 0.0, "big+small": 0.0}
@@ -65,5 +65,5 @@ for lane in ("main", "side"):
         lane, sum(r[1] - r[0] for r in recs if r[2] == lane), sum(r[1] - r[0] for r in recs if r[2] == lane and small(r[3]))))
 for t0, t1, lane, name in recs:
     lines.append("%8.3f %8.3f %7.3f  %s%s" % (t0 - T0, t1 - T0, t1 - t0, "" if lane == "main" else " " * 40, name))
-open(os.path.join(REPO, "gpurun_out", "lane_timeline_%s_%d.txt" % (cfg, stagger)), "w").write("\n".join(lines) + "\n")
+open(os.path.join(REPO, "gpurun_out", "lane_timeline_%s_%d.txt" % (cfg, interleave)), "w").write("\n".join(lines) + "\n")
 print("\n".join(lines[:4]))
