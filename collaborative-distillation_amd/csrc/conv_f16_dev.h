@@ -484,7 +484,8 @@ inline int num_cus() {
   static int n = [] {
     int dev = 0, v = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v < 1) v = 256;
-    if (const char* e = getenv("WCT_CU_RESERVE")) { const int r = atoi(e); if (r > 0 && r < v - 8) v -= r; }
+    // experiment (tools/experiments/ab_cu_reserve.sh): size the persistent grids for fewer CUs than there are
+    if (const char* e = wct_debug_env("WCT_CU_RESERVE")) { const int r = atoi(e); if (r > 0 && r < v - 8) v -= r; }
     return v;
   }();
   return n;
