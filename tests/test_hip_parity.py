@@ -178,6 +178,26 @@ def test_single_launch_newton_schulz_is_the_multi_launch_one(torch_cuda, weights
             out.append((M.clone(), b.clone(), info))
         out.append(w.stylize(c, s).clone())
         res[mode] = out
+    # channel counts that are padded to the kernel's 128 (identity block in the padding), with dead channels among the live ones
+    for Cq, dead in ((98, 0), (126, 5), (112, 17)):
+        live = Cq - dead
+        def spd_q(lo, scale):
+            Q, _ = np.linalg.qr(rng.standard_normal((live, live)))
+            A = np.zeros((Cq, Cq))
+            idx = np.sort(rng.permutation(Cq)[:live])
+            A[np.ix_(idx, idx)] = (Q * (scale * np.exp(np.linspace(0.0, np.log(lo), live)))) @ Q.T
+            return (A + A.T) / 2
+        cov_c, cov_s = spd_q(1e-4, 7.0), spd_q(1e-3, 2.0)
+        mu_c, mu_s = rng.random(Cq) * (cov_c.diagonal() > 0), rng.random(Cq) * (cov_s.diagonal() > 0)
+        got = {}
+        for mode in (1, 0):
+            w = WCT(types.SimpleNamespace(mode="16x", alpha=1.0), weights=weights16x)
+            w.debug_set("nscoop", mode)
+            got[mode] = w.solve(*raw(30000.0, mu_c, cov_c), *raw(9000.0, mu_s, cov_s), alpha=0.7, want_info=True)
+        assert torch.equal(got[1][0], got[0][0]) and torch.equal(got[1][1], got[0][1]) and got[1][2] == got[0][2], (Cq, got[1][2], got[0][2])
+        assert all(0 < i < 40 for i in got[1][2]), (Cq, got[1][2])
+        Mr, br = oracle.affine_from_moments(mu_c, cov_c, mu_s, cov_s, 0.7)
+        assert rel_err(got[1][0].cpu().numpy(), Mr) < 1e-6 and rel_err(got[1][1].cpu().numpy(), br) < 1e-6, Cq
     for (M1, b1, i1), (M0, b0, i0), (M2, b2, i2) in zip(res[1][:2], res[0][:2], res[2][:2]):
         assert torch.equal(M1, M0) and torch.equal(b1, b0) and i1 == i0 and all(0 < i < 40 for i in i1), (i1, i0)
         assert all(100 < i < 140 for i in i2), i2        # the Jacobi net ran (100 + sweeps) ...
