@@ -80,7 +80,7 @@ def source_id():
     return h.hexdigest()[:16]
 
 
-def live_pmc(config, timeout=180):
+def live_pmc(config, timeout=90):
     """The two PMC passes of MI355X_MICROARCH.md's HBM recipe, taken NOW: counters cannot be read from inside this process, so a
     bounded copy of this very command (`--steps-only`, 1 warm-up + 2 steps, kernels one at a time) runs twice as a child under
     `rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `... WRITE_SIZE` (separate passes, nothing else traced) while this process idles,
@@ -574,7 +574,7 @@ def main():
         pm = pmc_traffic(roof["kernel"], live) or pmc_traffic(roof["kernel"])
         roof["traffic"], roof["traffic_source"] = (pm[0], pm[1]) if pm else (None, None)
         r3 = passes.get("cfg3_original", {}).get("roofline") if args.config != "cfg3" else None
-        if r3 and live_ok:
+        if r3 and live:      # (not attempted when the first collection failed: bounded run time)
             live3 = live_pmc("cfg3")
             pm3 = pmc_traffic(r3["kernel"], live3) if live3 else None
             r3["traffic"], r3["traffic_source"] = (pm3[0], pm3[1]) if pm3 else (None, None)
