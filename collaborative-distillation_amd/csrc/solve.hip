@@ -398,6 +398,64 @@ __global__ __launch_bounds__(64 * NS) void ns_stage2_wide_kernel(NsWs w, int Cp,
   if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) *w.iters = it + 1;
 }
 
+// ---- the decoder-side fold of the wide models (--mode original, cin = 256 / 512): W'[(o, tap)][i] = SUM_c W[(o, tap)][c] M[c][i]
+// as a [cout * 9] x [cin] x [cin] fp64 GEMM on the matrix cores, with this file's 32 x 32 split-k tiles (the rows are the
+// decoder's first-conv weights as doubles, [(o, tap)][c], prepared once at load: fold_rows_kernel).  It replaces misc.hip's
+// fold_block_kernel on those layers -- fp64 VALU FMAs fed by wave-uniform LDS reads: 271 us per launch at cin = cout = 512, 9 TF --
+// which sits on the content lane between the inverse square root and the decoder.  Epilogue: the conv kernels' packed fp32
+// layout + max |w'| for the f16 split's scale; the workgroups past the GEMM rows form b'[o] = bias[o] + SUM_c Wsum[o][c] b[c].
+template <int NS>
+__global__ __launch_bounds__(64 * NS) void fold_gemm_kernel(const double* Wd, const double* Wsum, const float* bias, int cout, int cin, int cout_pad,
+                                                             const double* M, const double* b, float* wpk, float* bias_out, unsigned* maxbits) {
+  __shared__ double red[NS - 1][16 * 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int rows = cout * 9;
+  if ((int)blockIdx.y * 32 >= rows) {       // bias rows: one wave per output channel
+    if (blockIdx.x != 0) return;
+    const int o = ((int)blockIdx.y - rows / 32) * NS + wave;
+    if (o >= cout_pad) return;
+    double part = 0.;
+    if (o < cout)
+      for (int c = lane; c < cin; c += 64) part += Wsum[(size_t)o * cin + c] * b[c];
+    for (int k = 32; k > 0; k >>= 1) part += __shfl_xor(part, k);
+    if (lane == 0) bias_out[o] = o < cout ? (float)((double)bias[o] + part) : 0.f;
+    return;
+  }
+  const int i0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
+  Acc32 acc;
+  gemm32_splitk<NS>(Wd, M, cin, i0, j0, lane, wave, red, acc);
+  if (wave) return;
+  const int li = lane & 15, kk = lane >> 4;
+  float mx = 0.f;
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = i0 + 16 * (t >> 1) + kk + 4 * r, i = j0 + 16 * (t & 1) + li;
+      const int o = row / 9, tap = row - 9 * o;
+      const float v = (float)acc.t[t][r];
+      mx = fmaxf(mx, fabsf(v));
+      wpk[((((size_t)(i >> 4) * 9 + tap) * 4 + ((i >> 2) & 3)) * cout_pad + o) * 4 + (i & 3)] = v;
+    }
+  for (int k = 32; k > 0; k >>= 1) mx = fmaxf(mx, __shfl_xor(mx, k));
+  if (maxbits && lane == 0) atomicMax(maxbits, __float_as_uint(mx));
+}
+
+// OIHW fp32 [o][c][9] -> rows[(o * 9 + tap)][c] and wsum[o][c] = SUM_tap w (tap order 0..8), as doubles
+__global__ void fold_rows_kernel(const float* w, int cout, int cin, double* rows, double* wsum) {
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (long)cout * cin) return;
+  const int o = (int)(e / cin), c = (int)(e % cin);
+  double ws = 0.;
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const double v = (double)w[e * 9 + t];
+    rows[((size_t)o * 9 + t) * cin + c] = v;
+    ws += v;
+  }
+  wsum[e] = ws;
+}
+
 // ---- Cp = 128 (the 128-channel levels of --mode 16x): covariance, scaling, the whole iteration and the result in ONE launch.
 // Alone on the GPU the 1 + 2 x 16 + 1 launches above take ~0.13 ms.  In a stylise call they never are alone: the other lane runs
 // persistent convolution kernels whose workgroups own a CU each (all of its LDS and registers) for the kernel's lifetime, so
@@ -1109,6 +1167,29 @@ size_t eig_workspace_bytes(int C) {
 size_t assemble_workspace_bytes(int C) { return (size_t)C * C * sizeof(double); }
 
 bool eig_is_big(int C, bool wide_model) { return C > 128 || (wide_model && C > 64 && ns_pad(C) % 64 == 0); }
+
+bool fold_gemm_capable(int cout, int cin, int cout_pad) { return cin >= 256 && cin % 128 == 0 && cout % 32 == 0 && cout_pad == cout; }
+size_t fold_gemm_rows_doubles(int cout, int cin) { return (size_t)cout * 10 * cin; }
+
+hipError_t launch_fold_rows(const float* w_oihw, int cout, int cin, double* rows, hipStream_t s) {
+  const long n = (long)cout * cin;
+  hipLaunchKernelGGL(fold_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w_oihw, cout, cin, rows, rows + (size_t)cout * 9 * cin);
+  return hipGetLastError();
+}
+
+hipError_t launch_fold_gemm(const double* rows, const float* bias, int cout, int cin, int cout_pad, const double* M, const double* b,
+                            float* wpk_out, float* bias_out, unsigned* maxbits_dev, hipStream_t s) {
+  if (!fold_gemm_capable(cout, cin, cout_pad)) return hipErrorInvalidValue;
+  if (maxbits_dev) {
+    hipError_t e = hipMemsetAsync(maxbits_dev, 0, sizeof(unsigned), s);
+    if (e != hipSuccess) return e;
+  }
+  constexpr int NS = 8;
+  const dim3 grid((unsigned)(cin / 32), (unsigned)(cout * 9 / 32 + (cout_pad + NS - 1) / NS));
+  hipLaunchKernelGGL(fold_gemm_kernel<NS>, grid, dim3(64 * NS), 0, s, rows, rows + (size_t)cout * 9 * cin, bias, cout, cin, cout_pad, M, b, wpk_out,
+                     bias_out, maxbits_dev);
+  return hipGetLastError();
+}
 
 hipError_t launch_eig(int C, double n, const double* sum, const double* sumsq, int inverse, double* res, int* info_dev,
                       void* ws, size_t ws_bytes, hipStream_t s, double diag_add, bool wide_model, int* ok_defer, int coop_xcd, unsigned* coop_state) {

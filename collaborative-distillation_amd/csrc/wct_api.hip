@@ -25,6 +25,7 @@ struct LayerDev {
   ConvDesc d{};
   int pool_after = 0, up_after = 0;
   float* w_oihw = nullptr;  // device copy of the original weights (first decoder layer only: needed by the fold)
+  double* fold_rows = nullptr;  // ... and, for the wide models' decoders, as fp64 GEMM rows + tap sums (launch_fold_gemm)
   float* bias_raw = nullptr;
   float* wpk = nullptr;
   float* bias = nullptr;
@@ -73,6 +74,7 @@ struct wct_ctx {
   Lane main, side;
   hipEvent_t ev_fork = nullptr, ev_style[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   int eig_skip = 0, eig_calls = 0;
+  int foldgemm = 1;   // 1: the wide models' folds as fp64 matrix-core GEMMs (debug key "foldgemm"; 0: misc.hip fold_block_kernel)
   int nscoop = 1;     // 1: the Newton-Schulz iteration of a 128-channel level (--mode 16x) is ONE launch (debug key "nscoop")
   int interleave = 1; // 1: wct_stylize enqueues the style side of level L - 1 behind the content side of level L (debug key "interleave"; 0: all five up front)
   std::string err;
@@ -463,6 +465,7 @@ int upload(wct_ctx* ctx, float** dst, const std::vector<float>& v) {
 void free_module(Module& m) {
   for (auto& l : m.layers) {
     if (l.w_oihw) (void)hipFree(l.w_oihw);
+    if (l.fold_rows) (void)hipFree(l.fold_rows);
     if (l.bias_raw) (void)hipFree(l.bias_raw);
     if (l.wpk) (void)hipFree(l.wpk);
     if (l.wpk16) (void)hipFree(l.wpk16);
@@ -715,7 +718,8 @@ int fold_impl(wct_ctx* ctx, int level, const double* M, const double* b, ConvDes
     char* base = reinterpret_cast<char*>(ctx->foldW16.p);
     float* inv = reinterpret_cast<float*>(base + b16);
     unsigned* maxbits = reinterpret_cast<unsigned*>(base + b16 + 16);
-    HIPCHK(ctx, launch_fold_affine(l.w_oihw, l.bias_raw, l.d.cout, l.d.cin, l.d.cout_pad, M, b, wpk, bias, maxbits, st));
+    if (l.fold_rows && ctx->foldgemm) HIPCHK(ctx, launch_fold_gemm(l.fold_rows, l.bias_raw, l.d.cout, l.d.cin, l.d.cout_pad, M, b, wpk, bias, maxbits, st));
+    else HIPCHK(ctx, launch_fold_affine(l.w_oihw, l.bias_raw, l.d.cout, l.d.cin, l.d.cout_pad, M, b, wpk, bias, maxbits, st));
     HIPCHK(ctx, launch_split_pack(wpk, l.d.cin, l.d.cout_pad, taps, maxbits, base, inv, st, true));
     out.wpk16 = base;
     out.inv_scale_ptr = inv;
@@ -725,7 +729,8 @@ int fold_impl(wct_ctx* ctx, int level, const double* M, const double* b, ConvDes
       out.wph16 = base + b16 + 64;
     }
   } else {
-    HIPCHK(ctx, launch_fold_affine(l.w_oihw, l.bias_raw, l.d.cout, l.d.cin, l.d.cout_pad, M, b, wpk, bias, nullptr, st));
+    if (l.fold_rows && ctx->foldgemm) HIPCHK(ctx, launch_fold_gemm(l.fold_rows, l.bias_raw, l.d.cout, l.d.cin, l.d.cout_pad, M, b, wpk, bias, nullptr, st));
+    else HIPCHK(ctx, launch_fold_affine(l.w_oihw, l.bias_raw, l.d.cout, l.d.cin, l.d.cout_pad, M, b, wpk, bias, nullptr, st));
   }
   return WCT_OK;
 }
@@ -1034,6 +1039,7 @@ int wct_debug_set(wct_ctx* ctx, const char* key, double value) {
   else if (!strcmp(key, "upconv")) ctx->upconv = v;
   else if (!strcmp(key, "fastfold")) ctx->fastfold = v;
   else if (!strcmp(key, "interleave")) ctx->interleave = v;
+  else if (!strcmp(key, "foldgemm")) ctx->foldgemm = v;
   else if (!strcmp(key, "nscoop")) ctx->nscoop = (int)value;      // 0: multi-launch, 1: single launch, 2: single launch with an injected placement fault
   else if (!strcmp(key, "eig_skip")) { ctx->eig_skip = (int)value; ctx->eig_calls = 0; }
   else if (!strcmp(key, "side_priority")) {
@@ -1155,6 +1161,11 @@ int wct_load_module(wct_ctx* ctx, int kind, int level, int n_layers, const wct_l
       std::vector<float> raw(L.weight, L.weight + (size_t)L.cout * L.cin * 9), rb(L.bias, L.bias + L.cout);
       if (int rc = upload(ctx, &ld.w_oihw, raw)) return rc;
       if (int rc = upload(ctx, &ld.bias_raw, rb)) return rc;
+      if (fold_gemm_capable(L.cout, L.cin, ld.d.cout_pad)) {
+        HIPCHK(ctx, hipMalloc(reinterpret_cast<void**>(&ld.fold_rows), fold_gemm_rows_doubles(L.cout, L.cin) * sizeof(double)));
+        HIPCHK(ctx, launch_fold_rows(ld.w_oihw, L.cout, L.cin, ld.fold_rows, nullptr));
+        HIPCHK(ctx, hipDeviceSynchronize());
+      }
     }
   }
   m.loaded = true;

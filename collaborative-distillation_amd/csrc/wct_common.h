@@ -162,6 +162,13 @@ hipError_t launch_assemble(int C, const double* eig_c, const double* eig_s, doub
 // ---- fold csF = M x + b into a decoder's first conv:  W' = W o M, b' = bias + W o b
 //      w_oihw: device [cout][cin][3][3] fp32 (original weights), out: packed weights + bias for ConvDesc
 //      maxbits_dev (optional): receives max |W'| as float bits for launch_split_pack(..., have_max = true)
+// the same fold for the wide models' decoders (cin = 256 / 512) as an fp64 matrix-core GEMM (solve.hip fold_gemm_kernel): `rows` =
+// the layer's weights as doubles [(o, tap)][c] followed by their tap sums [o][c] (fold_gemm_rows_doubles; launch_fold_rows, once)
+bool fold_gemm_capable(int cout, int cin, int cout_pad);
+size_t fold_gemm_rows_doubles(int cout, int cin);
+hipError_t launch_fold_rows(const float* w_oihw, int cout, int cin, double* rows, hipStream_t s);
+hipError_t launch_fold_gemm(const double* rows, const float* bias, int cout, int cin, int cout_pad, const double* M, const double* b,
+                            float* wpk_out, float* bias_out, unsigned* maxbits_dev, hipStream_t s);
 hipError_t launch_fold_affine(const float* w_oihw, const float* bias, int cout, int cin, int cout_pad,
                               const double* M, const double* b, float* wpk_out, float* bias_out,
                               unsigned* maxbits_dev, hipStream_t s);

@@ -289,6 +289,29 @@ def test_interleaved_enqueue_changes_the_schedule_not_the_result(torch_cuda, wei
                 assert torch.equal(a, b), (mode, k, j, float((a.float() - b.float()).abs().max()))
 
 
+def test_wide_fold_as_matrix_core_gemm_matches_the_valu_fold(torch_cuda):
+    """--mode original, levels 5 / 4 / 3 (decoder first convs 512 -> 512, 512 -> 256, 256 -> 128): W' = W M as an fp64 matrix-core
+    GEMM (solve.hip fold_gemm_kernel) against misc.hip's fold_block_kernel (debug key "foldgemm" 0) -- the same fp64 sums in another
+    order, rounded to fp32 once: level outputs agree to fp32 round-off, alpha = 1 and the alpha blend; levels 2 / 1 (cin < 256) do
+    not take the GEMM and agree bitwise."""
+    from wct_hip import WCT, model_zoo
+    torch = torch_cuda
+    wo = model_zoo.synth_weights("original", 7)
+    gen = torch.Generator(device="cuda").manual_seed(33)
+    c = torch.rand((1, 3, 176, 208), device="cuda", generator=gen)
+    s = torch.rand((1, 3, 160, 144), device="cuda", generator=gen)
+    outs = {}
+    for fg in (1, 0):
+        w = WCT(types.SimpleNamespace(mode="original", alpha=1.0), weights=wo)
+        w.debug_set("foldgemm", fg)
+        outs[fg] = [w.style_transfer_level(k, c, s, alpha).clone() for k in (5, 4, 3, 2, 1) for alpha in (1.0, 0.6)]
+    for k, (a, b) in enumerate(zip(outs[1], outs[0])):
+        if k >= 6:
+            assert torch.equal(a, b), k
+        else:
+            assert float((a - b).abs().max() / b.abs().max()) < 2e-6, k
+
+
 def test_fused_ends_match_unfused(torch_cuda, weights16x):
     """Fused ends vs the layer-by-layer path (odd sizes, image-border tiles).
     Decoder tail (conv12+conv11): conv12 has the unfused kernel's arithmetic; the final 16 -> 3 conv runs block-packed in the
