@@ -140,8 +140,9 @@ struct NsWs {           // carved from the eig workspace
   double* zfro;         // [maxit + 1] ||Z_k||_F^2 of the iterate entering iteration k (live block), for the condition gate
   int* iters;           // iterations actually executed
   int* ok;              // 1: F holds the Newton-Schulz result
-  unsigned* coop;       // single-launch iteration (ns_coop128_kernel), the lane's own 64 bytes: [0] barrier arrivals, [1] abort flag,
-                        // [2] XCC id + 1 of participant 0; all zero between solves (the gated Jacobi launch behind every solve resets them)
+  unsigned* coop;       // single-launch iteration (ns_coop128_kernel): [0] barrier arrivals, [1] abort flag, [2] XCC id + 1 of participant 0.
+                        // A lane owns TWO such sets and alternates: a solve counts in one and zeroes the other for its successor, so a
+                        // solve that went wrong half-way leaves nothing behind that the next one could trip over
 };
 
 __device__ __forceinline__ void ns_init_body(const double* res, int C, double eps_rel, const NsWs& w, int maxit, double* red, int* sdead) {
@@ -472,12 +473,13 @@ __global__ void fold_rows_kernel(const float* w, int cout, int cin, double* rows
 // Element arithmetic, tile products, k split over the four waves, every summation order: the multi-launch path's -- the result is
 // that path's bit for bit (tools/experiments/ns_coop_probe.hip; tests/test_hip_parity.py).
 // It cannot hang: a participant that waits 0.25 s at a barrier (or finds itself on another XCD) raises the abort flag and everyone
-// leaves; the gated Jacobi launch behind every solve looks at that flag as well as at `ok`, does the solve, and zeroes the state.
+// leaves; the gated Jacobi launch behind every solve looks at that flag as well as at `ok` and does the solve.
 constexpr int COOP_NW = 32, COOP_MAXIT = 32;
 struct NsSched { double ca[COOP_MAXIT], cb[COOP_MAXIT]; };
 struct CoopArgs {
   int C; double n; const double* sum; const double* sumsq; double* res; double diag_add, eps_rel;
   NsWs w; int maxit, inverse; double zmax; int* info; int xcd;
+  unsigned* coop_next;
 };
 constexpr int BUF_SC1 = 16;   // buffer cache policy: agent scope (never served from this CU's L1)
 __device__ __forceinline__ unsigned xcc_id() { unsigned v; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v)); return v & 0xf; }
@@ -566,6 +568,7 @@ __global__ __launch_bounds__(256) void ns_coop128_kernel(CoopArgs a, NsSched sc)
   const double n = a.n;
   // ---- front end (ns_prep_kernel's arithmetic; nothing here reads what another participant writes)
   if (me == 0) {
+    if (tid < 4) a.coop_next[tid] = 0u;               // the state the NEXT single-launch solve of this lane will use (nobody touches it now)
     if (tid < 64) cov_floor(C, n, a.sumsq, a.res, tid);
     for (int k = tid; k <= a.maxit; k += 256) { w.resid[k] = 0ull; w.zfro[k] = 0.; }   // atomic targets of the iteration (first touched after the barriers below)
     if (tid == 0) { *w.iters = 0; *w.ok = 0; __hip_atomic_store(&w.coop[2], xcc_id() + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -929,15 +932,9 @@ __device__ __forceinline__ double reduce_pair(double v) {
 template <int LPP>
 __global__ __launch_bounds__(64 * LPP) void jacobi_lds_kernel(double* res, int n_full, int* info, const int* ns_ok, double expo, double rel_thresh, unsigned* coop) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  // the Newton-Schulz path converged: nothing to do (uniform branch).  `coop` (the single-launch iteration's state, or null):
-  // an aborted iteration never wrote `ok`, so its abort flag counts as "not converged"; and the state is zeroed for the next solve
-  bool done = *ns_ok != 0;
-  if (coop) {
-    done = done && coop[1] == 0u;
-    __syncthreads();
-    if (threadIdx.x < 4) coop[threadIdx.x] = 0u;
-  }
-  if (done) return;
+  // the Newton-Schulz path converged: nothing to do (uniform branch, before any barrier).  `coop` (the single-launch iteration's
+  // state, or null): an aborted iteration never wrote `ok`, so its abort flag counts as "not converged"
+  if (*ns_ok != 0 && (!coop || coop[1] == 0u)) return;
   __builtin_amdgcn_s_setprio(3);  // latency-critical single-CU kernel: win issue arbitration against co-resident conv waves
   const int tid = threadIdx.x;
   double* Gg = res;
@@ -1192,7 +1189,7 @@ hipError_t launch_fold_gemm(const double* rows, const float* bias, int cout, int
 }
 
 hipError_t launch_eig(int C, double n, const double* sum, const double* sumsq, int inverse, double* res, int* info_dev,
-                      void* ws, size_t ws_bytes, hipStream_t s, double diag_add, bool wide_model, int* ok_defer, int coop_xcd, unsigned* coop_state) {
+                      void* ws, size_t ws_bytes, hipStream_t s, double diag_add, bool wide_model, int* ok_defer, int coop_xcd, unsigned* coop_state, int* coop_epoch) {
   if (C < 2 || (C & 1) || C > 512 || n < 2) return hipErrorInvalidValue;  // unbiased covariance needs n >= 2
   if (ws_bytes < eig_workspace_bytes(C)) return hipErrorOutOfMemory;
   const size_t cc = (size_t)C * C;
@@ -1206,7 +1203,7 @@ hipError_t launch_eig(int C, double n, const double* sum, const double* sumsq, i
   w.zfro = reinterpret_cast<double*>(w.resid + NS_MAXIT_REG + 2);
   w.iters = reinterpret_cast<int*>(w.zfro + NS_MAXIT_REG + 2);
   w.ok = w.iters + 1;
-  w.coop = coop_state;
+  w.coop = nullptr;
   w.dead = w.iters + 2;
   const bool big = eig_is_big(C, wide_model);   // deflated, scaled iteration + host check of the outcome (or the caller's: ok_defer)
   // the covariance: its own grid-wide launch only where one workgroup would be too slow (C > 128); the single-workgroup front
@@ -1238,8 +1235,9 @@ hipError_t launch_eig(int C, double n, const double* sum, const double* sumsq, i
   } else {
     static const bool sk_env = [] { const char* e = wct_debug_env("WCT_NS_SPLITK"); return e ? atoi(e) != 0 : true; }();
     const bool splitk128 = sk_env && Cp % 64 == 0;
-    const bool coop = !big && Cp == 128 && splitk128 && coop_xcd >= 0 && coop_state && maxit <= COOP_MAXIT;
+    const bool coop = !big && Cp == 128 && splitk128 && coop_xcd >= 0 && coop_state && coop_epoch && maxit <= COOP_MAXIT;
     coop_used = coop;
+    if (coop) { w.coop = coop_state + 4 * (*coop_epoch & 1); ++*coop_epoch; }
     if (big) {
       hipLaunchKernelGGL(ns_init_kernel, dim3(1), dim3(1024), 0, s, res, C, NS_DEFLATE, w, maxit);
       hipLaunchKernelGGL(ns_fill_kernel, dim3((unsigned)((cp2 + 255) / 256)), dim3(256), 0, s, res, C, Cp, w);
@@ -1263,6 +1261,7 @@ hipError_t launch_eig(int C, double n, const double* sum, const double* sumsq, i
       CoopArgs ca;
       ca.C = C; ca.n = n; ca.sum = sum; ca.sumsq = sumsq; ca.res = res; ca.diag_add = diag_add; ca.eps_rel = 1e-15;
       ca.w = w; ca.maxit = maxit; ca.inverse = inverse; ca.zmax = NS_ZMAX; ca.info = info_dev; ca.xcd = coop_xcd & 23;
+      ca.coop_next = coop_state + 4 * (*coop_epoch & 1);     // (the epoch was advanced above: this is the other set)
       hipLaunchKernelGGL(ns_coop128_kernel, dim3(8 * COOP_NW), dim3(256), 0, s, ca, sc);
     }
     for (int it = 0; it < (coop ? 0 : maxit); ++it) {
@@ -1367,7 +1366,7 @@ hipError_t launch_eig(int C, double n, const double* sum, const double* sumsq, i
       if (e != hipSuccess) return e;
       const unsigned threads = (unsigned)(((C / 2) * LPPv + 63) / 64 * 64);
       hipLaunchKernelGGL(kern, dim3(1), dim3(threads), lds, s, res, C, info_dev, (const int*)w.ok, inverse ? -0.5 : 0.5, REL_THRESH,
-                         coop_used ? coop_state : (unsigned*)nullptr);
+                         coop_used ? w.coop : (unsigned*)nullptr);
       return hipSuccess;
     };
     // ONE gated launch: Jacobi and the symmetric power of its result (it returns at once when the iteration converged)

@@ -66,7 +66,8 @@ struct Lane {
   hipStream_t stream = nullptr;
   DevBuf actA, actB, wsMom, wsEig, sums;  // sums: sum[512] | sumsq[512*512] (doubles) | info (ints)
   int xcd = 0;   // where this lane's single-launch Newton-Schulz iterations run (launch_eig coop_xcd): one XCD per lane, process-wide round robin
-  unsigned* coop = nullptr;   // ... and their 64 bytes of barrier state (zero between solves)
+  unsigned* coop = nullptr;   // ... their two sets of barrier state (64 bytes, zeroed at creation) ...
+  int coop_epoch = 0;         // ... and which set the next one counts in
 };
 
 struct wct_ctx {
@@ -650,7 +651,7 @@ int eig_impl(wct_ctx* ctx, Lane& ln, int C, double n, const double* sum, const d
   int* defer = nullptr;
   if (ctx->defer_big && eig_is_big(C, ctx->wide_model) && ctx->ok_n < OK_SLOTS) defer = ctx->ok_log + ctx->ok_n++;
   HIPCHK(ctx, launch_eig(C, n, sum, sumsq, inverse, reinterpret_cast<double*>(res.p), info_dev, ln.wsEig.p, ln.wsEig.cap, ln.stream,
-                         (inverse && ctx->numpy_variant) ? 1.0 : 0.0, ctx->wide_model, defer, ctx->nscoop ? (ln.xcd | (ctx->nscoop == 2 ? 16 : 0)) : -1, ln.coop));
+                         (inverse && ctx->numpy_variant) ? 1.0 : 0.0, ctx->wide_model, defer, ctx->nscoop ? (ln.xcd | (ctx->nscoop == 2 ? 16 : 0)) : -1, ln.coop, &ln.coop_epoch));
   return WCT_OK;
 }
 
