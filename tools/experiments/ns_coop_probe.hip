@@ -160,9 +160,16 @@ __device__ __forceinline__ bool xcd_barrier(const Ws& w, unsigned& target, unsig
 
 constexpr int NW = 32;
 __global__ __launch_bounds__(256) void ns_coop(Ws w, Sched sc, int maxit) {
+#ifdef SPREAD   // -DSPREAD: the 32 participants are workgroups 0..31 = four on each XCD: do sc1 loads / stores and agent-scope atomics
+                // keep the iterates coherent ACROSS the XCDs' L2s?  (bitwise comparison with the multi-launch schedule below)
+  if (blockIdx.x >= NW) return;
+  __shared__ double red[3][16 * 64];
+  const int me = blockIdx.x;
+#else
   if ((blockIdx.x & 7) != 0) return;                 // the workgroups the dispatcher places on one XCD
   __shared__ double red[3][16 * 64];
   const int me = blockIdx.x >> 3;
+#endif
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, kk = lane >> 4;
   // all participants must really share an XCD (an L2): compare with workgroup 0's
   if (threadIdx.x == 0) {
@@ -170,8 +177,10 @@ __global__ __launch_bounds__(256) void ns_coop(Ws w, Sched sc, int maxit) {
   }
   unsigned target = 0;
   if (!xcd_barrier(w, target, NW)) return;
+#ifndef SPREAD
   if (threadIdx.x == 0 && __hip_atomic_load(w.xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != xcc_id() + 1u)
     __hip_atomic_store(w.abort_, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
   const int tile = me & 15, half = me >> 4;          // stage 1: tiles by workgroups 0..15; stage 2: Y' by half 0, Z' by half 1
   const int i0 = (tile >> 2) * 32, j0 = (tile & 3) * 32;
   int n = 0;
