@@ -468,7 +468,7 @@ __global__ void fold_rows_kernel(const float* w, int cout, int cin, double* rows
 //   front end   every participant derives dead flags, Frobenius scale (ns_init_body's summation order, on its own) from the raw
 //               moments, and writes ITS four rows of the covariance, of Y0 and of Z0
 //   iteration   16 participants form T (stage 1), all 32 form Y' and Z' (stage 2); a software barrier on an agent-scope counter
-//               after each stage; the iterates travel through that XCD's L2 with sc1 (L1-bypassing) buffer loads / stores
+//               after each stage; the iterates travel with sc1 (agent-scope, L1-bypassing) buffer loads / stores
 //   back end    ns_final_kernel's scaling of ITS four rows of the result
 // Element arithmetic, tile products, k split over the four waves, every summation order: the multi-launch path's -- the result is
 // that path's bit for bit (tools/experiments/ns_coop_probe.hip; tests/test_hip_parity.py).
@@ -638,7 +638,7 @@ __global__ __launch_bounds__(256) void ns_coop128_kernel(CoopArgs a, NsSched sc)
   }
   unsigned target = 0;
   if (!coop_barrier(w, target, &ok_s)) return;
-  // the iterates travel through ONE L2: every participant must sit on participant 0's XCD
+  // all participants on participant 0's XCD: the exchange is coherent across XCDs too (ns_coop_probe -DSPREAD), but 15 % slower
   if (tid == 0 && (__hip_atomic_load(&w.coop[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != xcc_id() + 1u || (inject && me == 7)))
     __hip_atomic_fetch_or(&w.coop[1], 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (!coop_barrier(w, target, &ok_s)) return;
