@@ -98,6 +98,7 @@ struct wct_ctx {
   int u8fuse = 1;     // 1: wct_stylize_u8 reads / writes uint8 inside the first / last kernel where one exists (reserved)
   int fastfold = 1;   // 1: (W Ss) Wc fold without T = Ss Wc / M / b on the content side's critical path where the decoder allows (cin <= 128)
   int upconv = 1;     // 1: decoder layers behind an upsample run as per-parity 2x2 convolutions of the low-resolution map (4/9 of the products)
+  int in3wide = 1;    // 1: the 3 -> 64 first conv of the un-pruned encoders in f16x3 (level1.hip in3_wide_kernel); 0: exact-fp32 MFMA (debug key "in3wide")
   int fuse = 1;       // 1: fused conv11+conv12+pool / conv12+conv11 kernels at the full-resolution ends of the 16x networks
   int overlap = 1;    // 1: style side on the side lane (overlaps the content side); 0: everything on the caller's stream
   int conv_mode = 1;  // 0: exact-fp32 MFMA everywhere; 1: split-f16 (f16x3) MFMA for all but the first conv
@@ -548,7 +549,7 @@ int encode_impl(wct_ctx* ctx, Lane& ln, int level, const float* img, int H, int 
     const bool out_sp = (conv_runs_f16(ctx, d) || img_in) && wants_sp(i);
     if (cur_sp) d.flags |= CONV_IN_SP16;
     if (out_sp) d.flags |= CONV_OUT_SP16;
-    if (i == 0 && ctx->conv_mode == 1 && ctx->fuse && in3_wide_capable(d)) {
+    if (i == 0 && ctx->conv_mode == 1 && ctx->fuse && ctx->in3wide && in3_wide_capable(d)) {
       // 3 -> 64 first conv of the un-pruned encoders: f16x3 with four cout tiles per operand read instead of exact-fp32 MFMA
       const double px = (double)h * w;
       ProfScope ps(ctx, ln.stream, "conv3x3_f16x3<co=64,in3>", 2.0 * 27.0 * 64 * px, 4.0 * (3 + 64) * px);
@@ -1042,7 +1043,12 @@ int wct_debug_set(wct_ctx* ctx, const char* key, double value) {
   else if (!strcmp(key, "interleave")) ctx->interleave = v;
   else if (!strcmp(key, "foldgemm")) ctx->foldgemm = v;
   else if (!strcmp(key, "nscoop")) ctx->nscoop = (int)value;      // 0: multi-launch, 1: single launch, 2: single launch with an injected placement fault
-  else if (!strcmp(key, "eig_skip")) { ctx->eig_skip = (int)value; ctx->eig_calls = 0; }
+  else if (!strcmp(key, "in3wide")) ctx->in3wide = v;
+  else if (!strcmp(key, "eig_skip")) {
+    // MEASUREMENT ONLY: solves are left out and stale results reused -- wrong pictures by design; refused outside a debug run
+    if (!getenv("WCT_DEBUG")) return fail(ctx, WCT_ERR_INVALID, "debug_set: 'eig_skip' produces wrong results by design (timing experiment); set WCT_DEBUG to allow it");
+    ctx->eig_skip = (int)value; ctx->eig_calls = 0;
+  }
   else if (!strcmp(key, "side_priority")) {
     // priority of the style-side stream relative to the default: 0 = default, 1 = lowest (style kernels only fill the
     // content cascade's gaps), -1 = highest
@@ -1055,7 +1061,7 @@ int wct_debug_set(wct_ctx* ctx, const char* key, double value) {
     ctx->side.stream = ns;
     return WCT_OK;
   }
-  else return fail(ctx, WCT_ERR_INVALID, "debug_set: unknown key '%s' (fuse, sp, l1fuse, u8fuse, upconv, fastfold, side_priority)", key);
+  else return fail(ctx, WCT_ERR_INVALID, "debug_set: unknown key '%s' (fuse, sp, l1fuse, u8fuse, upconv, fastfold, interleave, foldgemm, nscoop, in3wide, eig_skip, side_priority)", key);
   HIPCHK(ctx, hipStreamSynchronize(ctx->side.stream));
   return WCT_OK;
 }

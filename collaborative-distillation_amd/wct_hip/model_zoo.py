@@ -191,3 +191,43 @@ def synth_weights(mode: str, seed: int) -> Dict[str, np.ndarray]:
                 w["%s.%s.weight" % (key, l.name)] = wt.astype(np.float32)
                 w["%s.%s.bias" % (key, l.name)] = ((rng.random(l.cout) * 0.1) + (0.2 if (kind == "dec" and l.cout == 3) else 0.0)).astype(np.float32)
     return w
+
+
+def synth_weights_conditioned(mode: str, seed: int, dense: float = 0.05) -> Dict[str, np.ndarray]:
+    """A second deterministic stand-in set for a mode without checkpoints, built so that the reference's OWN fp32 arithmetic is
+    NOT chaotic on it (fixture G15, tests/test_hip_scale.py).  Why `synth_weights` is: random ReLU stacks sit on one of two
+    sides -- He-uniform filters keep a common-mode component, a third of the 512 channels die and many more fire at a handful of
+    pixels (smallest live eigenvalue of the relu4_1 / relu5_1 covariance 1e-8 of the largest), and whitening multiplies every
+    fp32-level difference between two implementations by lambda_min^-1/2; zero-mean filters keep every channel alive (cond 10..50)
+    but a random zero-mean ReLU layer grows relative perturbations by sqrt(0.5 / 0.34) = 1.21, x140 over an encoder + decoder.
+    Here every layer is (nearly) an isometry of a signed signal carried as a channel pair:
+        channels [0, m) hold relu(x), channels [m, 2m) hold relu(-x);  the next layer forms x = a - b, applies a random matrix Q with
+        unit-norm rows over the 3x3 x m patch (rows in a 9m-dimensional space, cout/2 << 9m: nearly orthonormal) and emits
+        relu(Qx), relu(-Qx)
+    so signal and perturbations travel with gain ~1, every channel is active on half of the pixels, and relu(z) / relu(-z) pairs of
+    decorrelated z give feature covariances with cond ~ 10.  `dense` adds an unstructured U(-1, 1) component of that relative
+    size to every weight (no exact structure for a kernel to exploit by accident).  The first conv (3 -> 64) takes the conv0 output
+    as x; the last decoder conv (-> 3) is Q x scaled into [0, 1] around +0.5.  Only Generator.random is used (stable stream)."""
+    rng = np.random.default_rng(seed)
+    w: Dict[str, np.ndarray] = {}
+    for level in range(1, 6):
+        for kind, layers in (("enc", encoder_layers(mode, level)), ("dec", decoder_layers(mode, level))):
+            key = module_key(kind, level)
+            if kind == "enc":
+                w[key + ".conv0.weight"] = ORIGINAL_CONV0_W.copy()
+                w[key + ".conv0.bias"] = ORIGINAL_CONV0_B.copy()
+            for l in layers:
+                paired_in = l.cin != 3
+                m = l.cin // 2 if paired_in else l.cin
+                last = kind == "dec" and l.cout == 3
+                rows = l.cout if last else l.cout // 2
+                q = rng.random((rows, m, 3, 3)) * 2.0 - 1.0
+                q /= np.sqrt((q ** 2).sum(axis=(1, 2, 3), keepdims=True))
+                qin = np.concatenate([q, -q], axis=1) if paired_in else q          # x = a - b
+                wt = qin if last else np.concatenate([qin, -qin], axis=0)            # relu(Qx), relu(-Qx)
+                wt = wt + dense * np.sqrt(1.0 / (9 * m)) * (rng.random(wt.shape) * 2.0 - 1.0)
+                if last:
+                    wt = wt * (0.15 / 73.6)        # the signal carries the image's scale x255 (std of U[0,1) x 255 = 73.6)
+                w["%s.%s.weight" % (key, l.name)] = wt.astype(np.float32)
+                w["%s.%s.bias" % (key, l.name)] = (rng.random(l.cout) * 0.1 + (0.5 if last else 0.0)).astype(np.float32)
+    return w

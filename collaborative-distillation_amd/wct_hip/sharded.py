@@ -92,28 +92,35 @@ class ShardedStylizer:
             raise ValueError("halo_mode='exchange' needs strips of at least %d columns (narrowest: %d)" % (2 * LEVEL_HALO[4], narrowest))
         self.halo_mode = halo_mode
         self.halo = LEVEL_HALO if halo_mode == "exchange" else CUM_HALO
-        self._range = None          # (pinned host value, event): f16x3 clamps of ANY rank during the last stylize_strip
+        self._range = []            # [(pinned host value, event)], oldest first: node-wide f16x3 clamp totals of past stylize_strip calls
 
     def input_columns(self) -> Tuple[int, int]:
         """Columns of the full content image this rank must be given (its strip + the level-5 halo of its halo mode)."""
         return ext_bounds(self.own, self.W, self.halo[5])
 
     # ---- f16x3 range flag, node-wide
+    #: frames a node-wide range flag may stay unread before stylize_strip() waits for it.  The read-back of frame k is recorded
+    #: behind frame k's last all-reduce; frame k + 1 reads frame k - 1's, which has long landed: no stall in a pipelined loop
+    RANGE_LAG = 1
+
     def check_range(self, wait: bool = True) -> None:
-        """Raise OverflowError on EVERY rank if any rank's f16x3 kernels clamped an activation during the last stylize_strip (each
+        """Raise OverflowError on EVERY rank if any rank's f16x3 kernels clamped an activation during a past stylize_strip (each
         rank's saturation counter rides in the all-reduce of the moments, so all ranks hold the same total and raise -- or fall
-        back to set_conv_mode('fp32') -- together).  wait=False: only if the value has already landed (no synchronisation)."""
-        if self._range is None:
-            return
-        host, ev = self._range
-        if not wait and not ev.query():
-            return
-        ev.synchronize()
-        self._range = None
-        if float(host[0]) > 0:
+        back to set_conv_mode('fp32') -- together).  wait=True: every frame issued so far (synchronises with the last one).
+        wait=False: only frames older than RANGE_LAG -- a FIXED lag, never "whatever has landed": which frame's flag is read
+        must not depend on a rank's timing, or one rank would raise and skip a frame's collectives while its peers enter them
+        (ADVICE r3).  The values are identical on all ranks (all-reduced), the point of reading is identical by construction."""
+        keep = 0 if wait else self.RANGE_LAG
+        total = 0.0
+        while len(self._range) > keep:
+            host, ev = self._range.pop(0)
+            ev.synchronize()
+            total = max(total, float(host[0]))
+        if total > 0:
+            self._range.clear()      # the counter is cumulative: later frames would only repeat the report
             raise OverflowError("wct_hip.sharded: %d activation(s) were clamped to the f16x3 range on some rank(s) of this job: the "
                                 "frame deviates from the fp32 reference; every rank should switch to set_conv_mode('fp32') and "
-                                "acknowledge with saturation_count(reset=True)" % int(host[0]))
+                                "acknowledge with saturation_count(reset=True)" % int(total))
 
     # ---- neighbour exchange (halo_mode "exchange")
     def _p2p(self, sends, recvs):
@@ -172,7 +179,7 @@ class ShardedStylizer:
           content_decode(L, M, b, H, W) -> image     decoder with (M, b) folded into its first conv
         """
         e, dist = self.e, self.dist
-        self.check_range(wait=False)     # the previous frame's node-wide flag, if it has landed
+        self.check_range(wait=False)     # the node-wide flag of the frame before the previous one: same decision on every rank
         range_flag = getattr(e, "range_flag", None)
         # the engine's own per-call range check must not fire on ONE rank in the middle of a frame -- its peers would wait for it in
         # the next collective for ever; the flag travels in the all-reduce instead and check_range() raises on every rank
@@ -252,7 +259,7 @@ class ShardedStylizer:
             host.copy_(flags[-1], non_blocking=True)
             ev = torch.cuda.Event()
             ev.record()
-            self._range = (host, ev)
+            self._range.append((host, ev))
         return img[..., own[0] - lo:own[1] - lo].contiguous()
 
 

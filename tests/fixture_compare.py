@@ -36,6 +36,19 @@ def cfg3_frames():
     return noise_frame(3, 1080, 1920), noise_frame(4, 1080, 1920)
 
 
+def cfg3_natural_frames(gold_dir):
+    """G15 `natural`: the reference's UHD sample pair (the committed G11 JPEGs: green_park 3840x2160, style/in1.jpg 2048x2048), each
+    resized to 1920x1080 with Pillow's bilinear filter and converted like ToTensor (uint8 / 255)."""
+    import os
+    from PIL import Image
+
+    def load(name):
+        im = Image.open(os.path.join(gold_dir, name)).convert("RGB").resize((1920, 1080), Image.BILINEAR)
+        return np.ascontiguousarray(np.asarray(im).transpose(2, 0, 1).astype(np.float32) / np.float32(255))
+
+    return load("g11_uhd_content_3840x2160.jpg"), load("g11_style_2048x2048.jpg")
+
+
 def compare_to_fixture(img, g):
     """img: 3 x H x W result; g: a frame fixture (dict of arrays).  -> dict of errors relative to the reference's maximum."""
     img = np.asarray(img)

@@ -155,8 +155,20 @@ def _range_worker(rank, world, port, out_dir):
             raised = False
         except OverflowError:
             raised = True
+        # a pipelined loop WITHOUT per-frame synchronisation: the flag of frame k is read at the start of frame k + 2 on
+        # every rank -- a fixed lag, not "whichever read-back has landed on this rank" -- so both ranks complete frames 1 and 2 and
+        # both raise at the start of frame 3, before any of its collectives
+        wct.saturation_count(reset=True)
+        seq = []
+        for _ in range(3):
+            try:
+                sh.stylize_strip(content[:, :, x0:x1].contiguous(), style)
+                seq.append(0)
+            except OverflowError:
+                seq.append(1)
+        dist.barrier()                             # nobody is stuck in a collective its peer skipped
         with open(os.path.join(out_dir, "r%d.txt" % rank), "w") as f:
-            f.write("%d %d %d" % (int(own_clamped), int(raised), int(bool(torch.isfinite(out).all()))))
+            f.write("%d %d %d %s" % (int(own_clamped), int(raised), int(bool(torch.isfinite(out).all())), " ".join(str(v) for v in seq)))
     finally:
         dist.destroy_process_group()
 
@@ -165,13 +177,14 @@ def test_range_flag_travels_with_the_moments(tmp_path):
     """A clamp of the f16x3 arithmetic on ONE rank (a 3e6 pixel in rank 1's strip) is seen by EVERY rank: each rank's saturation
     counter rides as one more double in the all-reduce of the moments, ShardedStylizer.check_range() raises OverflowError on both,
     and nobody raises in the middle of the frame (the engine's per-call check is suspended inside stylize_strip: a rank that
-    stopped there would leave its peers waiting in the next collective)."""
+    stopped there would leave its peers waiting in the next collective).  In a loop without check_range() the report comes at a
+    FIXED lag (frame k's flag at the start of frame k + 2), identically on every rank."""
     import torch.multiprocessing as mp
     mp.spawn(_range_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
     r0 = [int(v) for v in open(str(tmp_path / "r0.txt")).read().split()]
     r1 = [int(v) for v in open(str(tmp_path / "r1.txt")).read().split()]
-    assert r0 == [0, 1, 1], r0      # rank 0 did not clamp itself, raised all the same, finished its strip
-    assert r1 == [1, 1, 1], r1
+    assert r0 == [0, 1, 1, 0, 0, 1], r0      # rank 0 did not clamp itself, raised all the same, finished its strip; pipelined: frame 3
+    assert r1 == [1, 1, 1, 0, 0, 1], r1
 
 
 def _cfg5_worker(rank, world, port, out_dir):

@@ -8,7 +8,7 @@ mkdir -p gpurun_out; : > $OUT
 for r in 1 2; do
   for nc in 1 0; do
     for skip in 0 30; do
-      ms=$(python bench.py --config cfg2 --steps 20 --warmup 3 --steps-only --no-cpu-baseline --debug-set nscoop=$nc --debug-set eig_skip=$skip 2>/dev/null | python -c "import json,sys; print(json.loads(sys.stdin.read())['ms_per_step'])")
+      ms=$(WCT_DEBUG=1 python bench.py --config cfg2 --steps 20 --warmup 3 --steps-only --no-cpu-baseline --debug-set nscoop=$nc --debug-set eig_skip=$skip 2>/dev/null | python -c "import json,sys; print(json.loads(sys.stdin.read())['ms_per_step'])")
       echo "cfg2 round $r nscoop=$nc eig_skip=$skip ms_per_step=$ms" | tee -a $OUT
     done
   done

@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Build container, CPU: the oracle (C loops + numpy, deterministic) against every full-size reference-made frame fixture ->
+tests/golden/oracle_vs_reference.json.  bench.py quotes these figures beside its own `hip_vs_reference` where running the oracle
+inside the bench would cost minutes (config 3: `limit` = max(1e-3, 1.25 x oracle_vs_reference), tests/test_hip_scale.py recomputes
+them on the GPU box's host).  usage: python tools/oracle_vs_reference.py [fixture names...]   (~15 min for all five on 8 vCPU)"""
+import json, os, sys, time
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [REPO, os.path.join(REPO, "collaborative-distillation_amd")]
+import numpy as np
+from oracle import wct_oracle
+from wct_hip import model_zoo
+from tests.conftest import GOLD, PKG, load_golden
+from tests.fixture_compare import cfg2_frames, cfg3_frames, cfg3_natural_frames, compare_to_fixture
+
+OUT = os.path.join(GOLD, "oracle_vs_reference.json")
+names = sys.argv[1:] or ["g13_cfg2_noise", "g13_cfg2_smooth", "g14_cfg3_original", "g15_cfg3_conditioned_noise", "g15_cfg3_conditioned_natural"]
+res = json.load(open(OUT)) if os.path.exists(OUT) else {}
+wct_oracle.set_num_threads(os.cpu_count() or 1)
+for name in names:
+    g = load_golden(name + ".npz")
+    t0 = time.time()
+    if name.startswith("g13"):
+        c, s = cfg2_frames(name.rsplit("_", 1)[1])
+        mods = wct_oracle.Modules("16x", model_zoo.load_npz_weights(os.path.join(PKG, "weights", "16x.npz")))
+    elif name.startswith("g15"):
+        c, s = cfg3_frames() if name.endswith("noise") else cfg3_natural_frames(GOLD)
+        mods = wct_oracle.Modules("original", model_zoo.synth_weights_conditioned("original", 15))
+    else:
+        c, s = cfg3_frames()
+        mods = wct_oracle.Modules("original", model_zoo.synth_weights("original", 3))
+    r = compare_to_fixture(wct_oracle.stylize(mods, c, s, 1.0), g)
+    res[name] = {"oracle_vs_reference": r["max"], "lattice_p9999": r.get("lattice_p9999"), "down16": r["down16_max"],
+                 "lattice_frac_gt_1e-3": r.get("lattice_frac_gt_gate"), "seconds": round(time.time() - t0, 1), "threads": wct_oracle.num_threads()}
+    print(name, json.dumps(res[name]), flush=True)
+    json.dump(res, open(OUT, "w"), indent=1, sort_keys=True)
