@@ -178,6 +178,48 @@ def load_fixture(name):
         return {k: z[k] for k in z.files}
 
 
+def cli_folder_pass(wct, n_contents=8, depth=3, io_threads=8):
+    """A folder of `n_contents` copies (distinct names) of the reference's UHD sample content (3840x2160 JPEG, committed fixture G11) x
+    its 2048x2048 sample style through wct_hip.cli's two loops with the engine `wct`; JPEG decode, H2D, 5-level cascade (style
+    statistics cached per style), D2H and JPEG encode + file write are ALL inside the wall time."""
+    import shutil
+    import tempfile
+    from wct_hip import cli
+    src_c, src_s = os.path.join(GOLD, "g11_uhd_content_3840x2160.jpg"), os.path.join(GOLD, "g11_style_2048x2048.jpg")
+    root = tempfile.mkdtemp(prefix="wct_cli_bench_")
+    try:
+        cdir, sdir = os.path.join(root, "content"), os.path.join(root, "style")
+        os.makedirs(cdir); os.makedirs(sdir)
+        for i in range(n_contents):
+            shutil.copyfile(src_c, os.path.join(cdir, "c%02d.jpg" % i))
+        shutil.copyfile(src_s, os.path.join(sdir, "s.jpg"))
+        pairs = cli.list_pairs(cdir, sdir)
+        res = {"workload": "%d x 3840x2160 JPEG contents x 1 2048x2048 JPEG style, --mode 16x: decode -> H2D -> cascade -> D2H -> JPEG save, "
+                           "all inside the wall time" % n_contents}
+        out_bytes = {}
+        for tag, pipe in (("serial", 0), ("pipelined", depth)):
+            outf = os.path.join(root, "out_" + tag)
+            os.makedirs(outf)
+            a = cli.build_parser().parse_args(["--mode", "16x", "--contentPath", cdir, "--stylePath", sdir, "--outf", outf, "--log_mark", "B",
+                                               "--pipeline", str(pipe), "--io_threads", str(io_threads)])
+            log = lambda sth: None     # noqa: E731
+            (cli.run_pipelined if pipe else cli.run_serial)(a, wct, pairs[:2], cdir, sdir, log)      # warm-up: page cache, pinned pools
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            (cli.run_pipelined if pipe else cli.run_serial)(a, wct, pairs, cdir, sdir, log)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            res[tag] = {"pairs_per_s": round(len(pairs) / dt, 2), "ms_per_pair": round(dt / len(pairs) * 1e3, 2),
+                        "MPs": round(len(pairs) * 3840 * 2160 / 1e6 / dt, 1)}
+            out_bytes[tag] = [open(os.path.join(outf, f), "rb").read() for f in sorted(os.listdir(outf)) if f.endswith(".jpg")]
+        res["pipelined"].update({"pairs_in_flight": depth, "io_threads": io_threads})
+        res["outputs_byte_identical"] = out_bytes["serial"] == out_bytes["pipelined"]
+        res["speedup"] = round(res["serial"]["ms_per_pair"] / res["pipelined"]["ms_per_pair"], 2)
+        return res
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
+
+
 def oracle_vs_reference_table():
     path = os.path.join(GOLD, "oracle_vs_reference.json")
     return json.load(open(path)) if os.path.exists(path) else None
@@ -475,6 +517,12 @@ def main():
             pass
         passes["u8_end_to_end"] = u8
         del c_u8, s_u8, o_u8
+        # the reference's timed region as a FOLDER run (WCT.py:112-131 + data_loader.py:46-59): 8 x 4K JPEG contents x 1 style through the CLI's
+        # loop, serial (the reference's structure) and pipelined (decode-ahead pool, async copies, writer pool) -- same engine, same bytes out
+        try:
+            passes["cli_pairs_per_s"] = cli_folder_pass(wct16)
+        except Exception as e:      # Pillow missing, tmp dir not writable ...: a report line, not a failure of the bench
+            passes["cli_pairs_per_s"] = {"error": repr(e)}
         if args.config == "cfg2":
             # BASELINE configs[3]'s frame, 10240x4096, untiled on this ONE GPU (the north_star's target configuration)
             c4 = cu(frame_columns(0, W4, "cfg4"))

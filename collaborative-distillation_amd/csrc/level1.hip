@@ -298,15 +298,128 @@ hipError_t launch_l1_encode(const ConvDesc& e, const float* img, float* out, int
   return hipGetLastError();
 }
 
+// The same layer in EXACT fp32 products (v_mfma_f32_16x16x4_f32, one tap = one K = 4 step over the RGB0 slots).  Why it exists
+// (round 4, tools/experiments/first_conv_ab.py): conv0 folds `255 x - mean` into this layer, so its sums cancel from O(255 |w|) to
+// O(|w| sigma), and a split-f16 operand carries 22-23 bits against fp32's 24 -- the f16x3 form of THIS layer is measurably further
+// from the reference than fp32 (G15 end to end 3.4e-4 against 2.3e-4, G14 2.29e-3 against 1.58e-3), and it feeds every level of
+// both lanes.  The layer is a write stream (256 B/px out, 12 B/px in): 9 x 4 MFMAs of 32 cycles per 16 pixels still fit under the
+// HBM time of the stores, which the generic fp32 kernel (conv3x3.hip, one cout tile per operand read) did not (197 us per 1080p
+// launch against 128 us for the f16x3 form).  LDS: four fp32 planes R, G, B, 0 of the 36 x 12 window, plane stride 432 = 16 (mod 32)
+// dwords: the 32 lanes of a ds_read_b32 group (16 pixels x 2 planes) hit 32 distinct banks.
+constexpr int IMGF_PLANE = NPI2;          // 432 floats
+static_assert(IMGF_PLANE % 32 == 16, "plane stride must be 16 mod 32 dwords (conflict-free operand reads)");
+
+__global__ __launch_bounds__(256, 2) void in3_wide_f32_kernel(In3WideArgs a) {
+  __shared__ float imgF[4 * IMGF_PLANE + 4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, kq = lane >> 4;
+  const int ntiles = a.tiles_x * a.tiles_y;
+  const unsigned txm = tile_div_magic(a.tiles_x);
+  for (int e = tid; e < IMGF_PLANE + 4; e += 256) imgF[3 * IMGF_PLANE + e] = 0.f;   // the "0" slot of RGB0 (zero weights, finite data)
+  float wa[4][9];
+  f32x4 bias[4];
+  const float* wf = reinterpret_cast<const float*>(a.w);     // [tap][k = 4][64] fp32 (wct_api.hip pack_weights, in3)
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wa[ct][t] = wf[(t * 4 + kq) * 64 + ct * 16 + li];
+    bias[ct] = *reinterpret_cast<const f32x4*>(a.b + ct * 16 + 4 * kq);
+  }
+  int soff[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    int e = tid + 256 * k;
+    e = e < NPI2 ? e : NPI2 - 1;
+    soff[k] = (e / I2W) * a.W + e % I2W;
+  }
+  auto commit = [&](const float (&r)[2][3]) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int e = tid + 256 * k;
+      if (e < NPI2) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) imgF[c * IMGF_PLANE + e] = r[k][c];
+      }
+    }
+  };
+  float pxr[2][3];
+  SatTrack sat;
+  const size_t plane = sp16_plane_bytes(a.H, a.W);
+  int v = blockIdx.x;
+  if (v < ntiles) {
+    head_fetch(a.img, a.H, a.W, a.tiles_x, txm, pxr, soff, xcd_swizzle(v, ntiles), tid);
+    commit(pxr);
+  }
+  settle_preloop_loads();
+  const float* plane_k = imgF + kq * IMGF_PLANE;
+  for (; v < ntiles; v += gridDim.x) {
+    const int tile = xcd_swizzle(v, ntiles);
+    int trow_, tcol_;
+    tile_rc(tile, a.tiles_x, txm, trow_, tcol_);
+    const int ty0 = trow_ * 8, tx0 = tcol_ * FTW;
+    __syncthreads();
+    const int vn = v + gridDim.x;
+    if (vn < ntiles) head_fetch(a.img, a.H, a.W, a.tiles_x, txm, pxr, soff, xcd_swizzle(vn, ntiles), tid);
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int py = wave * 2 + r, px = h * 16 + li;
+        const int base = (py + 1) * I2W + px + 1;   // top-left of the 3x3 window in the 36 x 12 tile (origin -2, -2)
+        const int gy = ty0 + py, gx = tx0 + px;
+        f32x4 acc[4];
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+        float b[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) b[t] = plane_k[base + (t / 3) * I2W + t % 3];
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+          for (int ct = 0; ct < 4; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[ct][t], b[t], acc[ct], 0, 0, 0);
+        const bool ok = gy < a.H && gx < a.W;
+        const size_t pix = (size_t)gy * a.W + gx;
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+          f32x4 x = acc[ct] + bias[ct];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) x[e] = fmaxf(x[e], 0.f);
+          if (a.out_sp) {
+            u32x2 hi, lo;
+            split4(x, hi, lo, sat, true);
+            if (ok) {
+              char* g = reinterpret_cast<char*>(a.out) + ct * plane + pix * 64 + (kq >> 1) * 32 + (kq & 1) * 8;
+              *reinterpret_cast<u32x2*>(g) = hi;
+              *reinterpret_cast<u32x2*>(g + 16) = lo;
+            }
+          } else if (ok) {
+            *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.out) + pix * 64 + ct * 16 + 4 * kq) = x;
+          }
+        }
+      }
+    __syncthreads();
+    if (vn < ntiles) { head_pin(pxr); commit(pxr); }
+  }
+  sat.commit(a.sat);
+}
+
 bool in3_wide_capable(const ConvDesc& enc0) {
   return (enc0.flags & CONV_IN_NCHW3) && !(enc0.flags & (CONV_POOL_OUT | CONV_NO_RELU)) && enc0.l1w16 && enc0.cout == 64 && enc0.cout_pad == 64;
 }
 
-hipError_t launch_in3_wide(const ConvDesc& e, const float* img, void* out, int H, int W, bool out_sp, hipStream_t s) {
+hipError_t launch_in3_wide(const ConvDesc& e, const float* img, void* out, int H, int W, bool out_sp, bool exact_fp32, hipStream_t s) {
   if (!in3_wide_capable(e) || H < 2 || W < 2) return hipErrorInvalidValue;
   In3WideArgs a;
   a.img = img; a.out = out;
   a.w = reinterpret_cast<const u32x4*>(e.l1w16); a.b = e.l1bias; a.inv = e.l1inv;
+  if (exact_fp32) {
+    a.w = reinterpret_cast<const u32x4*>(e.wpk); a.b = e.bias; a.inv = 1.f;
+    a.H = H; a.W = W; a.tiles_x = (W + FTW - 1) / FTW; a.tiles_y = (H + 7) / 8; a.out_sp = out_sp ? 1 : 0;
+    a.sat = e.sat;
+    const int nt = a.tiles_x * a.tiles_y, g = nt < 2 * num_cus() ? nt : 2 * num_cus();
+    hipLaunchKernelGGL(in3_wide_f32_kernel, dim3(g), dim3(256), 0, s, a);
+    return hipGetLastError();
+  }
   a.H = H; a.W = W; a.tiles_x = (W + FTW - 1) / FTW; a.tiles_y = (H + 7) / 8; a.out_sp = out_sp ? 1 : 0;
   a.sat = e.sat;
   const size_t lds = (size_t)2 * IMG_E * 8;

@@ -98,7 +98,8 @@ struct wct_ctx {
   int u8fuse = 1;     // 1: wct_stylize_u8 reads / writes uint8 inside the first / last kernel where one exists (reserved)
   int fastfold = 1;   // 1: (W Ss) Wc fold without T = Ss Wc / M / b on the content side's critical path where the decoder allows (cin <= 128)
   int upconv = 1;     // 1: decoder layers behind an upsample run as per-parity 2x2 convolutions of the low-resolution map (4/9 of the products)
-  int in3wide = 1;    // 1: the 3 -> 64 first conv of the un-pruned encoders in f16x3 (level1.hip in3_wide_kernel); 0: exact-fp32 MFMA (debug key "in3wide")
+  int in3wide = 2;    // the 3 -> 64 first conv of the un-pruned encoders: 2 = exact-fp32 MFMA, four cout tiles per operand read (level1.hip in3_wide_f32_kernel);
+                      // 1 = f16x3 (in3_wide_kernel: measurably further from the reference at K = 27, see there); 0 = the generic fp32 kernel (debug key "in3wide")
   int fuse = 1;       // 1: fused conv11+conv12+pool / conv12+conv11 kernels at the full-resolution ends of the 16x networks
   int overlap = 1;    // 1: style side on the side lane (overlaps the content side); 0: everything on the caller's stream
   int conv_mode = 1;  // 0: exact-fp32 MFMA everywhere; 1: split-f16 (f16x3) MFMA for all but the first conv
@@ -550,10 +551,10 @@ int encode_impl(wct_ctx* ctx, Lane& ln, int level, const float* img, int H, int 
     if (cur_sp) d.flags |= CONV_IN_SP16;
     if (out_sp) d.flags |= CONV_OUT_SP16;
     if (i == 0 && ctx->conv_mode == 1 && ctx->fuse && ctx->in3wide && in3_wide_capable(d)) {
-      // 3 -> 64 first conv of the un-pruned encoders: f16x3 with four cout tiles per operand read instead of exact-fp32 MFMA
+      // 3 -> 64 first conv of the un-pruned encoders: four cout tiles per operand read, exact-fp32 products (default) or f16x3
       const double px = (double)h * w;
-      ProfScope ps(ctx, ln.stream, "conv3x3_f16x3<co=64,in3>", 2.0 * 27.0 * 64 * px, 4.0 * (3 + 64) * px);
-      HIPCHK(ctx, launch_in3_wide(d, cur, dst, h, w, out_sp, ln.stream));
+      ProfScope ps(ctx, ln.stream, ctx->in3wide == 2 ? "conv3x3_fp32<co=64,in3>" : "conv3x3_f16x3<co=64,in3>", 2.0 * 27.0 * 64 * px, 4.0 * (3 + 64) * px);
+      HIPCHK(ctx, launch_in3_wide(d, cur, dst, h, w, out_sp, ctx->in3wide == 2, ln.stream));
       cur = dst;
       cur_sp = out_sp;
       continue;
@@ -1043,7 +1044,7 @@ int wct_debug_set(wct_ctx* ctx, const char* key, double value) {
   else if (!strcmp(key, "interleave")) ctx->interleave = v;
   else if (!strcmp(key, "foldgemm")) ctx->foldgemm = v;
   else if (!strcmp(key, "nscoop")) ctx->nscoop = (int)value;      // 0: multi-launch, 1: single launch, 2: single launch with an injected placement fault
-  else if (!strcmp(key, "in3wide")) ctx->in3wide = v;
+  else if (!strcmp(key, "in3wide")) ctx->in3wide = (int)value;   // 2 / 1 / 0, see wct_ctx
   else if (!strcmp(key, "eig_skip")) {
     // MEASUREMENT ONLY: solves are left out and stale results reused -- wrong pictures by design; refused outside a debug run
     if (!getenv("WCT_DEBUG")) return fail(ctx, WCT_ERR_INVALID, "debug_set: 'eig_skip' produces wrong results by design (timing experiment); set WCT_DEBUG to allow it");

@@ -104,7 +104,7 @@ hipError_t launch_l1_encode(const ConvDesc& enc0, const float* img, float* out, 
 hipError_t launch_l1_decode(const ConvDesc& enc0, const ConvDesc& dec0_folded, const float* img, float* out, int H, int W, hipStream_t s);
 // the 3 -> 64 first conv of the un-pruned encoders in f16x3 (level1.hip in3_wide_kernel): fp32 NHWC or SP16 out
 bool in3_wide_capable(const ConvDesc& enc0);
-hipError_t launch_in3_wide(const ConvDesc& enc0, const float* img, void* out, int H, int W, bool out_sp, hipStream_t s);
+hipError_t launch_in3_wide(const ConvDesc& enc0, const float* img, void* out, int H, int W, bool out_sp, bool exact_fp32, hipStream_t s);
 size_t l1_moments_workspace_bytes();
 hipError_t launch_l1_moments(const ConvDesc& enc0, const float* img, int H, int W, int x0, int x1, double* sum, double* sumsq,
                              void* workspace, size_t workspace_bytes, hipStream_t s);

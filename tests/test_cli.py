@@ -105,3 +105,27 @@ def test_cli_resizes_on_the_device(tmp_path):
     ref = w.stylize_u8(torch.from_numpy(ch), torch.from_numpy(sh)).cpu().numpy()
     assert got.shape == ref.shape == (64, 96, 3)
     assert np.abs(got.astype(np.int32) - ref.astype(np.int32)).mean() < 12
+
+
+@pytest.mark.gpu
+def test_cli_pipeline_is_byte_identical_to_the_serial_loop(tmp_path):
+    """`--pipeline 3` (decode-ahead pool, asynchronous copies, writer pool: the reference's timed region WCT.py:112-131 as a
+    pipeline) writes the SAME BYTES as `--pipeline 0` (the reference's serial loop): 3 contents x 2 styles of different sizes, with
+    --content_size so that the device Resize is in the path, .jpg outputs."""
+    Image = pytest.importorskip("PIL.Image")
+    rng = np.random.default_rng(5)
+    c, s = tmp_path / "content", tmp_path / "style"
+    c.mkdir(); s.mkdir()
+    for n, shape in (("a.png", (96, 128, 3)), ("b.png", (80, 72, 3)), ("c.jpg", (120, 100, 3))):
+        Image.fromarray(rng.integers(0, 256, size=shape, dtype=np.uint8)).save(c / n)
+    for n, shape in (("s1.png", (64, 64, 3)), ("s2.png", (72, 56, 3))):
+        Image.fromarray(rng.integers(0, 256, size=shape, dtype=np.uint8)).save(s / n)
+    outs = {}
+    for tag, depth in (("serial", "0"), ("pipe", "3"), ("pipe1", "1")):
+        o = tmp_path / tag
+        assert cli.main(["--mode", "16x", "--contentPath", str(c), "--stylePath", str(s), "--outf", str(o), "--log_mark", "P",
+                         "--content_size", "64", "--pipeline", depth, "--io_threads", "3"]) == 0
+        outs[tag] = {f: (o / f).read_bytes() for f in sorted(os.listdir(o)) if f.endswith(".jpg")}
+        assert len(outs[tag]) == 6
+        assert "Processed 6 images." in (o / "log_P_16x.txt").read_text()
+    assert outs["pipe"] == outs["serial"] and outs["pipe1"] == outs["serial"]

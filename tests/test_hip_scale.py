@@ -237,8 +237,11 @@ def test_e2e_config3_graph_strict_gate(torch_cuda, oracle, golden, kind):
     ~1 per layer; see its docstring for why He-uniform stacks -- G14 -- are chaotic under the reference's OWN fp32 arithmetic).
     Frames: `noise` = config 3's seeds, `natural` = the reference's UHD sample pair resized to 1920x1080.  On these the oracle (a
     second fp32 implementation of the reference's op sequence) must itself sit within 2.5e-4 of the reference, so the 1e-3 gate is
-    unconditional -- no `1.25 x oracle` clause.  The same frame is also run with the 3->64 first conv in exact-fp32 MFMA (debug
-    key in3wide = 0): the A/B of VERDICT r3 task 1a (K = 27 split products feed every level of both lanes)."""
+    unconditional -- no `1.25 x oracle` clause.  The 3->64 first conv runs in exact-fp32 MFMA by default (in3_wide_f32_kernel); the
+    same frame is also run with it in f16x3 (debug key in3wide = 1) and on the generic fp32 kernel (0): the A/B of VERDICT r3 task
+    1a -- at K = 27, behind conv0's `255 x - mean` fold, split-f16 operands are measurably further from the reference (3.4e-4
+    against 2.3e-4 here, 2.29e-3 against 1.58e-3 on G14), which is why that one write-bound layer went back to fp32 products; the
+    two fp32 forms must agree closely (same products, another summation order)."""
     from tests.conftest import GOLD
     from tests.fixture_compare import cfg3_natural_frames
     from wct_hip import WCT
@@ -256,7 +259,7 @@ def test_e2e_config3_graph_strict_gate(torch_cuda, oracle, golden, kind):
     ro = compare_to_fixture(ref, g)
     wct = WCT(types.SimpleNamespace(mode="original", alpha=1.0), weights=w)
     res = {}
-    for tag, key in (("f16x3", 1), ("in3_fp32", 0)):
+    for tag, key in (("default", 2), ("in3_f16x3", 1), ("in3_fp32_generic", 0)):
         wct.debug_set("in3wide", key)
         wct.saturation_count(reset=True)
         got = wct.stylize(cu(torch, c), cu(torch, s)).cpu().numpy()[0]
@@ -264,15 +267,16 @@ def test_e2e_config3_graph_strict_gate(torch_cuda, oracle, golden, kind):
         assert got.shape == ref.shape == (3, 1072, 1920)
         res[tag] = compare_to_fixture(got, g)
         res[tag]["vs_oracle"] = rel_err(got, ref)
-    wct.debug_set("in3wide", 1)
-    rh = res["f16x3"]
+    wct.debug_set("in3wide", 2)
+    rh = res["default"]
     _report("e2e cfg3 graph, conditioned weights, " + kind, hip_vs_reference=rh["max"], oracle_vs_reference=ro["max"], limit=GATE,
             hip_p9999=rh["lattice_p9999"], oracle_p9999=ro["lattice_p9999"], hip_frac_gt_1e3=rh["lattice_frac_gt_gate"],
-            hip_down16=rh["down16_max"], hip_vs_oracle=rh["vs_oracle"], hip_in3_fp32_vs_reference=res["in3_fp32"]["max"],
-            hip_in3_fp32_p9999=res["in3_fp32"]["lattice_p9999"], oracle_s=round(t1 - t0, 1))
+            hip_down16=rh["down16_max"], hip_vs_oracle=rh["vs_oracle"], in3_f16x3_vs_reference=res["in3_f16x3"]["max"],
+            in3_f16x3_p9999=res["in3_f16x3"]["lattice_p9999"], in3_fp32_generic_vs_reference=res["in3_fp32_generic"]["max"], oracle_s=round(t1 - t0, 1))
     assert ro["max"] <= G15_ORACLE_LIMIT                       # the reference's arithmetic is well-conditioned on this frame
     assert rh["max"] <= GATE                                   # THE GATE, literal
-    assert res["in3_fp32"]["max"] <= GATE
+    assert res["in3_f16x3"]["max"] <= GATE and res["in3_fp32_generic"]["max"] <= GATE
+    assert abs(rh["max"] - res["in3_fp32_generic"]["max"]) <= 0.2 * rh["max"]     # the two exact-fp32 forms of the first conv: same error class
     assert rh["down16_max"] <= GATE / 4 and rh["lattice_p9999"] <= GATE / 2
 
 
