@@ -472,7 +472,7 @@ __global__ void fold_rows_kernel(const float* w, int cout, int cin, double* rows
 //   back end    ns_final_kernel's scaling of ITS four rows of the result
 // Element arithmetic, tile products, k split over the four waves, every summation order: the multi-launch path's -- the result is
 // that path's bit for bit (tools/experiments/ns_coop_probe.hip; tests/test_hip_parity.py).
-// It cannot hang: a participant that waits 0.25 s at a barrier (or finds itself on another XCD) raises the abort flag and everyone
+// It cannot hang: a participant that waits 5 ms at a barrier (or finds itself on another XCD) raises the abort flag and everyone
 // leaves; the gated Jacobi launch behind every solve looks at that flag as well as at `ok` and does the solve.
 constexpr int COOP_NW = 32, COOP_MAXIT = 32;
 struct NsSched { double ca[COOP_MAXIT], cb[COOP_MAXIT]; };
@@ -480,6 +480,7 @@ struct CoopArgs {
   int C; double n; const double* sum; const double* sumsq; double* res; double diag_add, eps_rel;
   NsWs w; int maxit, inverse; double zmax; int* info; int xcd;
   unsigned* coop_next;
+  unsigned* aborts;      // the lane's count of aborted single-launch solves (may be null): raised once per aborted solve
 };
 constexpr int BUF_SC1 = 16;   // buffer cache policy: agent scope (never served from this CU's L1)
 __device__ __forceinline__ unsigned xcc_id() { unsigned v; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v)); return v & 0xf; }
@@ -533,7 +534,16 @@ __device__ __forceinline__ void gemm32_coop(const double* P, const double* Q, in
   __syncthreads();     // red is reused by the next product
 }
 // all of this workgroup's stores have reached L2, then: arrive, wait for the other participants (or for the abort flag)
-__device__ __forceinline__ bool coop_barrier(const NsWs& w, unsigned& target, int* ok_s) {
+// The watchdog: 5 ms of the 100 MHz wall clock (a healthy solve takes ~0.1 ms in all; a participant that cannot be placed because the
+// other lane's persistent workgroups own the XCD waits for one of their jobs, < 1 ms).  Whoever raises the abort flag FIRST counts the
+// solve in the lane's abort counter: the host mirrors it and stops using the single launch on a lane where it keeps failing
+// (wct_api.hip coop_usable) instead of paying the timeout plus the ~2 ms Jacobi net on every solve, silently.
+constexpr long long COOP_TIMEOUT_TICKS = 500000ll;
+__device__ __forceinline__ void coop_abort(const NsWs& w, unsigned bit, unsigned* aborts) {
+  const unsigned old = __hip_atomic_fetch_or(&w.coop[1], bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (old == 0u && aborts) __hip_atomic_fetch_add(aborts, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bool coop_barrier(const NsWs& w, unsigned& target, int* ok_s, unsigned* aborts) {
   __builtin_amdgcn_s_waitcnt(0);
   __syncthreads();
   target += COOP_NW;
@@ -542,8 +552,8 @@ __device__ __forceinline__ bool coop_barrier(const NsWs& w, unsigned& target, in
     const long long t0 = wall_clock64();     // 100 MHz
     bool ok = true;
     while (__hip_atomic_load(&w.coop[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-      if (wall_clock64() - t0 > 25000000ll || __hip_atomic_load(&w.coop[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-        __hip_atomic_fetch_or(&w.coop[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (wall_clock64() - t0 > COOP_TIMEOUT_TICKS || __hip_atomic_load(&w.coop[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+        coop_abort(w, 1u, aborts);
         ok = false;
         break;
       }
@@ -637,11 +647,11 @@ __global__ __launch_bounds__(256) void ns_coop128_kernel(CoopArgs a, NsSched sc)
     }
   }
   unsigned target = 0;
-  if (!coop_barrier(w, target, &ok_s)) return;
+  if (!coop_barrier(w, target, &ok_s, a.aborts)) return;
   // all participants on participant 0's XCD: the exchange is coherent across XCDs too (ns_coop_probe -DSPREAD), but 15 % slower
   if (tid == 0 && (__hip_atomic_load(&w.coop[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != xcc_id() + 1u || (inject && me == 7)))
-    __hip_atomic_fetch_or(&w.coop[1], 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (!coop_barrier(w, target, &ok_s)) return;
+    coop_abort(w, 2u, a.aborts);
+  if (!coop_barrier(w, target, &ok_s, a.aborts)) return;
   if (__hip_atomic_load(&w.coop[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
   // ---- iteration
   const int tile = me & 15, zside = me >> 4;         // stage 1: tiles by participants 0..15; stage 2: Y' by 0..15, Z' by 16..31
@@ -670,7 +680,7 @@ __global__ __launch_bounds__(256) void ns_coop128_kernel(CoopArgs a, NsSched sc)
         if (lane == 0) atomicMax(&w.resid[it], (unsigned long long)__double_as_longlong(m));
       }
     }
-    if (!coop_barrier(w, target, &ok_s)) return;
+    if (!coop_barrier(w, target, &ok_s, a.aborts)) return;
     {                   // ns_stage2_wide_kernel
       Acc32 acc;
       gemm32_coop(zside ? w.T : w.Y[cur], zside ? w.Z[cur] : w.T, i0, j0, lane, wave, red, acc);
@@ -689,7 +699,7 @@ __global__ __launch_bounds__(256) void ns_coop128_kernel(CoopArgs a, NsSched sc)
         }
       }
     }
-    if (!coop_barrier(w, target, &ok_s)) return;
+    if (!coop_barrier(w, target, &ok_s, a.aborts)) return;
     nit = it + 1;
   }
   // ---- back end (ns_final_kernel): every participant reaches the same verdict from the same counters
@@ -1189,7 +1199,8 @@ hipError_t launch_fold_gemm(const double* rows, const float* bias, int cout, int
 }
 
 hipError_t launch_eig(int C, double n, const double* sum, const double* sumsq, int inverse, double* res, int* info_dev,
-                      void* ws, size_t ws_bytes, hipStream_t s, double diag_add, bool wide_model, int* ok_defer, int coop_xcd, unsigned* coop_state, int* coop_epoch) {
+                      void* ws, size_t ws_bytes, hipStream_t s, double diag_add, bool wide_model, int* ok_defer, int coop_xcd, unsigned* coop_state, int* coop_epoch,
+                      unsigned* coop_aborts, bool* coop_used_out) {
   if (C < 2 || (C & 1) || C > 512 || n < 2) return hipErrorInvalidValue;  // unbiased covariance needs n >= 2
   if (ws_bytes < eig_workspace_bytes(C)) return hipErrorOutOfMemory;
   const size_t cc = (size_t)C * C;
@@ -1237,6 +1248,7 @@ hipError_t launch_eig(int C, double n, const double* sum, const double* sumsq, i
     const bool splitk128 = sk_env && Cp % 64 == 0;
     const bool coop = !big && Cp == 128 && splitk128 && coop_xcd >= 0 && coop_state && coop_epoch && maxit <= COOP_MAXIT;
     coop_used = coop;
+    if (coop_used_out) *coop_used_out = coop;
     if (coop) { w.coop = coop_state + 4 * (*coop_epoch & 1); ++*coop_epoch; }
     if (big) {
       hipLaunchKernelGGL(ns_init_kernel, dim3(1), dim3(1024), 0, s, res, C, NS_DEFLATE, w, maxit);
@@ -1262,6 +1274,7 @@ hipError_t launch_eig(int C, double n, const double* sum, const double* sumsq, i
       ca.C = C; ca.n = n; ca.sum = sum; ca.sumsq = sumsq; ca.res = res; ca.diag_add = diag_add; ca.eps_rel = 1e-15;
       ca.w = w; ca.maxit = maxit; ca.inverse = inverse; ca.zmax = NS_ZMAX; ca.info = info_dev; ca.xcd = coop_xcd & 23;
       ca.coop_next = coop_state + 4 * (*coop_epoch & 1);     // (the epoch was advanced above: this is the other set)
+      ca.aborts = coop_aborts;
       hipLaunchKernelGGL(ns_coop128_kernel, dim3(8 * COOP_NW), dim3(256), 0, s, ca, sc);
     }
     for (int it = 0; it < (coop ? 0 : maxit); ++it) {

@@ -68,6 +68,9 @@ struct Lane {
   int xcd = 0;   // where this lane's single-launch Newton-Schulz iterations run (launch_eig coop_xcd): one XCD per lane, process-wide round robin
   unsigned* coop = nullptr;   // ... their two sets of barrier state (64 bytes, zeroed at creation) ...
   int coop_epoch = 0;         // ... and which set the next one counts in
+  // health of the single-launch solves on this lane, from the mirrored abort counter (coop_usable)
+  unsigned coop_solves = 0;   // single-launch solves enqueued
+  bool coop_off = false;      // they kept aborting here (rocprof serialising the dispatches, a partitioned device, the other lane owning the XCD): multi-launch from now on
 };
 
 struct wct_ctx {
@@ -110,7 +113,8 @@ struct wct_ctx {
   int* ok_host = nullptr;        // pinned [64]: outcomes [0, OK_SLOTS), the saturation counter read with them at [OK_SLOTS]
   int ok_n = 0;
   bool defer_big = false;
-  unsigned sat_mark = 0;         // the saturation counter at the end of the last VERIFIED wide-model call (see with_deferred_solves)
+  // sat_dev is a 256-byte block of counters (unsigned): [0] the saturation counter; [1] its snapshot at the start of a deferred
+  // wide-model call (with_deferred_solves); [2], [3] single-launch Newton-Schulz solves that ABORTED on the main / side lane
   unsigned* sat_host = nullptr;  // pinned host mirror, refreshed asynchronously at the end of every compute entry point (wct_range_poll)
   // profiling
   bool prof = false;
@@ -156,7 +160,8 @@ struct DevGuard {
 // the saturation counter follows every compute entry point to pinned host memory on the caller's stream (4 bytes, no sync):
 // wct_range_poll then reports a clamp of any COMPLETED call without stalling the pipeline
 int range_readback(wct_ctx* ctx) {
-  if (ctx->sat_host) HIPCHK(ctx, hipMemcpyAsync(ctx->sat_host, ctx->sat_dev, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->main.stream));
+  // 16 bytes: the saturation counter, its snapshot, and the two lanes' aborted single-launch solves (coop_health reads those)
+  if (ctx->sat_host) HIPCHK(ctx, hipMemcpyAsync(ctx->sat_host, ctx->sat_dev, 4 * sizeof(unsigned), hipMemcpyDeviceToHost, ctx->main.stream));
   return WCT_OK;
 }
 
@@ -639,6 +644,17 @@ int moments_impl(wct_ctx* ctx, Lane& ln, const float* feat, int C, int h, int w,
   return WCT_OK;
 }
 
+// May this lane still use the single-launch C = 128 solve?  An aborted solve is correct (the Jacobi net behind every solve repairs it) but costs
+// the watchdog's 5 ms plus ~2 ms, silently; the device counts aborts per lane (sat_dev[2 + lane], solve.hip coop_abort), every compute entry
+// point mirrors the count to pinned host memory without synchronising, and a lane on which at least three solves and at least a quarter of
+// all of them have aborted goes back to the multi-launch schedule for good.  Readable through wct_debug_get ("nscoop_aborts", "nscoop_off").
+bool coop_usable(wct_ctx* ctx, Lane& ln) {
+  if (ln.coop_off) return false;
+  const unsigned seen = ctx->sat_host ? reinterpret_cast<volatile unsigned*>(ctx->sat_host)[2 + (&ln == &ctx->side ? 1 : 0)] : 0u;
+  if (seen >= 3u && 4u * seen >= ln.coop_solves) ln.coop_off = true;
+  return !ln.coop_off;
+}
+
 // (n, sum, sumsq) of one feature map -> EigResult in `res` (covariance, Jacobi eigen-decomposition)
 int eig_impl(wct_ctx* ctx, Lane& ln, int C, double n, const double* sum, const double* sumsq, int inverse, DevBuf& res, int* info_dev) {
   if (C < 2 || (C & 1) || C > 512) return fail(ctx, WCT_ERR_INVALID, "solve: C=%d must be even and <= 512", C);
@@ -652,8 +668,12 @@ int eig_impl(wct_ctx* ctx, Lane& ln, int C, double n, const double* sum, const d
   ProfScope ps(ctx, ln.stream, inverse ? "matfun_invsqrt" : "matfun_sqrt", 0, 0);
   int* defer = nullptr;
   if (ctx->defer_big && eig_is_big(C, ctx->wide_model) && ctx->ok_n < OK_SLOTS) defer = ctx->ok_log + ctx->ok_n++;
+  const bool coop_ok = ctx->nscoop && coop_usable(ctx, ln);
+  bool coop_used = false;
   HIPCHK(ctx, launch_eig(C, n, sum, sumsq, inverse, reinterpret_cast<double*>(res.p), info_dev, ln.wsEig.p, ln.wsEig.cap, ln.stream,
-                         (inverse && ctx->numpy_variant) ? 1.0 : 0.0, ctx->wide_model, defer, ctx->nscoop ? (ln.xcd | (ctx->nscoop == 2 ? 16 : 0)) : -1, ln.coop, &ln.coop_epoch));
+                         (inverse && ctx->numpy_variant) ? 1.0 : 0.0, ctx->wide_model, defer, coop_ok ? (ln.xcd | (ctx->nscoop == 2 ? 16 : 0)) : -1, ln.coop, &ln.coop_epoch,
+                         ctx->sat_dev + 2 + (&ln == &ctx->side ? 1 : 0), &coop_used));
+  if (coop_used) ++ln.coop_solves;
   return WCT_OK;
 }
 
@@ -666,6 +686,10 @@ int with_deferred_solves(wct_ctx* ctx, bool wait_side, BODY&& body) {
   if (!ctx->wide_model) return body();
   ctx->defer_big = true;
   ctx->ok_n = 0;
+  // the counter as of NOW, in stream order (everything enqueued before this call -- wct_encode / wct_decode / ... included -- has
+  // counted by then): what a failed optimistic pass is rolled back to.  (It used to be rolled back to a host-side mark taken at the
+  // last verified wide-model call, which erased clamps raised since by the non-deferred entry points: ADVICE r3.)
+  HIPCHK(ctx, hipMemcpyAsync(ctx->sat_dev + 1, ctx->sat_dev, sizeof(unsigned), hipMemcpyDeviceToDevice, ctx->main.stream));
   int rc = body();
   ctx->defer_big = false;
   const int n = ctx->ok_n;
@@ -678,12 +702,14 @@ int with_deferred_solves(wct_ctx* ctx, bool wait_side, BODY&& body) {
   HIPCHK(ctx, hipStreamSynchronize(ctx->main.stream));
   bool all = true;
   for (int i = 0; i < n; ++i) all = all && ctx->ok_host[i] == 1;
-  if (all) { ctx->sat_mark = static_cast<unsigned>(ctx->ok_host[OK_SLOTS]); return WCT_OK; }
+  if (all) return WCT_OK;
   // the optimistic pass ran its decoders on unconverged matrix functions: whatever it clamped says nothing about the real result --
-  // put the saturation counter back to where the last verified call left it before repeating the call
+  // put the saturation counter back to where it stood when this call began before repeating the call
   HIPCHK(ctx, hipStreamSynchronize(ctx->side.stream));
-  HIPCHK(ctx, hipMemcpy(ctx->sat_dev, &ctx->sat_mark, sizeof(unsigned), hipMemcpyHostToDevice));
-  if (ctx->sat_host) *ctx->sat_host = ctx->sat_mark;
+  unsigned before = 0;
+  HIPCHK(ctx, hipMemcpy(&before, ctx->sat_dev + 1, sizeof(unsigned), hipMemcpyDeviceToHost));
+  HIPCHK(ctx, hipMemcpy(ctx->sat_dev, &before, sizeof(unsigned), hipMemcpyHostToDevice));
+  if (ctx->sat_host) *ctx->sat_host = before;
   return body();     // defer_big is off: every solve checks (and repairs) itself
 }
 
@@ -995,7 +1021,6 @@ int wct_sync(wct_ctx* ctx) {
     // reported ONCE and cleared: a later WCT_ERR_RANGE then means a later clamp, not a stale flag (the total stays readable
     // through wct_saturation_count until this point only)
     HIPCHK(ctx, hipMemset(ctx->sat_dev, 0, sizeof n));
-    ctx->sat_mark = 0;
     if (ctx->sat_host) *ctx->sat_host = 0u;
     return fail(ctx, WCT_ERR_RANGE, "%u thread(s) clamped an activation to the f16x3 range (|x| > 65504, or NaN) since the last report: results "
                 "deviate from the fp32 reference; use conv mode 0 (exact fp32) for these weights / inputs.  The flag is now cleared", n);
@@ -1011,7 +1036,6 @@ int wct_saturation_count(wct_ctx* ctx, int reset, unsigned long long* count) {
   unsigned n = 0;
   HIPCHK(ctx, hipMemcpy(&n, ctx->sat_dev, sizeof n, hipMemcpyDeviceToHost));
   if (reset && n) HIPCHK(ctx, hipMemset(ctx->sat_dev, 0, sizeof n));
-  if (reset) ctx->sat_mark = 0;
   if (ctx->sat_host) *ctx->sat_host = reset ? 0u : n;
   if (count) *count = n;
   return WCT_OK;
@@ -1065,6 +1089,23 @@ int wct_debug_set(wct_ctx* ctx, const char* key, double value) {
   else return fail(ctx, WCT_ERR_INVALID, "debug_set: unknown key '%s' (fuse, sp, l1fuse, u8fuse, upconv, fastfold, interleave, foldgemm, nscoop, in3wide, eig_skip, side_priority)", key);
   HIPCHK(ctx, hipStreamSynchronize(ctx->side.stream));
   return WCT_OK;
+}
+
+int wct_debug_get(wct_ctx* ctx, const char* key, double* value) {
+  if (!ctx || !key || !value) return WCT_ERR_INVALID;
+  WCT_GUARD(ctx);
+  if (!strcmp(key, "nscoop_aborts") || !strcmp(key, "nscoop_solves") || !strcmp(key, "nscoop_off")) {
+    if (!strcmp(key, "nscoop_solves")) { *value = (double)ctx->main.coop_solves + (double)ctx->side.coop_solves; return WCT_OK; }
+    if (!strcmp(key, "nscoop_off")) { (void)coop_usable(ctx, ctx->main); (void)coop_usable(ctx, ctx->side); *value = (ctx->main.coop_off ? 1 : 0) + (ctx->side.coop_off ? 2 : 0); return WCT_OK; }
+    HIPCHK(ctx, hipStreamSynchronize(ctx->side.stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->main.stream));
+    unsigned n[2] = {0u, 0u};
+    HIPCHK(ctx, hipMemcpy(n, ctx->sat_dev + 2, sizeof n, hipMemcpyDeviceToHost));
+    if (ctx->sat_host) { reinterpret_cast<volatile unsigned*>(ctx->sat_host)[2] = n[0]; reinterpret_cast<volatile unsigned*>(ctx->sat_host)[3] = n[1]; }
+    *value = (double)n[0] + (double)n[1];
+    return WCT_OK;
+  }
+  return fail(ctx, WCT_ERR_INVALID, "debug_get: unknown key '%s' (nscoop_aborts, nscoop_solves, nscoop_off)", key);
 }
 
 int wct_load_module(wct_ctx* ctx, int kind, int level, int n_layers, const wct_layer* layers, const float* c0w,

@@ -153,7 +153,7 @@ size_t assemble_workspace_bytes(int C);
 bool eig_is_big(int C, bool wide_model);
 hipError_t launch_eig(int C, double n, const double* sum, const double* sumsq, int inverse, double* res, int* info_dev,
                       void* workspace, size_t workspace_bytes, hipStream_t s, double diag_add = 0.0, bool wide_model = false,
-                      int* ok_defer = nullptr, int coop_xcd = -1, unsigned* coop_state = nullptr, int* coop_epoch = nullptr);
+                      int* ok_defer = nullptr, int coop_xcd = -1, unsigned* coop_state = nullptr, int* coop_epoch = nullptr, unsigned* coop_aborts = nullptr, bool* coop_used_out = nullptr);
 //   coop_xcd (0..7, or -1: off) + coop_state (32 device bytes of the calling lane, zero at first use) + coop_epoch (the lane's
 //   HOST counter of such solves, advanced here): the 128-channel levels of --mode 16x as ONE launch on that XCD (solve.hip
 //   ns_coop128_kernel); lanes that may solve at the same time are given different XCDs

@@ -18,7 +18,7 @@ LAYOUT_NHWC, LAYOUT_NCHW = 0, 1
 
 # every symbol include/wct_hip.h declares (tests check that the built library exports all of them)
 SYMBOLS = [
-    "wct_version", "wct_create", "wct_destroy", "wct_last_error", "wct_set_stream", "wct_sync", "wct_saturation_count", "wct_range_poll", "wct_range_flag_f64", "wct_debug_set",
+    "wct_version", "wct_create", "wct_destroy", "wct_last_error", "wct_set_stream", "wct_sync", "wct_saturation_count", "wct_range_poll", "wct_range_flag_f64", "wct_debug_set", "wct_debug_get",
     "wct_load_module", "wct_feature_shape", "wct_encode", "wct_decode", "wct_moments", "wct_solve",
     "wct_apply", "wct_transform", "wct_decode_affine", "wct_style_transfer_level", "wct_stylize",
     "wct_style_prepare", "wct_content_encode", "wct_content_solve", "wct_content_decode",
@@ -73,6 +73,7 @@ def load() -> ctypes.CDLL:
     lib.wct_saturation_count.argtypes = [c_void_p, c_int, POINTER(ctypes.c_ulonglong)]
     lib.wct_range_poll.argtypes = [c_void_p, POINTER(ctypes.c_ulonglong)]
     lib.wct_range_flag_f64.argtypes = [c_void_p, vp]
+    lib.wct_debug_get.argtypes = [c_void_p, c_char_p, POINTER(ctypes.c_double)]
     lib.wct_debug_set.argtypes = [c_void_p, c_char_p, c_double]
     lib.wct_load_module.argtypes = [c_void_p, c_int, c_int, c_int, POINTER(WctLayer), fp, fp]
     lib.wct_feature_shape.argtypes = [c_void_p, c_int, c_int, c_int, ip, ip, ip]

@@ -92,6 +92,8 @@ class ShardedStylizer:
             raise ValueError("halo_mode='exchange' needs strips of at least %d columns (narrowest: %d)" % (2 * LEVEL_HALO[4], narrowest))
         self.halo_mode = halo_mode
         self.halo = LEVEL_HALO if halo_mode == "exchange" else CUM_HALO
+        if broadcast_map and isinstance(dist, LoopbackGroup):
+            raise ValueError("LoopbackGroup emulates the style-statistics broadcasts only: broadcast_map=True is not supported by it")
         self._range = []            # [(pinned host value, event)], oldest first: node-wide f16x3 clamp totals of past stylize_strip calls
 
     def input_columns(self) -> Tuple[int, int]:
@@ -206,6 +208,8 @@ class ShardedStylizer:
         e.style_prepare(style, levels=[lvl for lvl in (5, 4, 3, 2, 1) if owner(lvl) == rank])
         for L in (5, 4, 3, 2, 1):
             sh = L - 1
+            if hasattr(dist, "set_level"):
+                dist.set_level(L)             # measurement stand-ins (LoopbackGroup) key their emulated peers' data on the level
             # crop the running image to this level's extended strip
             nlo, nhi = ext_bounds(own, W_cur, halo[L])
             assert lo <= nlo and nhi <= hi, (L, lo, hi, nlo, nhi)
@@ -283,6 +287,10 @@ class LoopbackGroup:
         self.rank, self.world, self.real = rank, world, real
         self.style_stats = {}
         self._bcast = 0
+        self._level = None      # set by ShardedStylizer before every level's collectives (set_level)
+
+    def set_level(self, level: int):
+        self._level = level
 
     def get_rank(self):
         return self.rank
@@ -298,13 +306,18 @@ class LoopbackGroup:
             self.real.all_reduce(t)
 
     def broadcast(self, t, src=0):
-        level = 5 - (self._bcast % 5)       # stylize_strip broadcasts the style statistics of levels 5..1 in turn
+        # the level comes from ShardedStylizer (set_level), not from counting calls: a skipped level or an extra broadcast per
+        # level (broadcast_map) would shift a count and copy statistics of the wrong level and size
+        level = self._level
         self._bcast += 1
         if src == self.rank:
             if self.real is not None:
                 self.real.broadcast(t, src=0)
         else:
-            t.copy_(self.style_stats[level])
+            stats = self.style_stats[level]
+            if stats.numel() != t.numel():
+                raise RuntimeError("LoopbackGroup: level %d statistics hold %d values, the receive buffer %d" % (level, stats.numel(), t.numel()))
+            t.copy_(stats)
 
     def barrier(self):
         return None

@@ -536,6 +536,12 @@ class WCT:
         """Experiment switches of the context ("fuse", "sp", "l1fuse", "u8fuse", "upconv"): kernel formulations of the same operators."""
         self._chk(self._lib.wct_debug_set(self._ctx, key.encode(), float(value)))
 
+    def debug_get(self, key: str) -> float:
+        """Health counters of the context: "nscoop_solves", "nscoop_aborts", "nscoop_off" (include/wct_hip.h wct_debug_get)."""
+        v = ctypes.c_double()
+        self._chk(self._lib.wct_debug_get(self._ctx, key.encode(), byref(v)))
+        return float(v.value)
+
     def set_overlap(self, on: bool):
         self._chk(self._lib.wct_set_overlap(self._ctx, int(on)))
 

@@ -104,6 +104,11 @@ int wct_range_flag_f64(wct_ctx* ctx, double* flag_dev);
  * functions are SKIPPED and stale results reused) is a timing experiment that produces wrong pictures by design: it is refused
  * unless the environment variable WCT_DEBUG is set.  Environment variables WCT_* are honoured only when WCT_DEBUG is set. */
 int wct_debug_set(wct_ctx* ctx, const char* key, double value);
+/* Health counters of the context (no reference counterpart): "nscoop_solves" = single-launch C = 128 matrix-function solves enqueued,
+ * "nscoop_aborts" = those that aborted into the Jacobi net (watchdog / placement; synchronises the context), "nscoop_off" = bit mask
+ * of lanes (1 main, 2 side) that went back to the multi-launch schedule because at least three and at least a quarter of their
+ * single-launch solves aborted.  An aborted solve is repaired (same results) but costs ~7 ms: this is how that shows. */
+int wct_debug_get(wct_ctx* ctx, const char* key, double* value);
 
 /* replaces SmallEncoder{L}_16x_aux(path) / SmallDecoder{L}_16x(path) / Encoder{L} / Decoder{L} construction
  * (util_wct.py:36-55; model_cd.py:712-718).  conv0_w [3*3] / conv0_b [3] (HOST): the encoder's 1x1 colour

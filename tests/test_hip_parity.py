@@ -152,7 +152,8 @@ def test_single_launch_newton_schulz_is_the_multi_launch_one(torch_cuda, weights
     barrier, iterates through that XCD's L2) against the 2 x 16 stage launches (debug key "nscoop" 0): the same tile products in
     the same order -> (M, b) and the iteration counts bit for bit, for a well-conditioned and an ill-conditioned pair, alone and
     while the other lane keeps the GPU busy (a whole overlapped cascade, bitwise).  And its safety net: with a participant
-    reported on the wrong XCD ("nscoop" 2) everyone leaves, the outcome says "not converged" and the gated Jacobi launch solves."""
+    reported on the wrong XCD ("nscoop" 2) everyone leaves, the outcome says "not converged" and the gated Jacobi launch solves -- and
+    the aborts are counted, and stop the lane from trying again once they are the rule."""
     from wct_hip import WCT
     torch = torch_cuda
     C = 128
@@ -178,6 +179,15 @@ def test_single_launch_newton_schulz_is_the_multi_launch_one(torch_cuda, weights
             out.append((M.clone(), b.clone(), info))
         out.append(w.stylize(c, s).clone())
         res[mode] = out
+        # health counters (wct_debug_get): an aborted single-launch solve is repaired by the Jacobi net but costs the watchdog + ~2 ms, so it
+        # is counted per lane, and a lane on which the single launch keeps failing goes back to the multi-launch schedule
+        aborts, off, solves = w.debug_get("nscoop_aborts"), int(w.debug_get("nscoop_off")), w.debug_get("nscoop_solves")
+        if mode == 1:
+            assert aborts == 0 and off == 0 and solves >= 8, (aborts, off, solves)
+        elif mode == 0:
+            assert aborts == 0 and solves == 0
+        else:
+            assert aborts >= 4 and (off & 1), (aborts, off, solves)      # every solve of the injected-fault run aborted: the main lane gave up
     # channel counts that are padded to the kernel's 128 (identity block in the padding), with dead channels among the live ones
     for Cq, dead in ((98, 0), (126, 5), (112, 17)):
         live = Cq - dead
