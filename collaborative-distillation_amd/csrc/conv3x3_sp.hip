@@ -301,6 +301,200 @@ __global__ __launch_bounds__(512) void conv3x3_sp_kernel(SpArgs a) {
 }
 
 // =====================================================================================================================
+// The HBM-side layers (32 couts, 16 or 32 input channels: conv21 / conv22 of the encoders, conv22 of the decoders) with THREE
+// activation stages and resident weights (round 4).  In the kernel above a job's DMA is issued during the previous job, i.e. one tile
+// (16 cin) or half a tile (32 cin) ahead: at 1728 matrix-core cycles per wave and job a CU then spends most of a job waiting at
+// vmcnt(0) -- for the next stage, and for the previous tile's stores, which gfx9 counts in the same in-order counter -- with one
+// stage of loads in flight: 3.6-3.8 TB/s algorithmic on the 1080 x 1920 maps, 0.6 of what a copy reaches.  Here
+//   * the weights of ALL chunks (<= 2 x 18 KB) are loaded once per workgroup and stay in LDS,
+//   * job j issues the DMA of job j + 2 into the third stage, on its LAST taps, and the parked epilogue of the previous tile on its
+//     FIRST taps, so that at the top of job j + 1 `s_waitcnt vmcnt(5)` (the wave's five newest vector-memory operations = the DMA
+//     of job j + 2, issued unconditionally) waits for job j + 1's stage and for the stores, while a whole stage stays in flight.
+// Same tiles, same MFMA order, same epilogue as the kernel above: results are bit-identical (tests/test_hip_parity.py).
+// LDS (16-B units): 3 x act[640 x 4] + wgt[chunks][36 x 32] + bias = 141 KB (16 cin) / 159 KB (32 cin).
+template <bool POOL, bool OUTF32>
+__global__ __launch_bounds__(512) void conv3x3_sp3_kernel(SpArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int COW = 32, NWV = 8, CPW = 1, NST = 3;
+  constexpr int ACT16 = 4 * SP_NPP;                    // one activation stage
+  constexpr int WCH16 = 36 * COW;                      // one chunk's weights
+  constexpr int W_DMA = WCH16 / 64;                    // 18 wave-instructions per chunk
+  constexpr int SP_ACT_PER_WAVE = (SP_ACT_DMA + NWV - 1) / NWV;   // 5
+  u32x4* lds = reinterpret_cast<u32x4*>(smem);
+  u32x4* wgt_all = lds + NST * ACT16;
+  float* biasL = reinterpret_cast<float*>(wgt_all + a.cin_chunks * WCH16);
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, kh = lane >> 5;
+  const int rw = wave;
+  const int ntiles = a.tiles_x * a.tiles_y;
+  for (int e = tid; e < a.cout_pad; e += NWV * 64) biasL[e] = a.bias[e];
+  const float inv = a.inv_scale_ptr ? *a.inv_scale_ptr : a.inv_scale;
+  const size_t in_plane = sp16_plane_bytes(a.inH, a.inW);
+  unsigned long long satmask = 0ull;
+  const float lob = a.relu ? 0.f : -65504.f;
+
+  size_t poff[SP_ACT_PER_WAVE];
+  auto tile_offsets = [&](int tile) {
+    const int ty0 = (tile / a.tiles_x) * SPH, tx0 = (tile % a.tiles_x) * FTW;
+#pragma unroll
+    for (int i = 0; i < SP_ACT_PER_WAVE; ++i) {
+      int idx = wave + NWV * i;
+      idx = idx < SP_ACT_DMA ? idx : SP_ACT_DMA - 1;
+      const int slot_pix = idx * 16 + (lane >> 2);
+      const int q = (lane & 3) ^ ((slot_pix >> 2) & 3);
+      const int pix = slot_pix < SP_NPH ? slot_pix : SP_NPH - 1;
+      const int py = pix / FHW, px = pix - py * FHW;
+      int gy = reflect_clamp(ty0 - 1 + py, a.H), gx = reflect_clamp(tx0 - 1 + px, a.W);
+      if (a.up_in) { gy >>= 1; gx >>= 1; }
+      poff[i] = ((size_t)gy * a.inW + gx) * 64 + q * 16;
+    }
+  };
+  auto issue_act = [&](int i, int ch, int stage) {
+    int idx = wave + NWV * i;
+    idx = idx < SP_ACT_DMA ? idx : SP_ACT_DMA - 1;
+    __builtin_amdgcn_global_load_lds(a.in + (size_t)ch * in_plane + poff[i], (lds_ptr)(lds + stage * ACT16 + idx * 64), 16, 0, 0);
+  };
+
+  constexpr int NPIECE = CPW * 4 * (POOL ? 1 : 2), PPT = 4;
+  auto epilogue_piece = [&](const f32x16 (&r)[CPW][2], int piece, int ty0, int tx0) {
+    const int gx = tx0 + li;
+    const int oH = POOL ? a.H >> 1 : a.H, oW = POOL ? a.W >> 1 : a.W;
+    const int q = piece & 3, cp = piece >> 2, p = POOL ? 0 : cp & 1;
+    const int co = 8 * q + 4 * kh;
+    const f32x4 bias = *reinterpret_cast<const f32x4*>(biasL + co);
+    f32x4 x;
+    int oy, ox;
+    bool ok;
+    if constexpr (POOL) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float t = fmaxf(r[0][0][4 * q + k], r[0][1][4 * q + k]);
+        x[k] = fmaxf(t, lane_xor1(t));
+      }
+      x = fma4(x, inv, bias);
+      if (OUTF32 && a.relu) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) x[k] = fmaxf(x[k], 0.f);
+      }
+      oy = (ty0 + rw * 2) >> 1; ox = gx >> 1;
+      ok = !(li & 1) && oy < oH && ox < oW && co < a.cout;
+    } else {
+      x = fma4(f32x4{r[0][p][4 * q], r[0][p][4 * q + 1], r[0][p][4 * q + 2], r[0][p][4 * q + 3]}, inv, bias);
+      if (OUTF32 && a.relu) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) x[k] = fmaxf(x[k], 0.f);
+      }
+      oy = ty0 + rw * 2 + p; ox = gx;
+      ok = oy < oH && ox < oW && co < a.cout;
+    }
+    if constexpr (OUTF32) {
+      if (ok) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.out) + ((size_t)oy * oW + ox) * a.cout + co) = x;
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) satmask |= __ballot(x[k] > 65504.f);
+      if (!a.relu) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) satmask |= __ballot(x[k] < -65504.f);
+      }
+      const u32x4 w = sp16_pair_exchange_lob(x, lob);
+      if (ok) *reinterpret_cast<u32x4*>(a.out + sp16_piece(sp16_plane_bytes(oH, oW), (size_t)oy * oW + ox, co >> 3, kh)) = w;
+    }
+  };
+
+  f32x16 acc[CPW][2], pend[CPW][2];
+  const int xq = ntiles >> 3, xr = ntiles & 7, xcd = blockIdx.x & 7;
+  const int tbase = xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq;
+  const int nunits = xq + (xcd < xr ? 1 : 0), ustep = gridDim.x >> 3;
+  const int nch = a.cin_chunks;
+  int v = blockIdx.x >> 3, ch = 0, stage = 0;
+  if (v >= nunits) return;
+  // job (v, ch) -> its successor; a job exists while v < nunits
+  auto succ = [&](int& jv, int& jc) { if (++jc == nch) { jc = 0; jv += ustep; } };
+  // ---- prologue: weights of every chunk (resident), then the stages of jobs 0 and 1
+  for (int idx = wave; idx < nch * W_DMA; idx += NWV) {
+    const int c = idx / W_DMA, k = idx - c * W_DMA;
+    const u32x4* g = a.wpk + ((size_t)(c * 36 + k * 2 + (lane >> 5)) * a.cout_pad + (lane & 31));
+    __builtin_amdgcn_global_load_lds(g, (lds_ptr)(wgt_all + c * WCH16 + k * 64), 16, 0, 0);
+  }
+  int dma_tile = tbase + v;
+  tile_offsets(dma_tile);
+#pragma unroll
+  for (int i = 0; i < SP_ACT_PER_WAVE; ++i) issue_act(i, 0, 0);
+  int v1 = v, c1 = 0;                       // job + 1
+  succ(v1, c1);
+  bool have1 = v1 < nunits;
+  if (have1) {
+    if (tbase + v1 != dma_tile) { dma_tile = tbase + v1; tile_offsets(dma_tile); }
+#pragma unroll
+    for (int i = 0; i < SP_ACT_PER_WAVE; ++i) issue_act(i, c1, 1);
+  }
+  int pty0 = 0, ptx0 = 0;
+  bool have_pend = false;
+  const unsigned txm = tile_div_magic(a.tiles_x);
+  while (true) {
+    // the stage of THIS job has landed once at most the DMA of the job after it (the wave's newest five operations) is outstanding
+    if (have1) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    int v2 = v1, c2 = c1;                   // job + 2: its DMA goes into the stage the previous job has just released
+    bool have2 = false;
+    if (have1) { succ(v2, c2); have2 = v2 < nunits; }
+    if (have2 && tbase + v2 != dma_tile) { dma_tile = tbase + v2; tile_offsets(dma_tile); }
+    const int stage2 = stage == 0 ? 2 : stage - 1;        // (stage + 2) % 3
+    if (ch == 0) {
+#pragma unroll
+      for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][p][r] = 0.f;
+    }
+    const u32x4* act = lds + stage * ACT16;
+    const u32x4* wgt = wgt_all + ch * WCH16;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int dy = tap / 3, dx = tap - dy * 3;
+      f16x8 bh[2], bl[2];
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        const int pix = (rw * 2 + p + dy) * FHW + li + dx;
+        bh[p] = __builtin_bit_cast(f16x8, act[sp_slot(pix, 2 * kh)]);
+        bl[p] = __builtin_bit_cast(f16x8, act[sp_slot(pix, 2 * kh + 1)]);
+      }
+      const f16x8 ah = __builtin_bit_cast(f16x8, wgt[((tap * 2 + 0) * 2 + kh) * COW + li]);
+      const f16x8 al = __builtin_bit_cast(f16x8, wgt[((tap * 2 + 1) * 2 + kh) * COW + li]);
+      // first taps: the parked tile's stores; last taps: the DMA of job + 2 (so that it is the newest thing in the wave's vmcnt queue)
+      if (tap * PPT < NPIECE && have_pend) {
+#pragma unroll
+        for (int k = 0; k < PPT; ++k)
+          if (tap * PPT + k < NPIECE) epilogue_piece(pend, tap * PPT + k, pty0, ptx0);
+      }
+      if (tap >= 9 - SP_ACT_PER_WAVE && have2) issue_act(tap - (9 - SP_ACT_PER_WAVE), c2, stage2);
+#pragma unroll
+      for (int term = 0; term < 3; ++term)
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+          acc[0][p] = __builtin_amdgcn_mfma_f32_32x32x16_f16(term == 2 ? al : ah, term == 1 ? bl[p] : bh[p], acc[0][p], 0, 0, 0);
+    }
+    have_pend = false;
+    if (ch + 1 == nch) {
+#pragma unroll
+      for (int p = 0; p < 2; ++p) pend[0][p] = acc[0][p];
+      int trow_, tcol_;
+      tile_rc(tbase + v, a.tiles_x, txm, trow_, tcol_);
+      pty0 = trow_ * SPH; ptx0 = tcol_ * FTW; have_pend = true;
+    }
+    if (!have1) break;
+    v = v1; ch = c1; v1 = v2; c1 = c2; have1 = have2;
+    stage = stage == 2 ? 0 : stage + 1;
+  }
+  if (have_pend) {
+#pragma unroll
+    for (int k = 0; k < NPIECE; ++k) epilogue_piece(pend, k, pty0, ptx0);
+  }
+  if (satmask != 0ull && lane == 0 && a.sat) sat_raise(a.sat);
+}
+
+// =====================================================================================================================
 // Layers BEHIND a nearest-x2 upsample (CONV_UP_IN), on the low-resolution grid.
 // The 3x3 convolution of the upsampled map is, per output parity (a, b), a 2x2 convolution of the low-resolution map with
 // summed taps (wct_api.hip pack_up_phase_f16): 4 instead of 9 products per output and channel pair.  The kernel above gathered
@@ -497,8 +691,9 @@ bool conv_sp_supported(const ConvDesc& d) {
   // 4: 64 couts, 8: 64 couts + pool, 16: >= 128 couts.  Measured (4K bench, ms per step, DMA vs register-staged on the
   // same SP16 input): 32: 1.29 / 1.30, 32+pool: 0.72 / 0.59, 64: 1.90 / 1.95, 64+pool: 0.33 / 0.33, >=128: 1.31 / 1.70
   // -> default 29: everything but the pooled 32-cout layers (re-measured after the chunk-planar SP16 layout and the
-  // per-XCD work units: 0.565 / 0.565 ms there now -- a tie, left as it was).
-  static const int mask = [] { const char* e = wct_debug_env("WCT_SP_DMA_MASK"); return e ? atoi(e) : 29; }();
+  // per-XCD work units: 0.565 / 0.565 ms there now -- a tie, left as it was).  Round 4: with the three-stage kernel
+  // (conv3x3_sp3_kernel) the pooled 32-cout layers run 0.551 against 0.578 ms there -> default 31, everything.
+  static const int mask = [] { const char* e = wct_debug_env("WCT_SP_DMA_MASK"); return e ? atoi(e) : 31; }();
   const bool pool = d.flags & CONV_POOL_OUT;
   const int fam = d.cout_pad >= 128 ? 16 : d.cout_pad == 64 ? (pool ? 8 : 4) : (pool ? 2 : 1);
   if (!(mask & fam)) return false;
@@ -539,6 +734,13 @@ hipError_t launch_conv3x3_sp(const ConvDesc& d, const void* in, void* out, int H
   }
   const int ct = (d.cout_pad % 64 == 0) ? 2 : 1;
   a.groups = d.cout_pad / (ct * 32);
+  // 32 couts from 16 / 32 input channels: three activation stages, resident weights (conv3x3_sp3_kernel); WCT_SP3=0 keeps the two-stage kernel
+  static const int sp3_env = [] { const char* e = wct_debug_env("WCT_SP3"); return e ? atoi(e) : 1; }();
+  if (sp3_env && d.cout_pad == 32 && d.cin_chunks <= 2) {
+    const size_t lds3 = ((size_t)3 * 4 * SP_NPP + (size_t)d.cin_chunks * 36 * 32) * 16 + (size_t)d.cout_pad * sizeof(float);
+    if (pool) return f32 ? launch_sp(conv3x3_sp3_kernel<true, true>, a, lds3, s, 512) : launch_sp(conv3x3_sp3_kernel<true, false>, a, lds3, s, 512);
+    return f32 ? launch_sp(conv3x3_sp3_kernel<false, true>, a, lds3, s, 512) : launch_sp(conv3x3_sp3_kernel<false, false>, a, lds3, s, 512);
+  }
   const size_t lds = (size_t)2 * (4 * SP_NPP + 36 * ct * 32) * 16 + (size_t)d.cout_pad * sizeof(float);
 #define WCT_SP_CASE(CTV, GV)                                                                                          \
   if (ct == CTV && (a.groups > 1) == GV) {                                                                            \

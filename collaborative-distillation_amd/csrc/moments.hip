@@ -14,6 +14,14 @@
 // in registers and there is no cross-wave reduction.  LDS row stride Cs == 16 (mod 32) dwords makes the
 // operand reads (lane = channel l&15 of pixel l>>4) bank-conflict free.  Partial tiles go to a workspace and a
 // second kernel adds them in a fixed order -> bitwise reproducible, no atomics.
+//
+// F32 variant (round 4; debug key "mom32", default on for maps of >= MOM32_MIN_PIXELS pixels): the products and the sums of
+// MOM32_FLUSH x 4 = 64 consecutive pixels run on v_mfma_f32_16x16x4_f32 (twice the fp64 matrix-core rate, no v_cvt_f64_f32 in front of
+// every operand -- the LDS-read -> convert -> fp64-MFMA chain is what bounds the fp64 form, tools/experiments/cvt_rate.hip), and each
+// such block is then added to the fp64 accumulators.  Arithmetic: a block's 64 fp32 products x_a x_b are summed in fp32 (relative
+// error <= 64 x 2^-24 worst case, ~1e-6 typical, zero-mean), the N / 64 blocks in fp64 -- the total's relative error is ~1e-6 /
+// sqrt(N / 64): 1e-8 at the 518 400 pixels of relu3_1 at 4K, against 1e-16 for the fp64 form and ~1e-7 for a covariance that the
+// reference's own fp32 FEATURES already carry (each x is an fp32 rounding of the exact activation).  Measured end to end: see DESIGN 9.
 #include "wct_common.h"
 #include "conv_f16_dev.h"
 #include <algorithm>
@@ -38,9 +46,46 @@ constexpr int MAXLD = 8;  // upper bound of float4 loads per thread per tile (MP
 // issued before the first conversion / MFMA and nothing in here is conditional, so the scheduler overlaps LDS
 // latency with the matrix pipe instead of serialising read -> wait -> MFMA.  A wave's pair list is processed in
 // triples (unused slots alias a valid LDS column; their accumulators are never stored).
+constexpr int MOM32_FLUSH = 16;     // steps (of 4 pixels) whose products are summed in fp32 before they are added to the fp64 accumulators
+
+// F32 = false: fp64 products on v_mfma_f64_16x16x4_f64, accumulators in ITS D layout (row = (lane >> 4) + 4 reg).
+// F32 = true : fp32 products on v_mfma_f32_16x16x4_f32 per block of MOM32_FLUSH steps, then added in fp64; the fp64 accumulators are then
+//              in the fp32 instruction's D layout (row = 4 (lane >> 4) + reg) -- mom_row() below is what the stores use.
+template <bool F32>
+__device__ __forceinline__ int mom_row(int pk, int r) { return F32 ? 4 * pk + r : pk + 4 * r; }
+
+template <bool F32>
 __device__ __forceinline__ void tile_steps3(const float* lds, int Cs, int st0, int st1, int pk, const int* offA, const int* offB,
                                             f64x4& c0, f64x4& c1, f64x4& c2, double& s0, double& s1, double& s2) {
   const int oa0 = offA[0], oa1 = offA[1], oa2 = offA[2], ob0 = offB[0], ob1 = offB[1], ob2 = offB[2];
+  if constexpr (F32) {
+    for (int sb = st0; sb < st1; sb += MOM32_FLUSH) {
+      const int se = sb + MOM32_FLUSH < st1 ? sb + MOM32_FLUSH : st1;
+      f32x4 f0 = f32x4{0.f, 0.f, 0.f, 0.f}, f1 = f0, f2 = f0;
+      float t0 = 0.f, t1 = 0.f, t2 = 0.f;
+      for (int st = sb; st < se; st += 4) {
+        float av[4][3], bv[4][3];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const float* row = lds + ((st + u) * 4 + pk) * Cs;
+          av[u][0] = row[oa0]; bv[u][0] = row[ob0];
+          av[u][1] = row[oa1]; bv[u][1] = row[ob1];
+          av[u][2] = row[oa2]; bv[u][2] = row[ob2];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          t0 += av[u][0]; t1 += av[u][1]; t2 += av[u][2];
+          f0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][0], bv[u][0], f0, 0, 0, 0);
+          f1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][1], bv[u][1], f1, 0, 0, 0);
+          f2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][2], bv[u][2], f2, 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { c0[r] += (double)f0[r]; c1[r] += (double)f1[r]; c2[r] += (double)f2[r]; }
+      s0 += (double)t0; s1 += (double)t1; s2 += (double)t2;
+    }
+    return;
+  }
   for (int st = st0; st < st1; st += 4) {
     float av[4][3], bv[4][3];
 #pragma unroll
@@ -62,8 +107,35 @@ __device__ __forceinline__ void tile_steps3(const float* lds, int Cs, int st0, i
 }
 
 // two pairs (l1_moments_kernel's packed tiling of 24 channels)
+template <bool F32>
 __device__ __forceinline__ void tile_steps2(const float* lds, int Cs, int st0, int st1, int pk, int oa0, int ob0, int oa1, int ob1,
                                             f64x4& c0, f64x4& c1, double& s0, double& s1) {
+  if constexpr (F32) {
+    for (int sb = st0; sb < st1; sb += MOM32_FLUSH) {
+      const int se = sb + MOM32_FLUSH < st1 ? sb + MOM32_FLUSH : st1;
+      f32x4 f0 = f32x4{0.f, 0.f, 0.f, 0.f}, f1 = f0;
+      float t0 = 0.f, t1 = 0.f;
+      for (int st = sb; st < se; st += 4) {
+        float av[4][2], bv[4][2];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const float* row = lds + ((st + u) * 4 + pk) * Cs;
+          av[u][0] = row[oa0]; bv[u][0] = row[ob0];
+          av[u][1] = row[oa1]; bv[u][1] = row[ob1];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          t0 += av[u][0]; t1 += av[u][1];
+          f0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][0], bv[u][0], f0, 0, 0, 0);
+          f1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][1], bv[u][1], f1, 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { c0[r] += (double)f0[r]; c1[r] += (double)f1[r]; }
+      s0 += (double)t0; s1 += (double)t1;
+    }
+    return;
+  }
   for (int st = st0; st < st1; st += 4) {
     float av[4][2], bv[4][2];
 #pragma unroll
@@ -84,7 +156,7 @@ __device__ __forceinline__ void tile_steps2(const float* lds, int Cs, int st0, i
 
 // NLD: float4 load slots per thread per tile = ceil(MP * C / 4 / 256); PW: tile pairs a wave can own (3 / 6 / 9 -- sized to
 // the problem so that small-C launches do not carry 9 accumulators); DEPTH: tiles in flight towards HBM (1 or 2)
-template <int NLD, int PW, int DEPTH>
+template <int NLD, int PW, int DEPTH, bool F32>
 __global__ __launch_bounds__(256, 2) void moments_kernel(MomArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* lds = reinterpret_cast<float*>(smem);  // [MP][Cs]
@@ -162,9 +234,9 @@ __global__ __launch_bounds__(256, 2) void moments_kernel(MomArgs a) {
       }
     __syncthreads();
     if (pt + DEPTH * MP < p1) fetch(pt + DEPTH * MP, cur);   // refill the register set that was just written out
-    if (cnt > 0) tile_steps3(lds, a.Cs, st0, st1, pk, offA, offB, acc[0], acc[1], acc[2], s[0], s[1], s[2]);
-    if constexpr (PW > 3) { if (cnt > 3) tile_steps3(lds, a.Cs, st0, st1, pk, offA + 3, offB + 3, acc[3], acc[4], acc[5], s[3], s[4], s[5]); }
-    if constexpr (PW > 6) { if (cnt > 6) tile_steps3(lds, a.Cs, st0, st1, pk, offA + 6, offB + 6, acc[6], acc[7], acc[8], s[6], s[7], s[8]); }
+    if (cnt > 0) tile_steps3<F32>(lds, a.Cs, st0, st1, pk, offA, offB, acc[0], acc[1], acc[2], s[0], s[1], s[2]);
+    if constexpr (PW > 3) { if (cnt > 3) tile_steps3<F32>(lds, a.Cs, st0, st1, pk, offA + 3, offB + 3, acc[3], acc[4], acc[5], s[3], s[4], s[5]); }
+    if constexpr (PW > 6) { if (cnt > 6) tile_steps3<F32>(lds, a.Cs, st0, st1, pk, offA + 6, offB + 6, acc[6], acc[7], acc[8], s[6], s[7], s[8]); }
   };
   if constexpr (DEPTH == 2) {
     for (long pt = p0; pt < p1; pt += 2 * MP) {
@@ -174,7 +246,7 @@ __global__ __launch_bounds__(256, 2) void moments_kernel(MomArgs a) {
   } else {
     for (long pt = p0; pt < p1; pt += MP) step(pt, nxa);
   }
-  // D layout (f64): col = lane & 15, row = (lane >> 4) + 4 * reg
+  // D layout: col = lane & 15, row = mom_row<F32>(lane >> 4, reg)
   if (pixsplit) {
     // add the four waves' partial sets through LDS (reusing the tile buffer; sized for it on the host)
     __syncthreads();
@@ -184,7 +256,7 @@ __global__ __launch_bounds__(256, 2) void moments_kernel(MomArgs a) {
     for (int j = 0; j < PW; ++j) {
       if (j < cnt) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) red[((size_t)wave * a.NP + j) * 256 + (pk + 4 * r) * 16 + c] = acc[j][r];
+        for (int r = 0; r < 4; ++r) red[((size_t)wave * a.NP + j) * 256 + mom_row<F32>(pk, r) * 16 + c] = acc[j][r];
         if (diag[j]) {
           double v = s[j];
           v += __shfl_xor(v, 16);
@@ -207,7 +279,7 @@ __global__ __launch_bounds__(256, 2) void moments_kernel(MomArgs a) {
     if (j < cnt) {
       double* dst = a.part_sq + ((size_t)pc * a.NP + pidx[j]) * 256;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) dst[(pk + 4 * r) * 16 + c] = acc[j][r];
+      for (int r = 0; r < 4; ++r) dst[mom_row<F32>(pk, r) * 16 + c] = acc[j][r];
       if (diag[j]) {  // the diagonal tile's owner also owns sum over that tile's channels
         double v = s[j];
         v += __shfl_xor(v, 16);
@@ -232,6 +304,7 @@ struct L1MomArgs {
   unsigned* sat;         // sticky saturation counter of the context (image values beyond the f16 range), may be null
 };
 
+template <bool F32>
 __global__ __launch_bounds__(256, 2) void l1_moments_kernel(L1MomArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NP = 3, T = 2, MP = 256;
@@ -297,7 +370,7 @@ __global__ __launch_bounds__(256, 2) void l1_moments_kernel(L1MomArgs a) {
       }
     __syncthreads();
     const int st0 = wave * (MP / 16);
-    tile_steps2(feat, a.Cs, st0, st0 + MP / 16, kq, li, li, oa1, ob1, acc[0], acc[1], s[0], s[1]);
+    tile_steps2<F32>(feat, a.Cs, st0, st0 + MP / 16, kq, li, li, oa1, ob1, acc[0], acc[1], s[0], s[1]);
     if (vn < ntiles) { head_pin(pxr); head_commit(pxr, imgH, imgL, tid, sat); }
   }
   sat.commit(a.sat);
@@ -312,7 +385,7 @@ __global__ __launch_bounds__(256, 2) void l1_moments_kernel(L1MomArgs a) {
     for (int e = lane; e < 2 * 256; e += 64) mine[256 + e] = 0.;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int row = kq + 4 * r;
+      const int row = mom_row<F32>(kq, r);
       mine[row * 16 + li] = acc[0][r];                                   // tile (0,0)
       const int ra = 8 + row, cb = ob1;                                   // channels of product 1's entry
       if (ra < 16 && cb >= 16) mine[256 + ra * 16 + (cb - 16)] = acc[1][r];             // tile (0,1) rows 8..15
@@ -407,7 +480,7 @@ size_t moments_workspace_bytes(int C, long npix) {
 }
 
 hipError_t launch_moments(const float* feat, int C, int h, int wfull, int x0, int x1, double* sum, double* sumsq,
-                          void* ws, size_t ws_bytes, hipStream_t s) {
+                          void* ws, size_t ws_bytes, hipStream_t s, bool f32_products) {
   if (x0 < 0 || x1 > wfull || x1 <= x0 || h < 1) return hipErrorInvalidValue;
   const long npix = (long)h * (x1 - x0);
   if (C < 4 || npix < 1 || (C & 3)) return hipErrorInvalidValue;
@@ -430,10 +503,12 @@ hipError_t launch_moments(const float* feat, int C, int h, int wfull, int x0, in
   };
   hipError_t le;
 #define WCT_MOM_CASE(N) \
-  case N: le = a.pw == 3 ? go(moments_kernel<N, 3, 2>) : go(moments_kernel<N, 6, 2>); break;
+  case N: le = f32_products ? (a.pw == 3 ? go(moments_kernel<N, 3, 2, true>) : go(moments_kernel<N, 6, 2, true>)) \
+                            : (a.pw == 3 ? go(moments_kernel<N, 3, 2, false>) : go(moments_kernel<N, 6, 2, false>)); break;
   switch (nld) {
     WCT_MOM_CASE(1) WCT_MOM_CASE(2) WCT_MOM_CASE(3) WCT_MOM_CASE(4) WCT_MOM_CASE(5) WCT_MOM_CASE(6) WCT_MOM_CASE(7)
-    default: le = a.pw == 3 ? go(moments_kernel<8, 3, 2>) : go(moments_kernel<8, 6, 2>); break;
+    default: le = f32_products ? (a.pw == 3 ? go(moments_kernel<8, 3, 2, true>) : go(moments_kernel<8, 6, 2, true>))
+                               : (a.pw == 3 ? go(moments_kernel<8, 3, 2, false>) : go(moments_kernel<8, 6, 2, false>)); break;
   }
 #undef WCT_MOM_CASE
   if (le != hipSuccess) return le;
@@ -445,7 +520,7 @@ hipError_t launch_moments(const float* feat, int C, int h, int wfull, int x0, in
 size_t l1_moments_workspace_bytes() { return (size_t)2 * num_cus() * (3 * 256 + 32) * sizeof(double); }
 
 hipError_t launch_l1_moments(const ConvDesc& e, const float* img, int H, int W, int x0, int x1, double* sum, double* sumsq,
-                             void* ws, size_t ws_bytes, hipStream_t s) {
+                             void* ws, size_t ws_bytes, hipStream_t s, bool f32_products) {
   if (!l1_capable(e) || H < 2 || W < 2 || x0 < 0 || x1 > W || x1 <= x0) return hipErrorInvalidValue;
   if (ws_bytes < l1_moments_workspace_bytes()) return hipErrorOutOfMemory;
   L1MomArgs a;
@@ -461,9 +536,10 @@ hipError_t launch_l1_moments(const ConvDesc& e, const float* img, int H, int W, 
   a.part_sq = reinterpret_cast<double*>(ws);
   a.part_sum = a.part_sq + (size_t)grid * 3 * 256;
   const size_t lds = (size_t)2 * IMG_E * 8 + (size_t)256 * a.Cs * sizeof(float);   // 52 KB (the reduction needs 25 KB of it)
-  hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(l1_moments_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  auto kern = f32_products ? l1_moments_kernel<true> : l1_moments_kernel<false>;
+  hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (err != hipSuccess) return err;
-  hipLaunchKernelGGL(l1_moments_kernel, dim3(grid), dim3(256), lds, s, a);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, a);
   MomArgs m{};
   m.C = e.cout; m.T = 2; m.NP = 3; m.NPC = grid; m.part_sq = a.part_sq; m.part_sum = a.part_sum;
   const long ne = (long)m.NP * 256 + m.T * 16;

@@ -101,6 +101,8 @@ struct wct_ctx {
   int u8fuse = 1;     // 1: wct_stylize_u8 reads / writes uint8 inside the first / last kernel where one exists (reserved)
   int fastfold = 1;   // 1: (W Ss) Wc fold without T = Ss Wc / M / b on the content side's critical path where the decoder allows (cin <= 128)
   int upconv = 1;     // 1: decoder layers behind an upsample run as per-parity 2x2 convolutions of the low-resolution map (4/9 of the products)
+  int mom32 = 1;      // 1: moments of maps with >= MOM32_MIN_PIXELS pixels take their products on the fp32 matrix cores in 64-pixel blocks, block sums in
+                      //    fp64 (moments.hip F32 variant; debug key "mom32"); 0: fp64 products throughout (2: fp32 products at every size)
   int in3wide = 2;    // the 3 -> 64 first conv of the un-pruned encoders: 2 = exact-fp32 MFMA, four cout tiles per operand read (level1.hip in3_wide_f32_kernel);
                       // 1 = f16x3 (in3_wide_kernel: measurably further from the reference at K = 27, see there); 0 = the generic fp32 kernel (debug key "in3wide")
   int fuse = 1;       // 1: fused conv11+conv12+pool / conv12+conv11 kernels at the full-resolution ends of the 16x networks
@@ -633,6 +635,12 @@ int mb_view(wct_ctx* ctx, double** M, double** b) {
   return WCT_OK;
 }
 
+// fp32-product moments only where the fp64 sum over blocks averages the blocks' fp32 rounding down far enough: maps of at least this many
+// pixels (>= 1024 blocks of 64: relative error of a raw second moment <= ~3e-8).  Smaller maps are cheap in fp64 and are the deep,
+// worst-conditioned levels.
+constexpr long MOM32_MIN_PIXELS = 65536;
+bool mom32_on(const wct_ctx* ctx, long npix) { return ctx->mom32 == 2 || (ctx->mom32 == 1 && npix >= MOM32_MIN_PIXELS); }
+
 int moments_impl(wct_ctx* ctx, Lane& ln, const float* feat, int C, int h, int w, int x0, int x1, double* sum, double* sumsq) {
   if (C < 4 || (C & 3) || C > 512) return fail(ctx, WCT_ERR_INVALID, "moments: C=%d must be a multiple of 4 in [4,512]", C);
   if (h < 1 || x0 < 0 || x1 > w || x1 <= x0) return fail(ctx, WCT_ERR_INVALID, "moments: bad window h=%d w=%d [%d,%d)", h, w, x0, x1);
@@ -640,7 +648,7 @@ int moments_impl(wct_ctx* ctx, Lane& ln, const float* feat, int C, int h, int w,
   const size_t wsb = moments_workspace_bytes(C, npix);
   if (int rc = ensure(ctx, ln.wsMom, wsb)) return rc;
   ProfScope ps(ctx, ln.stream, "moments", 2.0 * C * C * npix, 4.0 * C * npix);
-  HIPCHK(ctx, launch_moments(feat, C, h, w, x0, x1, sum, sumsq, ln.wsMom.p, ln.wsMom.cap, ln.stream));
+  HIPCHK(ctx, launch_moments(feat, C, h, w, x0, x1, sum, sumsq, ln.wsMom.p, ln.wsMom.cap, ln.stream, mom32_on(ctx, npix)));
   return WCT_OK;
 }
 
@@ -841,7 +849,7 @@ int l1_moments_impl(wct_ctx* ctx, Lane& ln, int level, const float* img, int H, 
   if (int rc = ensure(ctx, ln.wsMom, l1_moments_workspace_bytes())) return rc;
   const double px = (double)H * W;
   ProfScope ps(ctx, ln.stream, "l1_moments_fused<3-24>", 2.0 * (27.0 * e.cout + (double)e.cout * e.cout) * px, 12.0 * px);
-  HIPCHK(ctx, launch_l1_moments(e, img, H, W, x0, x1, sum, sumsq, ln.wsMom.p, ln.wsMom.cap, ln.stream));
+  HIPCHK(ctx, launch_l1_moments(e, img, H, W, x0, x1, sum, sumsq, ln.wsMom.p, ln.wsMom.cap, ln.stream, mom32_on(ctx, (long)H * (x1 - x0))));
   return WCT_OK;
 }
 
@@ -1068,6 +1076,7 @@ int wct_debug_set(wct_ctx* ctx, const char* key, double value) {
   else if (!strcmp(key, "interleave")) ctx->interleave = v;
   else if (!strcmp(key, "foldgemm")) ctx->foldgemm = v;
   else if (!strcmp(key, "nscoop")) ctx->nscoop = (int)value;      // 0: multi-launch, 1: single launch, 2: single launch with an injected placement fault
+  else if (!strcmp(key, "mom32")) ctx->mom32 = (int)value;       // 0 / 1 / 2, see wct_ctx
   else if (!strcmp(key, "in3wide")) ctx->in3wide = (int)value;   // 2 / 1 / 0, see wct_ctx
   else if (!strcmp(key, "eig_skip")) {
     // MEASUREMENT ONLY: solves are left out and stale results reused -- wrong pictures by design; refused outside a debug run
@@ -1086,7 +1095,7 @@ int wct_debug_set(wct_ctx* ctx, const char* key, double value) {
     ctx->side.stream = ns;
     return WCT_OK;
   }
-  else return fail(ctx, WCT_ERR_INVALID, "debug_set: unknown key '%s' (fuse, sp, l1fuse, u8fuse, upconv, fastfold, interleave, foldgemm, nscoop, in3wide, eig_skip, side_priority)", key);
+  else return fail(ctx, WCT_ERR_INVALID, "debug_set: unknown key '%s' (fuse, sp, l1fuse, u8fuse, upconv, fastfold, interleave, foldgemm, nscoop, in3wide, mom32, eig_skip, side_priority)", key);
   HIPCHK(ctx, hipStreamSynchronize(ctx->side.stream));
   return WCT_OK;
 }

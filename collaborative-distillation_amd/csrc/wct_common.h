@@ -107,7 +107,7 @@ bool in3_wide_capable(const ConvDesc& enc0);
 hipError_t launch_in3_wide(const ConvDesc& enc0, const float* img, void* out, int H, int W, bool out_sp, bool exact_fp32, hipStream_t s);
 size_t l1_moments_workspace_bytes();
 hipError_t launch_l1_moments(const ConvDesc& enc0, const float* img, int H, int W, int x0, int x1, double* sum, double* sumsq,
-                             void* workspace, size_t workspace_bytes, hipStream_t s);
+                             void* workspace, size_t workspace_bytes, hipStream_t s, bool f32_products = false);
 // fp32 packed weights (device) -> scaled split-f16 packed weights + inverse scale (device scalar)
 //   have_max: *maxbits_dev already holds max |w| (written by launch_fold_affine); otherwise it is computed here
 //   nmax > 1: maxbits_dev is an ARRAY of nmax partial maxima (launch_fold_fast's rowmax) that the kernel reduces itself
@@ -135,8 +135,9 @@ hipError_t launch_nchw_to_nhwc(const float* in, float* out, int C, int npix, hip
 // ---- moments: raw sums  sum[c] = SUM_p x[p][c],  sumsq[a][b] = SUM_p x[p][a] x[p][b]   (fp64)
 size_t moments_workspace_bytes(int C, long npix);
 // window = rows [0,h) x cols [x0,x1) of an NHWC map of width wfull
+// f32_products: products and 64-pixel block sums on the fp32 matrix cores, block totals in fp64 (moments.hip F32 variant); false: fp64 throughout
 hipError_t launch_moments(const float* feat_nhwc, int C, int h, int wfull, int x0, int x1, double* sum,
-                          double* sumsq, void* workspace, size_t workspace_bytes, hipStream_t s);
+                          double* sumsq, void* workspace, size_t workspace_bytes, hipStream_t s, bool f32_products = false);
 
 // ---- solve, in two steps (solve.hip): moments of one map -> EigResult; two EigResults -> M (C x C), b (C)
 //      csF = M cF + b   (util_wct.py:62-131, 219).  EigResult = doubles G[C*C] | lam[C] | mu[C] | floor | pad

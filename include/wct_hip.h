@@ -97,7 +97,7 @@ int wct_range_poll(wct_ctx* ctx, unsigned long long* count);
 int wct_range_flag_f64(wct_ctx* ctx, double* flag_dev);
 
 /* Context-level experiment switches (tests, A/B measurements): key in {"fuse", "sp", "l1fuse", "u8fuse", "upconv", "fastfold",
- * "interleave", "foldgemm", "in3wide"} with value 0 / 1, "nscoop" (0 multi-launch, 1 single launch, 2 single launch with an injected
+ * "interleave", "foldgemm"} with value 0 / 1, "in3wide" (2 / 1 / 0), "mom32" (0 / 1 / 2: fp64 / fp32-block products of the moments), "nscoop" (0 multi-launch, 1 single launch, 2 single launch with an injected
  * placement fault), "side_priority" (-1 / 0 / 1).  They select between kernel formulations of the same operators (fused
  * full-resolution ends, SP16 intermediates, level 1 without relu1_1 in HBM, f16x3 or exact-fp32 first conv of the un-pruned
  * encoders); results agree to fp32 round-off or bitwise (tests/test_hip_parity.py).  "eig_skip" (N: after N solves the matrix

@@ -112,6 +112,52 @@ def test_moments_and_solve_split_form(torch_cuda, wct16, oracle, C, n):
     assert rel_err(M.cpu().numpy(), Mr) < 1e-8 and rel_err(b.cpu().numpy(), br) < 1e-8
 
 
+@pytest.mark.parametrize("C,h,w", [(32, 540, 960), (64, 270, 480), (128, 300, 260), (256, 270, 262), (512, 135, 512), (24, 0, 0)])
+def test_moments_fp32_block_products(torch_cuda, weights16x, C, h, w):
+    """Maps of >= 65 536 pixels take their moments with fp32 products: 64-pixel blocks on v_mfma_f32_16x16x4_f32, block sums added in
+    fp64 (moments.hip F32 variant, debug key "mom32", VERDICT r3 task 7) -- twice the matrix-core rate and no conversions in front of
+    the operands.  Against the fp64 form (mom32 = 0, itself 1e-13 from numpy, test above): the raw sums to 1e-6 of their largest
+    entry (expected ~1e-8: zero-mean block rounding averaged over >= 1024 blocks), the COVARIANCE it implies to 2e-6 of its largest
+    entry, symmetric, the pixel count equal; smaller maps are untouched (bitwise the fp64 form).  C = 24: the fused level-1 kernel
+    (image -> conv11 -> moments), through content_encode."""
+    from wct_hip import WCT
+    torch = torch_cuda
+    e = WCT(types.SimpleNamespace(mode="16x", alpha=1.0), weights=weights16x)
+    g = torch.Generator(device="cuda").manual_seed(C)
+    if C == 24:
+        img = torch.rand((1, 3, 600, 800), device="cuda", generator=g)
+        res = {}
+        for m in (1, 0):
+            e.debug_set("mom32", m)
+            _, _, sm, sq = e.content_encode(1, img)
+            res[m] = (600 * 800, sm.clone(), sq.clone())
+    else:
+        f = torch.relu(torch.randn((1, h, w, C), device="cuda", generator=g) + 0.3)
+        f[..., 1] = 0
+        f[..., 2] *= 1e-3                  # a weak channel beside strong ones
+        res = {}
+        for m in (1, 0):
+            e.debug_set("mom32", m)
+            n, sm, sq = e.moments(f, 5, w - 3)
+            res[m] = (n, sm.clone(), sq.clone())
+        small = f[:, :100, :200].contiguous()      # 19 400 pixels in the window: below the threshold, fp64 either way
+        e.debug_set("mom32", 1)
+        a = e.moments(small, 3, 197)
+        e.debug_set("mom32", 0)
+        b = e.moments(small, 3, 197)
+        assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    (n1, s1, q1), (n0, s0, q0) = res[1], res[0]
+    assert n1 == n0
+    s1, q1, s0, q0 = (t.cpu().numpy() for t in (s1, q1, s0, q0))
+    assert np.array_equal(q1, q1.T)
+    es, eq = rel_err(s1, s0), rel_err(q1, q0)
+    cov = lambda s_, q_: (q_ - np.outer(s_, s_) / n0) / (n0 - 1)     # noqa: E731
+    ec = rel_err(cov(s1, q1), cov(s0, q0))
+    print("\n[moments fp32 blocks C=%d n=%d] sum %.2e  sumsq %.2e  covariance %.2e" % (C, n0, es, eq, ec))
+    assert es < 1e-6 and eq < 1e-6 and ec < 2e-6
+    assert not np.array_equal(q1, q0)      # the fp32 path really ran
+
+
 @pytest.mark.parametrize("C,lmin,dead,rank", [(128, 1e-8, 9, None), (128, 1e-15, 0, None), (256, 3e-11, 69, None), (512, 1e-9, 0, None),
                                               (512, 1e-7, 7, 100), (256, 1e-6, 0, 255), (512, 1e-5, 0, 15)])
 def test_solve_ill_conditioned_and_singular(torch_cuda, wct16, oracle, C, lmin, dead, rank):
