@@ -311,6 +311,9 @@ __global__ __launch_bounds__(512) void conv3x3_sp_kernel(SpArgs a) {
 //     FIRST taps, so that at the top of job j + 1 `s_waitcnt vmcnt(5)` (the wave's five newest vector-memory operations = the DMA
 //     of job j + 2, issued unconditionally) waits for job j + 1's stage and for the stores, while a whole stage stays in flight.
 // Same tiles, same MFMA order, same epilogue as the kernel above: results are bit-identical (tests/test_hip_parity.py).
+// (Also built and measured, not kept: the opposite order -- DMA on the first taps, the stores LAST and unconditional (lanes without an
+// output pixel writing to a sink), `vmcnt(5 + stores)` so that the stores stay in flight across the barrier as well.  4 % slower on the
+// same box, 0.705 against 0.678 ms per step for the family: it is the stage of loads in flight that pays, not the stores' latency.)
 // LDS (16-B units): 3 x act[640 x 4] + wgt[chunks][36 x 32] + bias = 141 KB (16 cin) / 159 KB (32 cin).
 template <bool POOL, bool OUTF32>
 __global__ __launch_bounds__(512) void conv3x3_sp3_kernel(SpArgs a) {
