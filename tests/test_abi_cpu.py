@@ -123,3 +123,13 @@ def test_weights_only_loader_reads_the_reference_checkpoints():
             assert set(mine) <= set(sd) and all("aux" in n for n in set(sd) - set(mine)), key
             for n, v in mine.items():
                 assert v.shape == sd[n].shape and np.array_equal(v, sd[n]), (key, n)
+
+
+def test_experiment_scripts_reference_live_switches():
+    """tools/experiments/ is the recipe book behind DESIGN's numbers: every script must byte-compile and use only WCT_* variables and
+    wct_debug_set keys that still exist in the library (tools/experiments/audit.py; VERDICT r3 task 8)."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "experiments", "audit.py")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout
+
