@@ -573,7 +573,7 @@ def main():
             ovr = (oracle_vs_reference_table() or {}).get("g14_cfg3_original")
             if ovr is not None:
                 p3["oracle_vs_reference"] = ovr["oracle_vs_reference"]
-                p3["oracle_vs_reference_source"] = "tests/golden/oracle_vs_reference.json (tools/oracle_vs_reference.py, build container: the oracle's C loops are deterministic; tests/test_hip_scale.py recomputes it on this box's host)"
+                p3["oracle_vs_reference_source"] = "tests/golden/oracle_vs_reference.json (tools/oracle_vs_reference.py, measured in the build container, 8 threads; tests/test_hip_scale.py recomputes it on the GPU box's host, where BLAS threading moves it by a few per cent: 2.32e-3 here, 2.38e-3 there)"
                 p3["limit"] = max(1e-3, 1.25 * ovr["oracle_vs_reference"])
                 p3["within_limit"] = bool(r["max"] <= p3["limit"])
         # the same graph at the LITERAL 1e-3: G15, well-conditioned generated weights (paired-isometry layers), the reference's classes

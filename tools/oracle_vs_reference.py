@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Build container, CPU: the oracle (C loops + numpy, deterministic) against every full-size reference-made frame fixture ->
+"""Build container, CPU: the oracle (C loops + numpy; reproducible on one host -- across hosts BLAS threading moves the chaotic frames by a few per cent)
+against every full-size reference-made frame fixture ->
 tests/golden/oracle_vs_reference.json.  bench.py quotes these figures beside its own `hip_vs_reference` where running the oracle
 inside the bench would cost minutes (config 3: `limit` = max(1e-3, 1.25 x oracle_vs_reference), tests/test_hip_scale.py recomputes
 them on the GPU box's host).  usage: python tools/oracle_vs_reference.py [fixture names...]   (~15 min for all five on 8 vCPU)"""
