@@ -821,7 +821,8 @@ __device__ __forceinline__ f64x4 tile_gemm_lds(const double* P, const double* Q,
 template <int CP>
 __global__ __launch_bounds__((CP / 16) * (CP / 16) * 64) void ns_lds_kernel(double* res, int C, int inverse, double eps_rel,
                                                                                int maxit, double zmax, int* ok_out, int* info,
-                                                                               double npix, const double* sum, const double* sumsq, double diag_add) {
+                                                                               double npix, const double* sum, const double* sumsq, double diag_add,
+                                                                               NsSched sched, int nsched) {
   constexpr int LD = CP + 2, TPR = CP / 16, NW = TPR * TPR, NT = NW * 64;
   extern __shared__ __attribute__((aligned(16))) char smem_ns[];
   double* Y = reinterpret_cast<double*>(smem_ns);
@@ -864,7 +865,8 @@ __global__ __launch_bounds__((CP / 16) * (CP / 16) * 64) void ns_lds_kernel(doub
   double prev = 1e300;   // residual measured before the last executed update
   for (int it = 0; it < maxit; ++it) {
     if (it > 0 && prev < NS_TOL) break;
-    // stage 1: T = 1.5 I - 0.5 Z Y, residual = max |Z Y - I|
+    // stage 1: T = ca I - cb Z Y (ca = 1.5, cb = 0.5 unscaled; the scaled schedule of launch_eig for the first `nsched` steps), residual = max |Z Y - I|
+    const double ca = it < nsched ? sched.ca[it] : 1.5, cb = it < nsched ? sched.cb[it] : 0.5;
     const f64x4 zy = tile_gemm_lds<CP>(Z, Y, i0, j0, lane);
     double m = 0.;
 #pragma unroll
@@ -872,7 +874,7 @@ __global__ __launch_bounds__((CP / 16) * (CP / 16) * 64) void ns_lds_kernel(doub
       const int row = i0 + kk + 4 * r, col = j0 + li;
       const double d = zy[r] - (row == col ? 1.0 : 0.0);
       m = (d == d) ? fmax(m, fabs(d)) : __longlong_as_double(0x7ff0000000000000ll);  // fmax would swallow a NaN
-      T[row * LD + col] = (row == col ? 1.5 : 0.0) - 0.5 * zy[r];
+      T[row * LD + col] = (row == col ? ca : 0.0) - cb * zy[r];
     }
     for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o));
     if (lane == 0) red[wave] = m;
@@ -1228,6 +1230,11 @@ hipError_t launch_eig(int C, double n, const double* sum, const double* sumsq, i
   // iterations on the 4K bench frame, 1.4 % of a cached-style frame (A/B on one box, tools/experiments/ns_guess.py).
   static const double guess_env = [] { const char* e = wct_debug_env("WCT_NS_GUESS"); return e ? atof(e) : -1.0; }();
   const double guess = big || Cp <= 64 ? 0.0 : (guess_env >= 0. ? guess_env : 1e-5);
+  // Cp <= 64 (round 4): the same scaled start inside the LDS kernel -- 16 / 18 / 15 plain iterations at levels 3 / 2 / 1 of the 4K bench
+  // frame.  The schedule covers its first COOP_MAXIT steps; beyond them (a spectrum far below the guess) the plain iteration goes on
+  // up to the unchanged budget NS_MAXIT, so a wrong guess still costs iterations only.
+  static const double guess64_env = [] { const char* e = wct_debug_env("WCT_NS_GUESS64"); return e ? atof(e) : -1.0; }();
+  const double guess64 = guess64_env >= 0. ? guess64_env : 1e-5;
   // C > 128 (original mode): the deflated, optimally scaled iteration takes 19-20 iterations whatever the matrix
   const int maxit = maxit_env ? maxit_env : (C > 128 ? 24 : (guess > 0. ? 16 : NS_MAXIT));
   bool coop_used = false;
@@ -1238,7 +1245,17 @@ hipError_t launch_eig(int C, double n, const double* sum, const double* sumsq, i
       const size_t lds = (size_t)3 * cp * (cp + 2) * sizeof(double) + (size_t)(nw + 2) * sizeof(double) + (size_t)cp * sizeof(int);
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return e;
-      hipLaunchKernelGGL(kern, dim3(1), dim3((unsigned)nw * 64), lds, s, res, C, inverse, 1e-15, maxit, NS_ZMAX, w.ok, info_dev, n, sum, sumsq, diag_add);
+      NsSched sc;
+      int nsched = 0;
+      if (guess64 > 0.) {
+        double xl = sqrt(guess64);
+        for (; nsched < COOP_MAXIT && nsched < maxit; ++nsched) {
+          const double mu = xl <= 0.9 ? sqrt(3.0 / (1.0 + xl + xl * xl)) : 1.0;
+          xl = mu * xl * (3.0 - mu * mu * xl * xl) / 2.0;
+          sc.ca[nsched] = 1.5 * mu; sc.cb[nsched] = 0.5 * mu * mu * mu;
+        }
+      }
+      hipLaunchKernelGGL(kern, dim3(1), dim3((unsigned)nw * 64), lds, s, res, C, inverse, 1e-15, maxit, NS_ZMAX, w.ok, info_dev, n, sum, sumsq, diag_add, sc, nsched);
       return hipSuccess;
     };
     hipError_t e = Cp == 32 ? go(ns_lds_kernel<32>, 32) : go(ns_lds_kernel<64>, 64);
