@@ -270,6 +270,8 @@ def run_pipelined(args, wct, pairs, content_dir, style_dir, logprinter) -> float
             if sfile not in style_cache:
                 s_u8 = fut[("s", sfile)].result().cuda(non_blocking=True)
                 style_dev[sfile] = s_u8
+                while len(style_dev) > depth + 2:           # the fallback reloads a style it no longer finds here: keep the few that can be in flight
+                    style_dev.pop(next(iter(style_dev)))
                 wct.style_prepare(_to_tensor(wct, s_u8, args.style_size))
                 style_cache[sfile] = {L: wct.style_export(L) for L in (5, 4, 3, 2, 1)}
             else:

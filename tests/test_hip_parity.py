@@ -633,6 +633,30 @@ def test_g6_original_arch(torch_cuda, golden):
         assert rel_err(y, g["L%d.out" % k]) < 5e-4, k
 
 
+def test_original_first_conv_forms(torch_cuda):
+    """The 3 -> 64 first conv of the un-pruned encoders in its three forms (debug key in3wide): 2 = exact-fp32 MFMA with four cout tiles per
+    operand read (level1.hip in3_wide_f32_kernel, the default), 0 = the generic exact-fp32 kernel -- the same products in the same order,
+    so bit-identical, fp32 NHWC out (level 1) and SP16 out (level 2), odd sizes and reflected borders included -- and 1 = f16x3 with K = 27,
+    which agrees to the split's accuracy (DESIGN 2 explains why it is no longer the default)."""
+    from wct_hip import WCT
+    torch = torch_cuda
+    w = model_zoo.synth_weights_conditioned("original", 15)
+    wct = WCT(types.SimpleNamespace(mode="original", alpha=1.0), weights=w)
+    g = torch.Generator(device="cuda").manual_seed(21)
+    for (H, W) in ((200, 264), (45, 37), (2, 3), (301, 1000)):
+        c = torch.rand((1, 3, H, W), device="cuda", generator=g)
+        outs = {}
+        for key in (2, 0, 1):
+            wct.debug_set("in3wide", key)
+            outs[key] = [wct.encode(1, c).clone()] + ([wct.encode(2, c).clone()] if H >= 4 and W >= 4 else [])
+        for a, b in zip(outs[2], outs[0]):
+            assert torch.equal(a, b), (H, W)
+        for a, b in zip(outs[2], outs[1]):
+            assert float((a - b).abs().max() / a.abs().max()) < 2e-5, (H, W)
+    wct.debug_set("in3wide", 2)
+    wct.sync()
+
+
 def test_g8_constant_content(torch_cuda, wct16, golden):
     g = golden("g8_constant.npz")
     c, s = cu(torch_cuda, g["content"])[None], cu(torch_cuda, g["style"])[None]
