@@ -313,7 +313,12 @@ __global__ __launch_bounds__(512) void conv3x3_sp_kernel(SpArgs a) {
 // Same tiles, same MFMA order, same epilogue as the kernel above: results are bit-identical (tests/test_hip_parity.py).
 // (Also built and measured, not kept: the opposite order -- DMA on the first taps, the stores LAST and unconditional (lanes without an
 // output pixel writing to a sink), `vmcnt(5 + stores)` so that the stores stay in flight across the barrier as well.  4 % slower on the
-// same box, 0.705 against 0.678 ms per step for the family: it is the stage of loads in flight that pays, not the stores' latency.)
+// same box, 0.705 against 0.678 ms per step for the family: it is the stage of loads in flight that pays, not the stores' latency.
+// And the opposite design altogether -- an OCCUPANCY kernel: one 32 x 8 tile per 4-wave workgroup, not persistent, the whole halo and
+// the weights DMA'd at once, one barrier, 2-3 workgroups per CU hiding each other's loads and stores (the store probe,
+// tools/experiments/write_bw.hip, favours more store-issuing waves per CU) -- bit-identical, and 6 % / 15 % SLOWER for the plain / pooled
+// layers (0.838 / 0.69 against 0.79 / 0.60 ms per step, profiles/r04_spq_occupancy_kernel_ab_slow_box.txt): a third more halo, the
+// weights reloaded per 256 pixels, 8 100 workgroups to dispatch.)
 // LDS (16-B units): 3 x act[640 x 4] + wgt[chunks][36 x 32] + bias = 141 KB (16 cin) / 159 KB (32 cin).
 template <bool POOL, bool OUTF32>
 __global__ __launch_bounds__(512) void conv3x3_sp3_kernel(SpArgs a) {
