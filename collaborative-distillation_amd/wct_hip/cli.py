@@ -309,8 +309,6 @@ def main(argv: Optional[List[str]] = None) -> int:
     style_dir = args.UHD_stylePath if args.UHD else args.stylePath
     pairs = list_pairs(content_dir, style_dir, args.picked_content_mark, args.picked_style_mark)
 
-    import torch
-    from PIL import Image
     from .wct import WCT      # raises ImportError if libwct_hip.so is missing: no CPU fallback
     wct = WCT(args)
     logprinter("Number of content-style pairs: %s" % len(pairs))
