@@ -129,3 +129,70 @@ def test_cli_pipeline_is_byte_identical_to_the_serial_loop(tmp_path):
         assert len(outs[tag]) == 6
         assert "Processed 6 images." in (o / "log_P_16x.txt").read_text()
     assert outs["pipe"] == outs["serial"] and outs["pipe1"] == outs["serial"]
+
+
+@pytest.mark.gpu
+def test_cli_pipeline_recovers_a_clamped_pair_like_the_serial_loop(tmp_path):
+    """A pair whose f16x3 arithmetic clamped is recomputed with exact-fp32 convolutions -- in the pipelined loop the flag is read
+    from a counter copied in stream order with the image, and everything enqueued BEHIND the clamped pair is discarded and redone
+    (its style statistics may carry the clamp).  uint8 images cannot reach the f16 range, so the clamp is injected: a wrapper engine
+    reports one for the third pair (through saturation_count in the serial loop, through range_flag in the pipelined one).  Both
+    loops must warn once and write the same bytes -- the third pair's being those of the fp32 path."""
+    import types
+    import torch
+    Image = pytest.importorskip("PIL.Image")
+    from wct_hip import WCT
+    rng = np.random.default_rng(9)
+    c, s = tmp_path / "content", tmp_path / "style"
+    c.mkdir(); s.mkdir()
+    for n in ("a.png", "b.png", "c.png", "d.png", "e.png"):
+        Image.fromarray(rng.integers(0, 256, size=(96, 112, 3), dtype=np.uint8)).save(c / n)
+    Image.fromarray(rng.integers(0, 256, size=(64, 72, 3), dtype=np.uint8)).save(s / "s1.png")
+    eng = WCT(types.SimpleNamespace(mode="16x", alpha=1.0))
+
+    class Injected:
+        """The real engine with a clamp reported for the pair that is stylised third (and only the first time it is)."""
+        def __init__(self):
+            self.n_prepared, self.fired, self.fake = 0, False, 0.0
+        def __getattr__(self, name):
+            return getattr(eng, name)
+        def __setattr__(self, name, value):
+            if name in ("n_prepared", "fired", "fake"):
+                object.__setattr__(self, name, value)
+            else:
+                setattr(eng, name, value)
+        def stylize_prepared(self, *a, **k):
+            self.n_prepared += 1
+            if self.n_prepared == 3 and not self.fired:
+                self.fired, self.fake = True, 1.0
+            return eng.stylize_prepared(*a, **k)
+        def range_flag(self):
+            return eng.range_flag() + self.fake
+        def saturation_count(self, reset=False):
+            n = eng.saturation_count(reset) + int(self.fake)
+            if reset:
+                self.fake = 0.0
+            return n
+
+    outs, logs = {}, {}
+    pairs = cli.list_pairs(str(c), str(s))
+    for tag, depth in (("serial", 0), ("pipe", 3)):
+        o = tmp_path / tag
+        o.mkdir()
+        a = cli.build_parser().parse_args(["--mode", "16x", "--contentPath", str(c), "--stylePath", str(s), "--outf", str(o), "--log_mark", "F",
+                                           "--pipeline", str(depth), "--io_threads", "2"])
+        lines = []
+        (cli.run_pipelined if depth else cli.run_serial)(a, Injected(), pairs, str(c), str(s), lambda x: lines.append(str(x)))
+        torch.cuda.synchronize()
+        outs[tag] = {f: (o / f).read_bytes() for f in sorted(os.listdir(o)) if f.endswith(".jpg")}
+        logs[tag] = "\n".join(lines)
+        assert len(outs[tag]) == 5 and logs[tag].count("WARNING: f16x3 range exceeded") == 1, logs[tag]
+    assert outs["pipe"] == outs["serial"]
+    # and the recomputed pair really is the fp32 path's picture, not the f16x3 one
+    eng.set_conv_mode("fp32")
+    third = pairs[2][0]
+    ref = eng.to_u8(eng.stylize(eng.to_tensor_u8(torch.from_numpy(cli.load_rgb_u8(str(c / third))).cuda()),
+                                eng.to_tensor_u8(torch.from_numpy(cli.load_rgb_u8(str(s / "s1.png"))).cuda()), 1.0, 1), 0).cpu().numpy()
+    eng.set_conv_mode("f16x3")
+    got = np.asarray(Image.open(tmp_path / "pipe" / ("F_mode=16x_alpha=1_%s+s1.jpg" % third.split(".")[0])).convert("RGB"))
+    assert np.abs(got.astype(np.int32) - ref.astype(np.int32)).mean() < 12
