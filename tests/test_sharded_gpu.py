@@ -130,6 +130,31 @@ def test_config4_eight_strips_match_untiled(tmp_path):
     assert np.isfinite(z["got"]).all() and e < 1e-3
 
 
+def test_config4_eight_strips_device_buffers_in_process():
+    """The same job -- 10240x4096 in eight 1280-column strips, exchange halos, 2048x2048 style -- with every collective on DEVICE buffers:
+    eight rank threads, eight engines, eight streams in this process (wct_hip.sharded.InProcessWorld), i.e. the geometry of the 8-GPU
+    configuration (edge strips with one halo, interior strips with two, the style levels dealt round robin, 3.5 MB edge-column messages)
+    through the branch of sharded.py that RCCL takes.  Against the untiled cascade (the gloo test's bound), and bitwise against the same
+    job with a device-wide synchronisation around every collective."""
+    import torch
+    from wct_hip import WCT, model_zoo
+    from wct_hip import sharded
+    w = model_zoo.load_npz_weights(os.path.join(PKG, "weights", "16x.npz"))
+    make = lambda: WCT(types.SimpleNamespace(mode="16x", alpha=1.0), weights=w)     # noqa: E731
+    g = torch.Generator(device="cuda").manual_seed(11)
+    content = torch.rand((3, 4096, 10240), device="cuda", generator=g)
+    style = torch.rand((3, 2048, 2048), device="cuda", generator=g)
+    got, groups = sharded.run_in_process(8, make, content, style, halo_mode="auto")
+    ref = make().stylize(content, style)
+    e = float((got - ref).abs().max() / ref.abs().max())
+    print("\n[cfg4 8 strips, device buffers, in process] rel_err=%.3e" % e)
+    assert tuple(got.shape) == (1, 3, 4096, 10240) and bool(torch.isfinite(got).all()) and e < 1e-3
+    assert all(grp.calls == {"all_reduce": 5, "broadcast": 5, "p2p": 4} for grp in groups)
+    del ref
+    synced, _ = sharded.run_in_process(8, make, content, style, sync_every=True, halo_mode="auto")
+    assert torch.equal(got, synced)
+
+
 def _replica_worker(rank, world, port, out_dir):
     for p in (REPO, PKG):
         if p not in sys.path:
