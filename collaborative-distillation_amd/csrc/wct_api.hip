@@ -648,7 +648,8 @@ int moments_impl(wct_ctx* ctx, Lane& ln, const float* feat, int C, int h, int w,
   const size_t wsb = moments_workspace_bytes(C, npix);
   if (int rc = ensure(ctx, ln.wsMom, wsb)) return rc;
   ProfScope ps(ctx, ln.stream, "moments", 2.0 * C * C * npix, 4.0 * C * npix);
-  HIPCHK(ctx, launch_moments(feat, C, h, w, x0, x1, sum, sumsq, ln.wsMom.p, ln.wsMom.cap, ln.stream, mom32_on(ctx, npix)));
+  // the arithmetic is chosen on the WHOLE map's pixel count, not the window's: every window of one map shares one arithmetic
+  HIPCHK(ctx, launch_moments(feat, C, h, w, x0, x1, sum, sumsq, ln.wsMom.p, ln.wsMom.cap, ln.stream, mom32_on(ctx, (long)h * w)));
   return WCT_OK;
 }
 
@@ -849,7 +850,7 @@ int l1_moments_impl(wct_ctx* ctx, Lane& ln, int level, const float* img, int H, 
   if (int rc = ensure(ctx, ln.wsMom, l1_moments_workspace_bytes())) return rc;
   const double px = (double)H * W;
   ProfScope ps(ctx, ln.stream, "l1_moments_fused<3-24>", 2.0 * (27.0 * e.cout + (double)e.cout * e.cout) * px, 12.0 * px);
-  HIPCHK(ctx, launch_l1_moments(e, img, H, W, x0, x1, sum, sumsq, ln.wsMom.p, ln.wsMom.cap, ln.stream, mom32_on(ctx, (long)H * (x1 - x0))));
+  HIPCHK(ctx, launch_l1_moments(e, img, H, W, x0, x1, sum, sumsq, ln.wsMom.p, ln.wsMom.cap, ln.stream, mom32_on(ctx, (long)H * W)));
   return WCT_OK;
 }
 
@@ -970,7 +971,7 @@ int wct_create(int device, wct_ctx** out) {
   ok = ok && hipHostMalloc(reinterpret_cast<void**>(&c->sat_host), 64, hipHostMallocDefault) == hipSuccess;
   ok = ok && hipMalloc(reinterpret_cast<void**>(&c->ok_log), 64 * sizeof(int)) == hipSuccess;
   ok = ok && hipHostMalloc(reinterpret_cast<void**>(&c->ok_host), 64 * sizeof(int), hipHostMallocDefault) == hipSuccess;
-  if (ok) *c->sat_host = 0u;
+  if (ok) memset(c->sat_host, 0, 64);     // all 16 words: [2 + lane] are the single-launch solves' abort counts coop_usable() reads
   if (!ok) { wct_destroy(c); return WCT_ERR_HIP; }
   *out = c;
   return WCT_OK;

@@ -208,6 +208,7 @@ def run_pipelined(args, wct, pairs, content_dir, style_dir, logprinter) -> float
     fut = {}                                          # ("c" | "s", file) -> decode future
     style_cache = {}                                  # sfile -> {level: statistics}
     style_dev = {}                                    # sfile -> uint8 device image while pairs using it may still need the fp32 fallback
+    style_by = {}                                     # sfile -> index of the pair whose style_prepare produced the cached statistics
     inflight = collections.deque()
     writes = []
     last_flag = 0.0
@@ -243,13 +244,26 @@ def run_pipelined(args, wct, pairs, content_dir, style_dir, logprinter) -> float
             rec["host"].copy_(wct.to_u8(res, args.round_mode))
             rec["ev"] = torch.cuda.Event()
             rec["ev"].record()
-            style_cache.pop(sfile, None)
+            # the reset above acknowledged EVERY clamp so far, also one inside a style_prepare of a discarded pair (index > i): statistics
+            # prepared by this pair or any later one are dropped with the pairs, so the redone pairs prepare them again under a live flag
+            # (only the clamped pair's own style used to be dropped)
+            for f in [f for f, by in style_by.items() if by >= rec["i"]] + [sfile]:
+                style_cache.pop(f, None)
+                style_dev.pop(f, None)
+                style_by.pop(f, None)
             last_flag = 0.0
             nxt = rec["i"] + 1
         else:
             last_flag = flag
         rec.pop("c_f32", None)
+        rec.pop("keep", None)                         # the event has passed: the GPU is done with the pair's device buffers
         writes.append(wr.submit(save, rec))
+        # bound the writer queue too: a slow disk must not let pinned result buffers pile up behind Image.save
+        for w in [w for w in writes if w.done()]:
+            w.result()                                # (re-raises a writer's exception here, not at the end of the folder)
+            writes.remove(w)
+        while len(writes) > 2 * io:
+            writes.pop(0).result()
         now = time.time()
         logprinter('#%s "%s" left the pipeline, %.4f seconds after the previous pair' % (rec["i"], rec["imname"], now - done_log))
         done_log = now
@@ -274,6 +288,7 @@ def run_pipelined(args, wct, pairs, content_dir, style_dir, logprinter) -> float
                     style_dev.pop(next(iter(style_dev)))
                 wct.style_prepare(_to_tensor(wct, s_u8, args.style_size))
                 style_cache[sfile] = {L: wct.style_export(L) for L in (5, 4, 3, 2, 1)}
+                style_by[sfile] = i
             else:
                 for L, stats in style_cache[sfile].items():
                     wct.style_import(L, stats)

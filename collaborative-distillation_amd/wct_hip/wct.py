@@ -185,7 +185,7 @@ class WCT:
         the deviation from the fp32 reference is then reported by the very next call on every path (stylize*, e*/d* modules,
         styleTransfer, the split-level calls of sharded.py / pipeline.py / replicas.py), not only by sync().  `strict_range =
         False` turns the check off; saturation_count(reset=True) or a reported sync() acknowledges and clears it."""
-        self._lib.wct_set_stream(self._ctx, c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
+        self._chk(self._lib.wct_set_stream(self._ctx, c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
         if self.strict_range:
             n = ctypes.c_ulonglong()
             self._lib.wct_range_poll(self._ctx, byref(n))

@@ -60,7 +60,7 @@ typedef struct wct_layer {
 
 /* per-kernel-family timing collected when profiling is enabled (bench.py's roofline leg) */
 typedef struct wct_prof_entry {
-  char name[48];     /* e.g. "conv3x3<ct=8>" */
+  char name[48];     /* e.g. "conv3x3_f16x3<co=64,dma>", "enc_head_fused<3-16-16,pool>" */
   double ms;         /* summed HIP-event time */
   double flops;      /* algorithmic FLOPs of those launches */
   double bytes;      /* algorithmic HBM bytes (input read once + output written once + weights) */
@@ -126,7 +126,14 @@ int wct_decode(wct_ctx* ctx, int level, const float* feat, int h, int w, int lay
 
 /* raw fp64 moments over the window rows [0,h) x cols [x0,x1) of an NHWC feature map of width w:
  *   sum[C], sumsq[C*C] (device, f64).  Replaces torch.mean + mm(cF, cF.t()) (util_wct.py:68-70, 94-96);
- * raw sums (not centred) so that a content-sharded run can all-reduce them across GPUs. */
+ * raw sums (not centred) so that a content-sharded run can all-reduce them across GPUs.
+ * Arithmetic: maps of >= 65 536 pixels (h * w of the MAP, whatever the window) take their products and the sums of 64-pixel blocks in
+ * fp32 on the matrix cores, block totals in fp64 (raw sums within ~1e-8 relative of the all-fp64 form); smaller maps -- the deep,
+ * worst-conditioned levels -- fp64 products throughout.  Consequences: windows of ONE map share one arithmetic but cut the 64-pixel
+ * blocks differently, so window sums add up to the whole map's to ~1e-8 relative, not to fp64 round-off; and a strip (+ halo) of a
+ * sharded frame is its own, smaller map and may take the fp64 form where the untiled frame takes fp32 blocks (sharded and untiled
+ * (M, b) agree to ~1e-8 either way; tests/test_sharded_gpu.py).  wct_debug_set("mom32", 0) selects exact fp64 products everywhere:
+ * windows then add up to 1e-13. */
 int wct_moments(wct_ctx* ctx, const float* feat, int C, int h, int w, int x0, int x1, double* sum, double* sumsq);
 
 /* (n, sum, sumsq) of content and style -> csF = M cF + b.  M [C*C] row-major, b [C], device f64.

@@ -49,6 +49,12 @@ def cfg3_natural_frames(gold_dir):
     return load("g11_uhd_content_3840x2160.jpg"), load("g11_style_2048x2048.jpg")
 
 
+def cfg4_geometry_frames():
+    """G16: BASELINE configs[3]'s WIDTH (10240 = eight 1280-column strips) at a height the reference finishes in a minute: 10240x512
+    content (seed 5) + the 2048x2048 style (seed 2)."""
+    return noise_frame(5, 512, 10240), noise_frame(2, 2048, 2048)
+
+
 def compare_to_fixture(img, g):
     """img: 3 x H x W result; g: a frame fixture (dict of arrays).  -> dict of errors relative to the reference's maximum."""
     img = np.asarray(img)

@@ -864,3 +864,48 @@ def test_frame_pipeline_equals_single_engine(torch_cuda, wct16, weights16x):
         assert y.shape == ref.shape and torch_cuda.equal(y, ref)
     with pytest.raises(RuntimeError):
         FramePipeline(lambda: wct16, slots=1).stylize_many(frames[:1])
+
+
+def test_stylize_16x_is_capturable_into_a_hip_graph(torch_cuda, weights16x):
+    """include/wct_hip.h: "the 16x path never synchronises" -- so the whole 5-level cascade (both lanes: the side stream forks from and
+    rejoins the caller's stream through events) must be capturable into ONE HIP graph.  Captured once
+    after a warm-up call (workspaces sized: no allocation in the capture), replayed on the SAME buffers with a different content: bitwise
+    the direct call's result both times.  In a fresh process: a failed capture can leave the runtime in capture mode."""
+    import os
+    import subprocess
+    import sys
+    from tests.conftest import PKG, REPO
+    code = r"""
+import sys, types
+sys.path[:0] = [%r, %r]
+import torch
+from wct_hip import WCT, model_zoo
+import os
+w = model_zoo.load_npz_weights(os.path.join(%r, "weights", "16x.npz"))
+wct = WCT(types.SimpleNamespace(mode="16x", alpha=1.0), weights=w)
+g = torch.Generator(device="cuda").manual_seed(5)
+c1 = torch.rand((3, 272, 400), device="cuda", generator=g)
+c2 = torch.rand((3, 272, 400), device="cuda", generator=g)
+s = torch.rand((3, 200, 240), device="cuda", generator=g)
+want1 = wct.stylize(c1, s).clone()
+want2 = wct.stylize(c2, s).clone()
+c = c1.clone()
+out = torch.empty((3, 272, 400), device="cuda")
+wct.stylize(c, s, out=out)                       # warm-up on the buffers the graph will use
+torch.cuda.synchronize()
+graph = torch.cuda.CUDAGraph()
+with torch.cuda.graph(graph):
+    wct.stylize(c, s, out=out)
+out.zero_()
+graph.replay()
+torch.cuda.synchronize()
+assert torch.equal(out.view(1, 3, 272, 400), want1), "replay 1 differs"
+c.copy_(c2)
+graph.replay()
+torch.cuda.synchronize()
+assert torch.equal(out.view(1, 3, 272, 400), want2), "replay 2 (new content, same graph) differs"
+assert wct.saturation_count() == 0
+print("GRAPH_OK")
+""" % (REPO, PKG, PKG)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "GRAPH_OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])

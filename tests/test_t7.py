@@ -152,3 +152,69 @@ def test_t7_errors(tmp_path):
     (tmp_path / "cut.t7").write_bytes(data[: len(data) // 2])
     with pytest.raises(t7.T7Error):
         t7.load(str(tmp_path / "cut.t7"))
+
+
+def test_t7_hand_assembled_stream(tmp_path):
+    """Breaks the circle of the tests above (which read what this file's own Writer wrote): ONE stream put together BY HAND,
+    byte string by byte string, from the description of torch7's binary serialiser (torch7 File.lua writeObject / Tensor.c / Storage.c:
+    little-endian; int32 type tag -- 0 nil, 1 number = f64, 2 string = int32 n + n chars, 3 table, 4 torch object, 5 boolean = int32;
+    tables and torch objects carry an int32 reference index first; a torch object then has the string "V 1", its class name, and its
+    payload: tensor = int32 ndim, int64 sizes, int64 strides, int64 1-based storage offset, storage object; storage = int64 n + raw
+    elements; any other class = one table of its fields).  The object: nn.Sequential { modules = { [1] = nn.SpatialConvolution(3 -> 64,
+    3x3) } } as `torch.save` lays it out -- what model_original.py:24-28 hands to load_lua and utils.py:64-67 reads `.weight` /
+    `.bias` from.  No helper of this file is used to build it."""
+    import struct
+    O, I, K = 64, 3, 3
+    weight = (np.arange(O * I * K * K, dtype=np.float32) - 800.0) / 1024.0
+    bias = np.linspace(-1.0, 1.0, O).astype(np.float32)
+    s = b""
+    # -- object 1: torch object, class nn.Sequential
+    s += b"\x04\x00\x00\x00" + b"\x01\x00\x00\x00"                      # tag 4 (TORCH), index 1
+    s += b"\x03\x00\x00\x00V 1"                                          # version string, length 3
+    s += b"\x0d\x00\x00\x00nn.Sequential"                                # class name, length 13
+    # its payload: table (index 2) with ONE entry "modules" -> table
+    s += b"\x03\x00\x00\x00" + b"\x02\x00\x00\x00" + b"\x01\x00\x00\x00"  # tag 3 (TABLE), index 2, 1 entry
+    s += b"\x02\x00\x00\x00" + b"\x07\x00\x00\x00modules"                # key: string "modules"
+    s += b"\x03\x00\x00\x00" + b"\x03\x00\x00\x00" + b"\x01\x00\x00\x00"  # value: table, index 3, 1 entry
+    s += b"\x01\x00\x00\x00" + struct.pack("<d", 1.0)                    # key: number 1 (Lua arrays start at 1)
+    # -- object 4: nn.SpatialConvolution
+    s += b"\x04\x00\x00\x00" + b"\x04\x00\x00\x00"                      # TORCH, index 4
+    s += b"\x03\x00\x00\x00V 1"
+    s += b"\x15\x00\x00\x00nn.SpatialConvolution"                        # length 21
+    s += b"\x03\x00\x00\x00" + b"\x05\x00\x00\x00" + b"\x05\x00\x00\x00"  # its field table: index 5, 5 entries
+    s += b"\x02\x00\x00\x00" + b"\x02\x00\x00\x00kW" + b"\x01\x00\x00\x00" + struct.pack("<d", 3.0)
+    s += b"\x02\x00\x00\x00" + b"\x02\x00\x00\x00kH" + b"\x01\x00\x00\x00" + struct.pack("<d", 3.0)
+    s += b"\x02\x00\x00\x00" + b"\x05\x00\x00\x00train" + b"\x05\x00\x00\x00" + b"\x00\x00\x00\x00"   # boolean false
+    # weight: torch.FloatTensor 64 x 3 x 3 x 3, contiguous, storage offset 1 (= element 0)
+    s += b"\x02\x00\x00\x00" + b"\x06\x00\x00\x00weight"
+    s += b"\x04\x00\x00\x00" + b"\x06\x00\x00\x00" + b"\x03\x00\x00\x00V 1" + b"\x11\x00\x00\x00torch.FloatTensor"   # index 6, name length 17
+    s += b"\x04\x00\x00\x00"                                             # nDimension 4
+    s += struct.pack("<4q", 64, 3, 3, 3) + struct.pack("<4q", 27, 9, 3, 1) + struct.pack("<q", 1)
+    s += b"\x04\x00\x00\x00" + b"\x07\x00\x00\x00" + b"\x03\x00\x00\x00V 1" + b"\x12\x00\x00\x00torch.FloatStorage"  # index 7, name length 18
+    s += struct.pack("<q", 1728) + weight.astype("<f4").tobytes()
+    # bias: torch.FloatTensor 64
+    s += b"\x02\x00\x00\x00" + b"\x04\x00\x00\x00bias"
+    s += b"\x04\x00\x00\x00" + b"\x08\x00\x00\x00" + b"\x03\x00\x00\x00V 1" + b"\x11\x00\x00\x00torch.FloatTensor"   # index 8
+    s += b"\x01\x00\x00\x00" + struct.pack("<q", 64) + struct.pack("<q", 1) + struct.pack("<q", 1)
+    s += b"\x04\x00\x00\x00" + b"\x09\x00\x00\x00" + b"\x03\x00\x00\x00V 1" + b"\x12\x00\x00\x00torch.FloatStorage"  # index 9
+    s += struct.pack("<q", 64) + bias.astype("<f4").tobytes()
+    path = tmp_path / "hand.t7"
+    path.write_bytes(s)
+    seq = t7.load(str(path))
+    assert seq.torch_typename == "nn.Sequential"
+    conv = seq.modules[1]
+    assert conv.torch_typename == "nn.SpatialConvolution" and conv.kW == 3 and conv.kH == 3 and conv.train is False
+    assert conv.weight.shape == (64, 3, 3, 3) and conv.weight.dtype == np.float32 and conv.bias.shape == (64,)
+    assert np.array_equal(conv.weight.reshape(-1), weight) and np.array_equal(conv.bias, bias)
+    (idx, w, b), = t7.sequential_convs(seq)                 # `model.get(0)` of utils.py:64-67
+    assert idx == 0 and np.array_equal(w, weight.reshape(64, 3, 3, 3)) and np.array_equal(b, bias)
+    # and the same stream from a 32-bit torch (longs are 4 bytes: load_lua's long_size = 4) is read through the reader's second attempt
+    s32 = s.replace(struct.pack("<4q", 64, 3, 3, 3) + struct.pack("<4q", 27, 9, 3, 1) + struct.pack("<q", 1),
+                    struct.pack("<4i", 64, 3, 3, 3) + struct.pack("<4i", 27, 9, 3, 1) + struct.pack("<i", 1))
+    s32 = s32.replace(struct.pack("<q", 1728) + weight.tobytes(), struct.pack("<i", 1728) + weight.tobytes())
+    s32 = s32.replace(b"\x01\x00\x00\x00" + struct.pack("<q", 64) + struct.pack("<q", 1) + struct.pack("<q", 1),
+                      b"\x01\x00\x00\x00" + struct.pack("<i", 64) + struct.pack("<i", 1) + struct.pack("<i", 1))
+    s32 = s32.replace(struct.pack("<q", 64) + bias.tobytes(), struct.pack("<i", 64) + bias.tobytes())
+    (tmp_path / "hand32.t7").write_bytes(s32)
+    seq32 = t7.load(str(tmp_path / "hand32.t7"))
+    assert np.array_equal(seq32.modules[1].weight.reshape(-1), weight) and np.array_equal(seq32.modules[1].bias, bias)

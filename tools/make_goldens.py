@@ -576,6 +576,37 @@ def gen_g15(which=("noise", "natural")):
         print("G15 %s: mean %.6f std %.6f max %.4f (%.0f s)" % (kind, g["mean"], g["std"], g["max"], time.time() - t0), flush=True)
 
 
+G16_CROPS = ((0, 0), (416, 10144), (200, 1232), (100, 2512), (416, 5072), (0, 6352), (300, 7632), (150, 8912))
+
+
+def gen_g16():
+    """G16 (round 5): config 4's GEOMETRY through the reference itself -- a 10240-wide x 512-tall content (BASELINE configs[3]'s width:
+    eight 1280-column strips, every level's halo 160/72/24/10/2 inside one strip; a fifth of a megapixel-row budget the reference
+    finishes in ~2 min here), numpy.random.default_rng(5).random((3, 512, 10240), float32), + the config-2/4 style (default_rng(2),
+    2048x2048), util_wct.WCT with the real 16x checkpoints on torch CPU, WCT.py:120-125 restated.  Six of the eight crops straddle
+    strip boundaries (x = 1280 k).  Gated in tests/test_sharded_gpu.py: the untiled frame AND the 8 x 1280 exchange-halo job against
+    these pixels."""
+    import time
+    torch.set_num_threads(8)
+    util_wct = import_reference()
+    wct = util_wct.WCT(ref_args("16x", 1.0))
+    s = np.random.default_rng(2).random((3, 2048, 2048), dtype=np.float32)
+    c = np.random.default_rng(5).random((3, 512, 10240), dtype=np.float32)
+    t0 = time.time()
+    img = t(c[None])
+    for k in (5, 4, 3, 2, 1):
+        img = ref_style_transfer(wct, getattr(wct, "e%d" % k), getattr(wct, "d%d" % k), img, t(s[None]), 1.0)
+        print("G16: level %d done, %.0f s" % (k, time.time() - t0), flush=True)
+    y = img.squeeze(0).numpy()
+    assert y.shape == (3, 512, 10240) and np.isfinite(y).all()
+    g = pack_frame_fixture(y, G16_CROPS)
+    g["content.checksum"] = np.float64(c.sum(dtype=np.float64))
+    g["style.checksum"] = np.float64(s.sum(dtype=np.float64))
+    g["torch"] = np.array(torch.__version__)
+    np.savez_compressed(os.path.join(GOLD, "g16_cfg4_geometry.npz"), **g)
+    print("G16: mean %.6f std %.6f max %.4f  (%.0f s)" % (g["mean"], g["std"], g["max"], time.time() - t0), flush=True)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 2 and sys.argv[1] == "--only" and sys.argv[2] == "g12":
         os.makedirs(GOLD, exist_ok=True)
@@ -583,6 +614,7 @@ if __name__ == "__main__":
         gen_g13()
         gen_g14()
         gen_g15()
+        gen_g16()
     elif len(sys.argv) > 2 and sys.argv[1] == "--only" and sys.argv[2] == "g13":
         os.makedirs(GOLD, exist_ok=True)
         gen_g13(tuple(sys.argv[3:]) or ("noise", "smooth"))
@@ -592,6 +624,9 @@ if __name__ == "__main__":
     elif len(sys.argv) > 2 and sys.argv[1] == "--only" and sys.argv[2] == "g15":
         os.makedirs(GOLD, exist_ok=True)
         gen_g15(tuple(sys.argv[3:]) or ("noise", "natural"))
+    elif len(sys.argv) > 2 and sys.argv[1] == "--only" and sys.argv[2] == "g16":
+        os.makedirs(GOLD, exist_ok=True)
+        gen_g16()
     elif len(sys.argv) > 2 and sys.argv[1] == "--only" and sys.argv[2] == "g11":
         os.makedirs(GOLD, exist_ok=True)
         gen_g11()
@@ -610,3 +645,4 @@ if __name__ == "__main__":
         gen_g13()
         gen_g14()
         gen_g15()
+        gen_g16()
