@@ -222,11 +222,21 @@ while True:
         import glob
         import subprocess
         self.proc, self.t0 = None, None
-        cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device"))
-        cards = [c for c in cards if glob.glob(c + "/hwmon/hwmon*")]
-        if not cards:
-            return
-        dev = cards[min(device_index, len(cards) - 1)]
+        # the box may expose many amdgpu cards (partitions of a multi-GPU host): find THIS device's sysfs node through its PCI address
+        dev = None
+        try:
+            pr = torch.cuda.get_device_properties(device_index)
+            addr = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+            if glob.glob("/sys/bus/pci/devices/%s/hwmon/hwmon*" % addr):
+                dev = "/sys/bus/pci/devices/%s" % addr
+            self.pci = addr
+        except Exception:     # noqa: BLE001
+            self.pci = None
+        if dev is None:
+            cards = [c for c in sorted(glob.glob("/sys/class/drm/card[0-9]*/device")) if glob.glob(c + "/hwmon/hwmon*")]
+            if len(cards) != 1:          # several candidates and no PCI match: a wrong card's numbers are worse than none
+                return
+            dev = cards[0]
         try:
             self.proc = subprocess.Popen([sys.executable, "-c", self.CHILD, dev], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
             self.files = self.proc.stdout.readline().split()[1:]
@@ -253,7 +263,7 @@ while True:
         col = lambda i, scale: [r[i] * scale for r in rows if r[i] >= 0]   # noqa: E731
         pw, sclk, mclk, temp = col(1, 1e-6), col(2, 1e-6), col(3, 1e-6), col(4, 1e-3)
         avg = lambda v: round(sum(v) / len(v), 1) if v else None   # noqa: E731
-        return {"source": "amdgpu sysfs hwmon (power1_average | power1_input, freq1_input, freq2_input, temp), %d samples at ~2 ms during the timed steps" % len(rows),
+        return {"source": "amdgpu sysfs hwmon of PCI device %s (power1_average | power1_input, freq1_input, freq2_input, temp), %d samples at ~2 ms during the timed steps" % (self.pci, len(rows)),
                 "power_W_avg": avg(pw), "power_W_max": round(max(pw), 1) if pw else None, "sclk_MHz_avg": avg(sclk),
                 "sclk_MHz_min": round(min(sclk), 1) if sclk else None, "mclk_MHz_avg": avg(mclk), "temp_C_avg": avg(temp)}
 
