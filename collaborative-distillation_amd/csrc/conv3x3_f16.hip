@@ -818,6 +818,13 @@ struct TailGeo {
   static_assert(NPI % 16 == 0 && (NPI * 16) % 256 == 0 && (NPX * 16) % 256 == 0, "plane strides");
 };
 template <int TH> struct TailRegs { f32x4 v0[TailGeo<TH>::SL], v1[TailGeo<TH>::SL]; };
+// thread slot e -> (window pixel, 8-channel half).  The half sits on bit 3, not bit 0 (rounds 2-4): the 8 contiguous lanes of a
+// ds_write_b128 group then write 8 consecutive 16-byte slots of ONE plane (128 contiguous bytes, conflict-free) instead of 4 slots in
+// each of two planes whose stride is a multiple of the 128-byte bank row (2-way conflict on every window store).  The global side
+// still reads whole 64-byte pixel records per wave-instruction (the two halves of a pixel are 8 lanes apart).  Pixel counts are
+// multiples of 8 (or padded to one), so this is a bijection onto [0, pixels) x {0, 1}.
+__device__ __forceinline__ int tail_slot_pix(int e) { return (e & 7) | ((e >> 4) << 3); }
+__device__ __forceinline__ int tail_slot_half(int e) { return (e >> 3) & 1; }
 
 // soff[k]: tile-independent element offset of slot k from the window origin, valid for interior tiles (the window
 // origin (ty0 - 2, tx0 - 2) is even, so the nearest-x2 shift distributes over origin + offset)
@@ -840,7 +847,7 @@ __device__ __forceinline__ void tail_fetch(const TailArgs& a, unsigned txm, Tail
   for (int k = 0; k < G::SL; ++k) {
     int e = tid + G::NT * k;
     e = e < G::NPI * 2 ? e : G::NPI * 2 - 1;
-    const int h2 = e & 1, pix = e >> 1;
+    const int h2 = tail_slot_half(e), pix = tail_slot_pix(e);
     const int py = pix / I2W, px = pix - py * I2W;
     int gy = reflect_clamp(ty0 - 2 + py, a.H), gx = reflect_clamp(tx0 - 2 + px, a.W);
     if (a.up_in) { gy >>= 1; gx >>= 1; }
@@ -860,8 +867,8 @@ __device__ __forceinline__ void tail_commit(const TailRegs<TH>& r, u32x4* act0, 
       f16x8 hi, lo;
       if (in_sp) { hi = __builtin_bit_cast(f16x8, r.v0[k]); lo = __builtin_bit_cast(f16x8, r.v1[k]); }
       else split8(r.v0[k], r.v1[k], hi, lo, sat);
-      act0[(0 * 2 + (e & 1)) * G::NPI + (e >> 1)] = __builtin_bit_cast(u32x4, hi);
-      act0[(1 * 2 + (e & 1)) * G::NPI + (e >> 1)] = __builtin_bit_cast(u32x4, lo);
+      act0[(0 * 2 + tail_slot_half(e)) * G::NPI + tail_slot_pix(e)] = __builtin_bit_cast(u32x4, hi);
+      act0[(1 * 2 + tail_slot_half(e)) * G::NPI + tail_slot_pix(e)] = __builtin_bit_cast(u32x4, lo);
     }
   }
 }
@@ -895,8 +902,8 @@ __global__ __launch_bounds__(32 * TH, TH == 8 ? 2 : 1) void dec_tail_kernel(Tail
   for (int k = 0; k < SL; ++k) {
     int e = tid + NT * k;
     e = e < NPI * 2 ? e : NPI * 2 - 1;
-    const int pix = e >> 1, py = pix / I2W, px = pix - py * I2W;
-    soff[k] = ((py >> a.up_in) * a.inW + (px >> a.up_in)) * 16 + (e & 1) * 8;
+    const int pix = tail_slot_pix(e), py = pix / I2W, px = pix - py * I2W;
+    soff[k] = ((py >> a.up_in) * a.inW + (px >> a.up_in)) * 16 + tail_slot_half(e) * 8;
   }
   // the wave's NG 16-pixel groups of the 34 x (TH + 2) halo (22 groups over 4 waves / 39 over 8: the last ones may not exist)
   int gpix[NG], gpy[NG], gpx[NG], gslot[NG];
@@ -1000,7 +1007,7 @@ struct TailUpGeo {
   static constexpr int HROWS = TH + 2, NROWG = 2 * HROWS, NLEFT = 4 * ((HROWS / 2 + 15) / 16), NGRP = NROWG + NLEFT, NG = (NGRP + NWV - 1) / NWV;
   static constexpr int LW = FTW / 2 + 2, LH = TH / 2 + 2, NPL = (LW * LH + 15) / 16 * 16;     // low-resolution window 18 x (TH / 2 + 2): 256 / 192 / 112 slots
   static constexpr int NPX = (HROWS * PH_W + 15) / 16 * 16;
-  static_assert(NWV % 4 == 0 && NROWG % 4 == 0 && 2 * LW * LH <= NT, "phase-uniform waves; one (pixel, channel half) slot per thread");
+  static_assert(NWV % 4 == 0 && NROWG % 4 == 0 && 2 * ((LW * LH + 7) / 8 * 8) <= NT, "phase-uniform waves; one (pixel, channel half) slot per thread");
   // (the two leftover columns' rows of one parity: HROWS / 2 pixels per (column, parity) = one group of 16, or two at TH = 32)
   static constexpr size_t lds = ((size_t)4 * NPL + PH_WSLOTS + (size_t)4 * NPX) * 16;           // 93.2 / 66.6 / 47.1 KB
 };
@@ -1029,9 +1036,12 @@ __global__ __launch_bounds__(32 * TH, TH <= 16 ? 2 : 1) void dec_tail_up_kernel(
   const size_t plane = (size_t)a.H * a.W;
   const int inH = a.H >> 1;
 
-  // this thread's slot of the low-resolution window: pixel e >> 1, channel half e & 1
-  const int fe = tid < 2 * LW * LH ? tid : 2 * LW * LH - 1;
-  const int fpix = fe >> 1, fpy = fpix / LW, fpx = fpix - fpy * LW, fh = fe & 1;
+  // this thread's slot of the low-resolution window: (pixel, channel half) = tail_slot_*(tid) over the pixel count padded to a multiple
+  // of 8 (pixels beyond the window: a clamped fetch, stored to spare slots behind the window that nobody reads)
+  constexpr int NWPIX = LW * LH, NWPAD = (NWPIX + 7) / 8 * 8;
+  static_assert(2 * NWPAD <= NT && NWPAD <= NPL, "one (pixel, channel half) slot per thread, spare slots inside the plane");
+  const int fe = tid < 2 * NWPAD ? tid : 2 * NWPAD - 1;
+  const int fslot = tail_slot_pix(fe), fpix = fslot < NWPIX ? fslot : NWPIX - 1, fpy = fpix / LW, fpx = fpix - fpy * LW, fh = tail_slot_half(fe);
   const int soff = (fpy * a.inW + fpx) * 16 + fh * 8;
   // the wave's halo groups
   int gpy[NG], gpx[NG], gslot[NG], gbase[NG];
@@ -1066,12 +1076,12 @@ __global__ __launch_bounds__(32 * TH, TH <= 16 ? 2 : 1) void dec_tail_up_kernel(
     r1 = *reinterpret_cast<const f32x4*>(src + 4);
   };
   auto commit = [&]() {
-    if (tid < 2 * LW * LH) {
+    if (tid < 2 * NWPAD) {
       f16x8 hi, lo;
       if (a.in_sp) { hi = __builtin_bit_cast(f16x8, r0); lo = __builtin_bit_cast(f16x8, r1); }
       else split8(r0, r1, hi, lo, sat);
-      act0[(0 * 2 + fh) * NPL + fpix] = __builtin_bit_cast(u32x4, hi);
-      act0[(1 * 2 + fh) * NPL + fpix] = __builtin_bit_cast(u32x4, lo);
+      act0[(0 * 2 + fh) * NPL + fslot] = __builtin_bit_cast(u32x4, hi);
+      act0[(1 * 2 + fh) * NPL + fslot] = __builtin_bit_cast(u32x4, lo);
     }
   };
   int v = blockIdx.x;

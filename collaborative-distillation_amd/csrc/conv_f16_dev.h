@@ -285,8 +285,25 @@ __device__ __forceinline__ void store_split4(u32x4* planes, int npp, int pix, in
     { const HiLo t_ = split2(clamp_pm(v[0]), clamp_pm(v[1])); h[0] = t_.hi; l[0] = t_.lo; }
     { const HiLo t_ = split2(clamp_pm(v[2]), clamp_pm(v[3])); h[1] = t_.hi; l[1] = t_.lo; }
   }
+#ifndef WCT_SS4_SWAP
+  // two 8-byte stores per lane.  A ds_write_b64 is serviced in contiguous 16-lane groups against 32 banks: 16 lanes writing the SAME
+  // half of 16 consecutive 16-byte slots cover every bank twice -- a 2-way conflict on every store of this function, the largest
+  // single source of the 23-26 % conflict share in profiles/r04b_sq_counters_fused_ends.txt.  The conflict-free form below was built
+  // and measured in round 5 and LOST: it is kept only as the record of that experiment.
   *(reinterpret_cast<u32x2*>(planes + (0 * 2 + (kq >> 1)) * npp + pix) + (kq & 1)) = h;
   *(reinterpret_cast<u32x2*>(planes + (1 * 2 + (kq >> 1)) * npp + pix) + (kq & 1)) = l;
+#else
+  // round 5 experiment (-DWCT_SS4_SWAP): lanes (li, kq) and (li, kq ^ 1) -- 16 lanes apart, the same pixel -- trade halves through
+  // v_permlane16_swap (the 16x16 counterpart of sp16_pair_exchange): the even row keeps both hi halves, the odd row both lo halves, and
+  // each lane writes ONE 16-byte slot; ds_write_b128 groups are 8 contiguous lanes = 128 contiguous bytes: conflict-free, half the
+  // LDS store instructions, bit-identical results.  Same-box A/B (profiles/r05_lds_conflict_ab.txt): SQ_WAIT_INST_LDS of dec_tail_up
+  // 34.6 M -> 12.3 M quad-cycles -- and the kernel 26 % SLOWER (0.464 -> 0.584 ms per step; enc_head 1.034 -> 1.046, l1_decode
+  // unchanged): the two cross-lane swaps sit between the MFMA result and the store in every group's dependent chain, and a 16-byte
+  // LDS store occupies the VGPR -> LDS path for 13 cycles against 2 x 6.  The conflicts were never what these kernels wait for.
+  const auto ra = __builtin_amdgcn_permlane16_swap(h[0], l[0], false, false);
+  const auto rb = __builtin_amdgcn_permlane16_swap(h[1], l[1], false, false);
+  planes[((kq & 1) * 2 + (kq >> 1)) * npp + pix] = u32x4{ra[0], rb[0], ra[1], rb[1]};
+#endif
 }
 
 // 16->16 conv on the [4][NPP] planes of a 34 x 10 halo tile for the wave's 2 rows x 32 px (the c16 kernel's body)

@@ -106,9 +106,10 @@ __device__ __forceinline__ void tile_steps3(const float* lds, int Cs, int st0, i
   }
 }
 
-// two pairs (l1_moments_kernel's packed tiling of 24 channels)
+// two pairs (l1_moments_kernel's packed tiling of 24 channels).  oa / ob: [pair][parity of the step u] column offsets of the lane -- two
+// sets because l1_moments_kernel's feature tile XOR-swizzles its columns with bits of the pixel index (see there); st0 is a multiple of 4.
 template <bool F32>
-__device__ __forceinline__ void tile_steps2(const float* lds, int Cs, int st0, int st1, int pk, int oa0, int ob0, int oa1, int ob1,
+__device__ __forceinline__ void tile_steps2(const float* lds, int Cs, int st0, int st1, int pk, const int (&oa)[2][2], const int (&ob)[2][2],
                                             f64x4& c0, f64x4& c1, double& s0, double& s1) {
   if constexpr (F32) {
     for (int sb = st0; sb < st1; sb += MOM32_FLUSH) {
@@ -120,8 +121,8 @@ __device__ __forceinline__ void tile_steps2(const float* lds, int Cs, int st0, i
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const float* row = lds + ((st + u) * 4 + pk) * Cs;
-          av[u][0] = row[oa0]; bv[u][0] = row[ob0];
-          av[u][1] = row[oa1]; bv[u][1] = row[ob1];
+          av[u][0] = row[oa[0][u & 1]]; bv[u][0] = row[ob[0][u & 1]];
+          av[u][1] = row[oa[1][u & 1]]; bv[u][1] = row[ob[1][u & 1]];
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -141,8 +142,8 @@ __device__ __forceinline__ void tile_steps2(const float* lds, int Cs, int st0, i
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const float* row = lds + ((st + u) * 4 + pk) * Cs;
-      av[u][0] = row[oa0]; bv[u][0] = row[ob0];
-      av[u][1] = row[oa1]; bv[u][1] = row[ob1];
+      av[u][0] = row[oa[0][u & 1]]; bv[u][0] = row[ob[0][u & 1]];
+      av[u][1] = row[oa[1][u & 1]]; bv[u][1] = row[ob[1][u & 1]];
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -326,6 +327,21 @@ __global__ __launch_bounds__(256, 2) void l1_moments_kernel(L1MomArgs a) {
   //              and a duplicate of part of tile (0,0) that is dropped
   // -- a third less work on the fp64 matrix cores, which bound this kernel.  The partials leave in the standard three-tile format.
   const int oa1 = 8 + li, ob1 = li < 8 ? 16 + li : li - 8;
+  // LDS layout of the feature tile (round 5): row stride Cs = 48 floats and column c of pixel p stored at c ^ (((p >> 1) & 3) << 2).
+  //   reads (ds_read_b32, groups of 32 lanes = rows pk in {0, 1} or {2, 3} x 16 columns): 48 p mod 32 = 16 (p & 1) puts the two rows of a
+  //     group on opposite halves of the 32 banks, and the XOR (uniform within a group: (p >> 1) & 3 is the same for rows 4k + {0, 1} and for
+  //     4k + {2, 3}) permutes columns inside their aligned 16-blocks -- conflict-free.  With the former stride 44 every read was a 2-way
+  //     conflict (rows 44 apart: banks 0-15 against 12-27): profiles/r04b_sq_counters_fused_ends.txt, 26 % of this kernel's LDS cycles.
+  //   writes (ds_write_b128, groups of 8 neighbouring pixels of a row): 16-byte slot index mod 8 = 4 ((px & 1) ^ ct) + (kq ^ ((px >> 1) & 3)):
+  //     eight distinct slots of the 128-byte bank row -- conflict-free (a plain stride of 48 would be 4-way: why rounds 3-4 kept 44).
+  // Row p = 4 (st + u) + pk of the pair loop (st a multiple of 4): (p >> 1) & 3 = pk >> 1 for even u, 2 + (pk >> 1) for odd u.
+#ifdef WCT_L1MOM_CS44
+  constexpr bool L1M_SWZ = false;
+#else
+  constexpr bool L1M_SWZ = true;
+#endif
+  const int sw0 = L1M_SWZ ? (kq >> 1) << 2 : 0, sw1 = L1M_SWZ ? (2 + (kq >> 1)) << 2 : 0;
+  const int oa[2][2] = {{li ^ sw0, li ^ sw1}, {oa1 ^ sw0, oa1 ^ sw1}}, ob[2][2] = {{li ^ sw0, li ^ sw1}, {ob1 ^ sw0, ob1 ^ sw1}};
   f64x4 acc[2];
   double s[2];
 #pragma unroll
@@ -366,11 +382,11 @@ __global__ __launch_bounds__(256, 2) void l1_moments_kernel(L1MomArgs a) {
         l1_conv_pair(imgH, base, w, xs[0], xs[1]);
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct)
-          *reinterpret_cast<f32x4*>(feat + (py * 32 + px) * a.Cs + ct * 16 + 4 * kq) = in ? xs[ct] : f32x4{0.f, 0.f, 0.f, 0.f};
+          *reinterpret_cast<f32x4*>(feat + (py * 32 + px) * a.Cs + ((ct * 16 + 4 * kq) ^ (L1M_SWZ ? ((px >> 1) & 3) << 2 : 0))) = in ? xs[ct] : f32x4{0.f, 0.f, 0.f, 0.f};
       }
     __syncthreads();
     const int st0 = wave * (MP / 16);
-    tile_steps2<F32>(feat, a.Cs, st0, st0 + MP / 16, kq, li, li, oa1, ob1, acc[0], acc[1], s[0], s[1]);
+    tile_steps2<F32>(feat, a.Cs, st0, st0 + MP / 16, kq, oa, ob, acc[0], acc[1], s[0], s[1]);
     if (vn < ntiles) { head_pin(pxr); head_commit(pxr, imgH, imgL, tid, sat); }
   }
   sat.commit(a.sat);
@@ -530,7 +546,11 @@ hipError_t launch_l1_moments(const ConvDesc& e, const float* img, int H, int W, 
   // LDS row stride of the feature tile (floats).  44: the 16-byte conv11 stores of eight neighbouring pixels fall on distinct banks (48
   // made them 4-way conflicts: 64 LDS cycles per store pair instead of 16) at the price of 2-way conflicts on the pair loop's 4-byte
   // reads (model: 320 vs 416 LDS cycles per wave and tile; measured -6 %)
+#ifdef WCT_L1MOM_CS44
   a.Cs = 44;
+#else
+  a.Cs = 48;      // with the kernel's column swizzle: reads and writes free of bank conflicts (l1_moments_kernel)
+#endif
   a.sat = e.sat;
   const int ntiles = a.tiles_x * a.tiles_y, grid = ntiles < 2 * num_cus() ? ntiles : 2 * num_cus();
   a.part_sq = reinterpret_cast<double*>(ws);
