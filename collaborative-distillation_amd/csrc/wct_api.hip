@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <atomic>
 #include <cstring>
+#include <dlfcn.h>
 #include <map>
 #include <string>
 #include <vector>
@@ -118,11 +119,30 @@ struct wct_ctx {
   // sat_dev is a 256-byte block of counters (unsigned): [0] the saturation counter; [1] its snapshot at the start of a deferred
   // wide-model call (with_deferred_solves); [2], [3] single-launch Newton-Schulz solves that ABORTED on the main / side lane
   unsigned* sat_host = nullptr;  // pinned host mirror, refreshed asynchronously at the end of every compute entry point (wct_range_poll)
+  // RCCL communicator of a column-sharded job (wct_comm_*, wct_level_sharded); the library resolves RCCL at run time (no link-time dependency)
+  void* comm = nullptr;
+  bool comm_owned = false;
+  int comm_ranks = 0, comm_rank = 0;
+  DevBuf packed;      // wct_level_sharded: [sum C | sumsq C*C | range flag] fp64, all-reduced in place
   // profiling
   bool prof = false;
   std::vector<ProfRec> recs;
   std::map<std::string, wct_prof_entry> prof_acc;
 };
+
+// RCCL, resolved at run time (wct_comm_load): the library keeps no link-time dependency on it
+struct NcclUid { char b[128]; };      // nccl.h ncclUniqueId: 128 opaque bytes, passed BY VALUE to ncclCommInitRank
+struct RcclApi {
+  void* lib = nullptr;
+  int (*GetUniqueId)(void*) = nullptr;
+  int (*CommInitRank)(void**, int, NcclUid, int) = nullptr;
+  int (*CommDestroy)(void*) = nullptr;
+  int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+  std::string path;
+};
+static RcclApi g_rccl;
+constexpr int NCCL_FLOAT64 = 8, NCCL_SUM = 0;    // nccl.h: ncclDataType_t ncclFloat64 = 8, ncclRedOp_t ncclSum = 0
 
 namespace {
 
@@ -1003,6 +1023,8 @@ void wct_destroy(wct_ctx* ctx) {
 
   if (ctx->side.stream) (void)hipStreamDestroy(ctx->side.stream);
   if (ctx->sat_dev) (void)hipFree(ctx->sat_dev);
+  if (ctx->comm && ctx->comm_owned && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(ctx->comm);
+  release(ctx->packed);
   if (ctx->sat_host) (void)hipHostFree(ctx->sat_host);
   if (ctx->ok_log) (void)hipFree(ctx->ok_log);
   if (ctx->ok_host) (void)hipHostFree(ctx->ok_host);
@@ -1504,6 +1526,113 @@ int wct_content_decode(wct_ctx* ctx, int level, const double* M, const double* b
   if (Ho) *Ho = ctx->cur_h << (level - 1);
   if (Wo) *Wo = ctx->cur_w << (level - 1);
   return range_readback(ctx);
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// RCCL inside the boundary ("multi-GPU variant takes an ncclComm_t").  One level of a column-sharded cascade is ONE call:
+// encoder + raw moments over the owned feature columns -> ncclAllReduce(SUM, fp64) of [sum | sumsq | range flag] on the context's
+// stream -> matrix functions against the level's (imported) style statistics -> fold -> decoder.  RCCL's entry points are looked up
+// at run time in the librccl the host process names (wct_comm_load; the Python mirror passes the one torch has loaded), so the
+// library links against nothing new and single-GPU users never touch RCCL.
+namespace {
+int rccl_ready(wct_ctx* ctx) {
+  if (g_rccl.AllReduce) return WCT_OK;
+  return fail(ctx, WCT_ERR_STATE, "RCCL is not loaded: call wct_comm_load(path of librccl.so) first");
+}
+}  // namespace
+
+int wct_comm_load(const char* path) {
+  if (g_rccl.AllReduce) return WCT_OK;
+  const char* cands[] = {path, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so"};
+  void* h = nullptr;
+  for (const char* c : cands) {
+    if (!c || !*c) continue;
+    h = dlopen(c, RTLD_NOW | RTLD_LOCAL);      // a library the process has already mapped is reused, not loaded twice
+    if (h) { g_rccl.path = c; break; }
+  }
+  if (!h) return WCT_ERR_STATE;
+  g_rccl.lib = h;
+  g_rccl.GetUniqueId = reinterpret_cast<decltype(g_rccl.GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
+  g_rccl.CommInitRank = reinterpret_cast<decltype(g_rccl.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
+  g_rccl.CommDestroy = reinterpret_cast<decltype(g_rccl.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
+  g_rccl.GetErrorString = reinterpret_cast<decltype(g_rccl.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+  auto ar = reinterpret_cast<decltype(g_rccl.AllReduce)>(dlsym(h, "ncclAllReduce"));
+  if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy || !ar) { g_rccl = RcclApi(); return WCT_ERR_STATE; }
+  g_rccl.AllReduce = ar;
+  return WCT_OK;
+}
+
+int wct_comm_unique_id(unsigned char* id128) {
+  if (!g_rccl.AllReduce || !id128) return WCT_ERR_STATE;
+  return g_rccl.GetUniqueId(id128) == 0 ? WCT_OK : WCT_ERR_HIP;
+}
+
+int wct_comm_init(wct_ctx* ctx, int nranks, int rank, const unsigned char* id128) {
+  if (!ctx) return WCT_ERR_INVALID;
+  WCT_GUARD(ctx);
+  if (int rc = rccl_ready(ctx)) return rc;
+  if (!id128 || nranks < 1 || rank < 0 || rank >= nranks) return fail(ctx, WCT_ERR_INVALID, "comm_init: bad arguments (nranks %d, rank %d)", nranks, rank);
+  if (ctx->comm) return fail(ctx, WCT_ERR_STATE, "comm_init: the context already has a communicator");
+  NcclUid uid;
+  memcpy(uid.b, id128, 128);
+  void* comm = nullptr;
+  const int r = g_rccl.CommInitRank(&comm, nranks, uid, rank);     // collective over the job's ranks; the context's device is current
+  if (r != 0 || !comm) return fail(ctx, WCT_ERR_HIP, "ncclCommInitRank(%d ranks, rank %d): %s", nranks, rank, g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "error");
+  ctx->comm = comm; ctx->comm_owned = true; ctx->comm_ranks = nranks; ctx->comm_rank = rank;
+  return WCT_OK;
+}
+
+int wct_comm_attach(wct_ctx* ctx, void* nccl_comm, int nranks, int rank) {
+  if (!ctx) return WCT_ERR_INVALID;
+  WCT_GUARD(ctx);
+  if (int rc = rccl_ready(ctx)) return rc;
+  if (!nccl_comm || nranks < 1 || rank < 0 || rank >= nranks) return fail(ctx, WCT_ERR_INVALID, "comm_attach: bad arguments");
+  if (ctx->comm) return fail(ctx, WCT_ERR_STATE, "comm_attach: the context already has a communicator");
+  ctx->comm = nccl_comm; ctx->comm_owned = false; ctx->comm_ranks = nranks; ctx->comm_rank = rank;
+  return WCT_OK;
+}
+
+int wct_comm_destroy(wct_ctx* ctx) {
+  if (!ctx) return WCT_ERR_INVALID;
+  WCT_GUARD(ctx);
+  if (ctx->comm && ctx->comm_owned && g_rccl.CommDestroy) {
+    (void)hipStreamSynchronize(ctx->main.stream);
+    (void)g_rccl.CommDestroy(ctx->comm);
+  }
+  ctx->comm = nullptr; ctx->comm_owned = false; ctx->comm_ranks = 0; ctx->comm_rank = 0;
+  return WCT_OK;
+}
+
+int wct_level_sharded(wct_ctx* ctx, int level, const float* content, int H, int W, int x0, int x1, double n_total, float alpha,
+                      float* out, int* Ho, int* Wo, double* range_total) {
+  if (!ctx) return WCT_ERR_INVALID;
+  WCT_GUARD(ctx);
+  if (int rc = rccl_ready(ctx)) return rc;
+  if (!ctx->comm) return fail(ctx, WCT_ERR_STATE, "level_sharded: no communicator (wct_comm_init / wct_comm_attach)");
+  if (!valid_level(level) || !content || !out || !(n_total >= 1.0)) return fail(ctx, WCT_ERR_INVALID, "level_sharded: bad arguments");
+  Module& me = ctx->mod[WCT_KIND_ENC][level];
+  if (!me.loaded) return fail(ctx, WCT_ERR_STATE, "encoder %d not loaded", level);
+  if (ctx->wide_model) return fail(ctx, WCT_ERR_STATE, "level_sharded: the wide models' deferred solves synchronise the host per call; use the split-level entries");
+  if (!ctx->eigS[level].p) return fail(ctx, WCT_ERR_STATE, "level_sharded: no style statistics for level %d (wct_style_prepare / wct_style_import)", level);
+  const int C = me.layers.back().d.cout;
+  const size_t npk = (size_t)C * C + C + 1;
+  if (int rc = ensure(ctx, ctx->packed, npk * sizeof(double))) return rc;
+  double* pk = reinterpret_cast<double*>(ctx->packed.p);
+  // the four steps below are wct_content_encode / wct_range_flag_f64 / [all-reduce] / wct_content_solve / wct_content_decode in this order,
+  // on the same buffers' worth of arithmetic: results are those of the split-level path bit for bit (tests/test_sharded_gpu.py)
+  int h = 0, w = 0;
+  if (int rc = wct_content_encode(ctx, level, content, H, W, x0, x1, pk, pk + C, &h, &w)) return rc;
+  HIPCHK(ctx, launch_counter_to_f64(ctx->sat_dev, pk + C + (size_t)C * C, ctx->main.stream));
+  {
+    const int r = g_rccl.AllReduce(pk, pk, npk, NCCL_FLOAT64, NCCL_SUM, ctx->comm, ctx->main.stream);
+    if (r != 0) return fail(ctx, WCT_ERR_HIP, "ncclAllReduce(%zu doubles): %s", npk, g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "error");
+  }
+  if (range_total) HIPCHK(ctx, hipMemcpyAsync(range_total, pk + C + (size_t)C * C, sizeof(double), hipMemcpyDeviceToDevice, ctx->main.stream));
+  double *M, *b;
+  if (int rc = mb_view(ctx, &M, &b)) return rc;
+  if (int rc = wct_content_solve(ctx, level, n_total, pk, pk + C, alpha, M, b)) return rc;
+  return wct_content_decode(ctx, level, M, b, out, Ho, Wo);
 }
 
 namespace {

@@ -22,6 +22,7 @@ SYMBOLS = [
     "wct_load_module", "wct_feature_shape", "wct_encode", "wct_decode", "wct_moments", "wct_solve",
     "wct_apply", "wct_transform", "wct_decode_affine", "wct_style_transfer_level", "wct_stylize",
     "wct_style_prepare", "wct_content_encode", "wct_content_solve", "wct_content_decode",
+    "wct_comm_load", "wct_comm_unique_id", "wct_comm_init", "wct_comm_attach", "wct_comm_destroy", "wct_level_sharded",
     "wct_style_prepare_levels", "wct_style_stats_count", "wct_style_export", "wct_style_import", "wct_stylize_prepared",
     "wct_u8_to_planar", "wct_planar_to_u8", "wct_stylize_u8", "wct_resize_shape", "wct_resize_u8", "wct_resize_u8_to_planar",
     "wct_workspace_bytes", "wct_reserve", "wct_set_conv_mode", "wct_set_numpy_variant", "wct_set_overlap", "wct_profile_enable", "wct_profile_reset", "wct_profile_read",
@@ -90,6 +91,12 @@ def load() -> ctypes.CDLL:
     lib.wct_content_encode.argtypes = [c_void_p, c_int, vp, c_int, c_int, c_int, c_int, vp, vp, ip, ip]
     lib.wct_content_solve.argtypes = [c_void_p, c_int, c_double, vp, vp, c_float, vp, vp]
     lib.wct_content_decode.argtypes = [c_void_p, c_int, vp, vp, vp, ip, ip]
+    lib.wct_comm_load.argtypes = [c_char_p]
+    lib.wct_comm_unique_id.argtypes = [ctypes.c_char_p]
+    lib.wct_comm_init.argtypes = [c_void_p, c_int, c_int, ctypes.c_char_p]
+    lib.wct_comm_attach.argtypes = [c_void_p, c_void_p, c_int, c_int]
+    lib.wct_comm_destroy.argtypes = [c_void_p]
+    lib.wct_level_sharded.argtypes = [c_void_p, c_int, vp, c_int, c_int, c_int, c_int, c_double, c_float, vp, ip, ip, vp]
     lib.wct_style_prepare_levels.argtypes = [c_void_p, vp, c_int, c_int, ctypes.c_uint]
     lib.wct_style_stats_count.argtypes = [c_void_p, c_int, POINTER(c_size_t)]
     lib.wct_style_export.argtypes = [c_void_p, c_int, vp]

@@ -37,6 +37,7 @@ and tests run the same code under gloo with a CPU checker as the engine.
 """
 from __future__ import annotations
 
+import time
 from typing import List, Optional, Tuple
 
 import torch
@@ -73,9 +74,18 @@ def ext_bounds(own: Tuple[int, int], W: int, halo: int) -> Tuple[int, int]:
 
 class ShardedStylizer:
     def __init__(self, engine, dist, H: int, W_total: int, Hs: int, Ws: int, rank: Optional[int] = None,
-                 world: Optional[int] = None, alpha: float = 1.0, broadcast_map: bool = False, halo_mode: str = "auto"):
+                 world: Optional[int] = None, alpha: float = 1.0, broadcast_map: bool = False, halo_mode: str = "auto",
+                 c_collectives: Optional[bool] = None):
         self.e, self.dist = engine, dist
         self.broadcast_map = broadcast_map
+        # c_collectives: a level's encode -> all-reduce -> solve -> decode chain as ONE library call on the engine's own RCCL communicator
+        # (engine.comm_init(dist); include/wct_hip.h wct_level_sharded) instead of three calls + torch.distributed.all_reduce + tensor glue.
+        # None = whenever the engine has a communicator (and every rank solves for itself: not with broadcast_map).  Bit-identical.
+        has = bool(getattr(engine, "has_comm", False))
+        self.c_collectives = (has and not broadcast_map) if c_collectives is None else bool(c_collectives)
+        if self.c_collectives and (not has or broadcast_map):
+            raise ValueError("c_collectives needs engine.comm_init(dist) and broadcast_map=False")
+        self.t_range_wait = 0.0     # seconds stylize_strip() has spent WAITING for an old frame's range flag (not enqueueing): bench.py splits on it
         self.rank = dist.get_rank() if rank is None else rank
         self.world = dist.get_world_size() if world is None else world
         self.H, self.W, self.Hs, self.Ws = H, W_total, Hs, Ws
@@ -117,7 +127,9 @@ class ShardedStylizer:
         total = 0.0
         while len(self._range) > keep:
             host, ev = self._range.pop(0)
+            t0 = time.perf_counter()
             ev.synchronize()
+            self.t_range_wait += time.perf_counter() - t0
             total = max(total, float(host[0]))
         if total > 0:
             self._range.clear()      # the counter is cumulative: later frames would only repeat the report
@@ -219,6 +231,28 @@ class ShardedStylizer:
             H_in, W_in = int(img.shape[-2]), int(img.shape[-1])
             f0 = (own[0] - lo) >> sh                                   # owned feature columns
             f1 = -1 if own[1] >= W_cur else (own[1] - lo) >> sh        # last strip: to the (floored) end
+            if self.c_collectives:
+                # the level's style statistics first (import is all the solver needs), then the whole level in one call
+                if self.world > 1:
+                    if rank == owner(L):
+                        stats = e.style_export(L)
+                    else:
+                        stats = torch.empty(e.style_stats_count(L), dtype=torch.float64, device=img.device)
+                    dist.broadcast(stats, src=owner(L))
+                    if rank != owner(L):
+                        e.style_import(L, stats)
+                h = H_in >> sh
+                flag = torch.empty(1, dtype=torch.float64, device=img.device) if range_flag is not None else None
+                img = e.level_sharded(L, img, f0, f1, float(h * (W_cur >> sh)), self.alpha, flag)
+                if flag is not None:
+                    flags.append(flag)
+                W_cur = (W_cur >> sh) << sh
+                hi = lo + int(img.shape[-1])
+                own = (own[0], min(own[1], W_cur))
+                if exchange and L > 1:
+                    img, lo = self._exchange(img, lo, own, W_cur, halo[L - 1])
+                    hi = lo + int(img.shape[-1])
+                continue
             h, w_ext, sum_c, sumsq_c = e.content_encode(L, img, f0, f1)
             C = int(sum_c.numel())
             parts = [sum_c.reshape(-1), sumsq_c.reshape(-1)]

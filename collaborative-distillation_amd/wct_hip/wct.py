@@ -88,6 +88,7 @@ class WCT:
         self.device = torch.cuda.current_device() if device is None else int(device)
         self.stats_device = "cuda:%d" % self.device   # where style_export() tensors live (wct_hip/replicas.py, sharded.py)
         self.strict_range = True                      # see _stream(): f16x3 clamps are reported by the next call
+        self.has_comm = False                         # comm_init(): the context owns an RCCL communicator (level_sharded)
         self._lib = _lib.load()
         self._ctx = c_void_p()
         _lib.check(self._lib, None, self._lib.wct_create(self.device, byref(self._ctx)))
@@ -494,6 +495,50 @@ class WCT:
         ho, wo = c_int(), c_int()
         self._stream()
         self._chk(self._lib.wct_content_decode(self._ctx, level, M.data_ptr(), b.data_ptr(), out.data_ptr(), byref(ho), byref(wo)))
+        assert (ho.value, wo.value) == tuple(out.shape[2:])
+        return out
+
+    # ------------------------------------------------------------------ RCCL behind the boundary (include/wct_hip.h wct_comm_*, wct_level_sharded)
+    def comm_init(self, dist, group=None) -> None:
+        """Give this engine's context its own RCCL communicator over the ranks of `dist` (torch.distributed, any backend: it only carries
+        the 128-byte unique id from rank 0): every rank calls this once.  The library then runs the per-level all-reduce of a sharded
+        job itself (level_sharded); RCCL is the librccl.so torch has loaded -- one RCCL per process."""
+        import os as _os
+        path = _os.path.join(_os.path.dirname(torch.__file__), "lib", "librccl.so")
+        if self._lib.wct_comm_load(path.encode() if _os.path.exists(path) else None) != 0:
+            raise RuntimeError("libwct_hip: librccl.so could not be loaded (tried %s and the loader's search path)" % path)
+        rank, world = dist.get_rank(), dist.get_world_size()
+        buf = ctypes.create_string_buffer(128)
+        if rank == 0:
+            if self._lib.wct_comm_unique_id(buf) != 0:
+                raise RuntimeError("libwct_hip: ncclGetUniqueId failed")
+        if world > 1:
+            box = [bytes(buf.raw)]
+            dist.broadcast_object_list(box, src=0, group=group)
+            buf = ctypes.create_string_buffer(box[0], 128)
+        with torch.cuda.device(self.device):
+            self._chk(self._lib.wct_comm_init(self._ctx, world, rank, buf))
+        self.has_comm = True
+
+    def comm_destroy(self) -> None:
+        self._chk(self._lib.wct_comm_destroy(self._ctx))
+        self.has_comm = False
+
+    @torch.no_grad()
+    def level_sharded(self, level: int, img: torch.Tensor, x0: int, x1: int, n_total: float, alpha: Optional[float] = None,
+                      range_total: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """One level of a column-sharded cascade in ONE library call (encoder + owned-column moments -> ncclAllReduce -> solve -> fold ->
+        decoder; wct_level_sharded).  img: this rank's strip + halo [3, H, W]; [x0, x1): owned FEATURE columns; n_total: feature
+        pixels of the whole image.  range_total: optional 1-element fp64 device tensor receiving the node-wide f16x3 clamp count."""
+        alpha = self.alpha if alpha is None else float(alpha)
+        x = self._img(img)
+        H, W = int(x.shape[1]), int(x.shape[2])
+        C, h, w = self.feature_shape(level, H, W)
+        out = torch.empty((1, 3, h << (level - 1), w << (level - 1)), device=x.device, dtype=torch.float32)
+        ho, wo = c_int(), c_int()
+        self._stream()
+        self._chk(self._lib.wct_level_sharded(self._ctx, level, x.data_ptr(), H, W, int(x0), int(x1), float(n_total), alpha, out.data_ptr(),
+                                              byref(ho), byref(wo), range_total.data_ptr() if range_total is not None else None))
         assert (ho.value, wo.value) == tuple(out.shape[2:])
         return out
 

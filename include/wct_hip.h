@@ -174,6 +174,34 @@ int wct_content_solve(wct_ctx* ctx, int level, double n_c, const double* sum_c, 
                       double* M, double* b);
 int wct_content_decode(wct_ctx* ctx, int level, const double* M, const double* b, float* out, int* Ho, int* Wo);
 
+/* The multi-GPU variant of one level BEHIND the boundary ("multi-GPU variant takes an ncclComm_t"; the reference is
+ * single-GPU, WCT.py:97,110 -- nothing to replace but styleTransfer() itself, WCT.py:98-106, run on a column strip).
+ *   wct_comm_load        dlopen the RCCL the host process uses (path of librccl.so; NULL: "librccl.so.1", "librccl.so",
+ *                        /opt/rocm/lib/librccl.so) and resolve ncclGetUniqueId / ncclCommInitRank / ncclAllReduce / ncclCommDestroy.
+ *                        libwct_hip.so itself links against no communication library; single-GPU callers never load one.
+ *   wct_comm_unique_id   ncclGetUniqueId into 128 caller bytes (rank 0; the caller ships them to the other ranks, e.g. through the
+ *                        rendezvous it already has)
+ *   wct_comm_init        ncclCommInitRank on the context's device: the context then OWNS a communicator over `nranks` contexts
+ *                        (one per GPU / process); collective over the job -- every rank calls it
+ *   wct_comm_attach      use a communicator the caller owns (`nccl_comm` is an ncclComm_t); not destroyed by the library
+ *   wct_comm_destroy     ncclCommDestroy of an owned communicator (also done by wct_destroy)
+ *   wct_level_sharded    one level of the column-sharded cascade in ONE call, everything on the context's stream, no host
+ *                        synchronisation: encoder of `content` (3 x H x W: this rank's strip + halo) + raw moments over the OWNED feature
+ *                        columns [x0, x1) (x1 < 0: to the end) -> ncclAllReduce(SUM, fp64, C*C + C + 1 values: sums, second moments, the
+ *                        f16x3 range flag of wct_range_flag_f64) -> matrix functions with n_total = feature pixels of the WHOLE image,
+ *                        against the level's style statistics (wct_style_prepare* on this rank, or wct_style_import of another rank's)
+ *                        -> (M, b) folded into the decoder's first conv -> decoder -> out (3 x Ho x Wo).  range_total (device, one
+ *                        double, may be NULL) receives the node-wide clamp count.  Same arithmetic in the same order as
+ *                        wct_content_encode / all-reduce / wct_content_solve / wct_content_decode: bit-identical to that path.
+ *                        --mode 16x only (the wide models' deferred solves read back per call: use the split-level entries). */
+int wct_comm_load(const char* librccl_path);
+int wct_comm_unique_id(unsigned char* id128);
+int wct_comm_init(wct_ctx* ctx, int nranks, int rank, const unsigned char* id128);
+int wct_comm_attach(wct_ctx* ctx, void* nccl_comm, int nranks, int rank);
+int wct_comm_destroy(wct_ctx* ctx);
+int wct_level_sharded(wct_ctx* ctx, int level, const float* content, int H, int W, int x0, int x1, double n_total, float alpha,
+                      float* out, int* Ho, int* Wo, double* range_total);
+
 /* replaces the cascade of WCT.py:120-125 (levels 5..1, num_run times).  out must hold 3*H*W floats. */
 int wct_stylize(wct_ctx* ctx, const float* content, int H, int W, const float* style, int Hs, int Ws, float alpha,
                 int num_run, float* out, int* Ho, int* Wo);

@@ -24,7 +24,7 @@ def _free_port():
     return p
 
 
-def _shard_worker(rank, world, port, H, W, halo_mode, bmap, out_path, style_hw=(300, 260), frames="rand", backend="gloo"):
+def _shard_worker(rank, world, port, H, W, halo_mode, bmap, out_path, style_hw=(300, 260), frames="rand", backend="gloo", c_coll=False):
     for p in (REPO, PKG):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -50,7 +50,10 @@ def _shard_worker(rank, world, port, H, W, halo_mode, bmap, out_path, style_hw=(
             g = torch.Generator(device="cuda").manual_seed(11)
             content = torch.rand((3, H, W), device="cuda", generator=g)
             style = torch.rand((3,) + tuple(style_hw), device="cuda", generator=g)
+        if c_coll:                   # the per-level all-reduce inside the library, on its own RCCL communicator (wct_level_sharded)
+            wct.comm_init(dist)
         sh = ShardedStylizer(wct, dist, H, W, style_hw[0], style_hw[1], halo_mode=halo_mode, broadcast_map=bmap)
+        assert sh.c_collectives == bool(c_coll)
         x0, x1 = sh.input_columns()
         strip = sh.stylize_strip(content[:, :, x0:x1].contiguous(), style)
         wct.sync()
@@ -483,6 +486,74 @@ def test_two_devices_rccl_matches_untiled_and_in_process(tmp_path, halo_mode, bm
     style = torch.rand((3, 300, 260), device="cuda", generator=g)
     inproc, _ = standins.run_in_process(world, make, content, style, halo_mode=halo_mode, broadcast_map=bmap)
     assert np.array_equal(z["got"], inproc.cpu().numpy())
+
+
+def test_level_behind_one_c_call_with_rccl_inside_single_rank():
+    """SURVEY 8b's "multi-GPU variant takes an ncclComm_t": include/wct_hip.h wct_comm_* + wct_level_sharded -- one level's encoder -> owned-column
+    moments -> ncclAllReduce (issued BY THE LIBRARY on the context's stream, RCCL resolved at run time from torch's librccl.so) -> solve ->
+    fold -> decoder as ONE call.  This box has one device, so the communicator has one rank (RCCL refuses two ranks on one device): the job is
+    the sharded path at world 1 with every call, buffer and collective of the N-rank job.  In a fresh process:
+      * the C-collective path is BITWISE the torch.distributed path (wct_content_encode / all_reduce / wct_content_solve / wct_content_decode);
+      * it stays within the sharded test's tolerance of the untiled cascade; the range flag arrives (0 clamps);
+      * a context without a communicator refuses wct_level_sharded with WCT_ERR_STATE (no silent fallback)."""
+    code = r"""
+import os, sys, types
+sys.path[:0] = [%r, %r]
+import torch, torch.distributed as dist
+os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='%d', RANK='0', WORLD_SIZE='1')
+torch.cuda.set_device(0)
+dist.init_process_group('nccl', device_id=torch.device('cuda', 0))
+from wct_hip import WCT, model_zoo
+from wct_hip.lib import WctError
+from wct_hip.sharded import ShardedStylizer
+w = model_zoo.load_npz_weights(os.path.join(%r, 'weights', '16x.npz'))
+make = lambda: WCT(types.SimpleNamespace(mode='16x', alpha=1.0), weights=w)
+g = torch.Generator(device='cuda').manual_seed(11)
+H, W = 272, 1525
+content = torch.rand((3, H, W), device='cuda', generator=g)
+style = torch.rand((3, 300, 260), device='cuda', generator=g)
+plain = make()
+try:
+    plain.level_sharded(5, content, 0, -1, 1.0)
+    raise SystemExit('level_sharded without a communicator did not fail')
+except (WctError, RuntimeError) as e:
+    assert 'RCCL' in str(e) or 'communicator' in str(e), e
+ref_sh = ShardedStylizer(plain, dist, H, W, 300, 260, halo_mode='exchange')
+assert not ref_sh.c_collectives
+want = ref_sh.stylize_strip(content, style)
+ref_sh.check_range()
+eng = make()
+eng.comm_init(dist)
+sh = ShardedStylizer(eng, dist, H, W, 300, 260, halo_mode='exchange')
+assert sh.c_collectives
+got = sh.stylize_strip(content, style)
+sh.check_range()
+eng.sync()
+assert torch.equal(got, want), float((got - want).abs().max())
+untiled = make().stylize(content, style)
+err = float((got - untiled).abs().max() / untiled.abs().max())
+assert tuple(got.shape) == tuple(untiled.shape) and err < 5e-4, err
+got2 = sh.stylize_strip(content, style)          # again on the same communicator
+assert torch.equal(got2, got)
+eng.comm_destroy()
+dist.destroy_process_group()
+print('CCOLL_OK %%.2e' %% err)
+""" % (REPO, PKG, _free_port(), PKG)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert r.returncode == 0 and "CCOLL_OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+
+
+@needs_two_devices
+@pytest.mark.parametrize("halo_mode", ["exchange", "recompute"])
+def test_two_devices_c_collectives_bitwise_equal_torch_distributed(tmp_path, halo_mode):
+    """Two devices: the library's own all-reduce (wct_level_sharded over xGMI) against torch.distributed's, same job, bit for bit."""
+    import torch.multiprocessing as mp
+    outs = []
+    for c_coll in (False, True):
+        out = str(tmp_path / ("c%d.npz" % c_coll))
+        mp.spawn(_shard_worker, args=(2, _free_port(), 272, 1525, halo_mode, False, out, (300, 260), "rand", "nccl", c_coll), nprocs=2, join=True)
+        outs.append(np.load(out)["got"])
+    assert np.array_equal(outs[0], outs[1])
 
 
 @needs_two_devices

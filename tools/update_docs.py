@@ -16,6 +16,16 @@ cli = p.get("cli_pairs_per_s", {})
 g = lambda x, f="%.3g": (f % x) if isinstance(x, (int, float)) else "n/a"
 lines = ["_All figures in this block come from one `bench.py` line, `%s` (one MI355X; regenerate with `python tools/update_docs.py <line>`)._" % os.path.relpath(src, REPO), ""]
 lines.append("* **Headline** (BASELINE configs[1]: `--mode 16x`, 3840×2160 content + 2048×2048 style, style side included): **%s ms per frame = %s MP/s**." % (g(d.get("ms_per_step"), "%.3f"), g(d.get("value"), "%.1f")))
+tel = d.get("gpu_telemetry") or {}
+lines.append("* Latency (SURVEY 8d: each frame synchronised on its own, median of >= 10): **%s ms** (min %s, max %s); GPU during the timed steps: %s W average (max %s), sclk %s MHz average (min %s)." % (
+    g(d.get("latency_ms_median"), "%.3f"), g((d.get("latency_ms_min_max") or [None, None])[0], "%.3f"), g((d.get("latency_ms_min_max") or [None, None])[1], "%.3f"),
+    g(tel.get("power_W_avg"), "%.0f"), g(tel.get("power_W_max"), "%.0f"), g(tel.get("sclk_MHz_avg"), "%.0f"), g(tel.get("sclk_MHz_min"), "%.0f")))
+f32 = p.get("cfg2_fp32_exact", {})
+if f32:
+    lines.append("* **The reference's own arithmetic class beside the headline** (`wct_set_conv_mode(0)`: exact-fp32 MFMA products in every convolution, the same frame and call): %s ms per frame = %s MP/s = %s of the 157.3 TF fp32-MFMA roofline (dominant `%s`: %s TF = %s); the f16x3 headline is %s× faster; G13 distance %s (limit 1e-3)." % (
+        g(f32.get("ms_per_frame"), "%.2f"), g(f32.get("MPs"), "%.1f"), g(f32.get("algo_frac_fp32_mfma_157TF"), "%.3f"), (f32.get("roofline") or {}).get("kernel"),
+        g((f32.get("roofline") or {}).get("achieved"), "%.1f"), g((f32.get("roofline") or {}).get("frac"), "%.3f"), g(f32.get("headline_f16x3_speedup"), "%.2f"),
+        g((f32.get("parity") or {}).get("hip_vs_reference"), "%.2e")))
 lines.append("* Parity on the timed frame (G13, the reference's own pixels): this library %s (p99.99 %s), oracle %s, limit %s; reference UHD pair (G11) %s." % (
     g(par.get("hip_vs_reference"), "%.2e"), g(par.get("hip_vs_reference_p9999"), "%.2e"), g(par.get("oracle_vs_reference"), "%.2e"), g(par.get("limit"), "%.0e"),
     g((par.get("reference_uhd_pair") or {}).get("hip_vs_reference"), "%.2e")))
@@ -41,6 +51,13 @@ for k, name in (("cfg4_rank_sim", "10240×4096 in 8 strips"), ("cfg2x8_rank_sim"
     if rs:
         lines.append("* One rank's share of the 8-GPU job, timed on one GPU (%s): %s ms per frame → %s predicted%s (compute + orchestration only; no link time, no skew)." % (
             name, g(rs.get("predicted_ms_per_frame"), "%.2f"), ("%s× one GPU" % g(rs.get("predicted_speedup_vs_1gpu"), "%.2f")) if rs.get("predicted_speedup_vs_1gpu") else ("%s efficiency" % g(rs.get("predicted_efficiency"), "%.3f")), ""))
+        for r, e in sorted((rs.get("ranks") or {}).items()):
+            for tag in ("torch_distributed", "c_collectives"):
+                t = e.get(tag)
+                if t:
+                    lines.append("  * rank %s, %s: %s ms per frame; host %s ms = %s ms pure enqueue (%s of the frame) + %s ms waiting for an old frame's range flag." % (
+                        r, "three calls + torch.distributed per level" if tag == "torch_distributed" else "ONE library call per level, RCCL inside (`wct_level_sharded`)",
+                        g(t.get("ms_per_frame"), "%.2f"), g(t.get("host_enqueue_ms"), "%.2f"), g(t.get("pure_enqueue_ms"), "%.2f"), g(t.get("pure_enqueue_share_of_frame"), "%.2f"), g(t.get("range_flag_wait_ms"), "%.2f")))
 lines.append("* CPU checker on the same host, the timed frame itself: %s MP/s on %s threads (%s)." % (g(cpu.get("value"), "%.3f"), cpu.get("cores"), cpu.get("kind")))
 ks = d.get("kernels") or []
 if ks:
