@@ -291,6 +291,124 @@ __global__ __launch_bounds__(256, 2) void moments_kernel(MomArgs a) {
   }
 }
 
+// ---- round 5: the big shallow maps (C = 32 / 64, fp32 block products) WITHOUT the LDS round trip.
+// v_mfma_f32_16x16x4_f32 takes A[i][k] from lane (i = l & 15, k = l >> 4) and B[k][j] from lane (j = l & 15, k = l >> 4): with
+// i = j = "channel slot" and k = "pixel of the step", the A and the B operand of a covariance block ARE the registers a coalesced load
+// delivers -- lane (cl, k) loads the R = C / 16 consecutive channels R cl .. R cl + R - 1 of pixel 4 step + k (16 lanes x 4 R bytes = one
+// pixel's whole C-vector, contiguous), and component r of that load, seen across the 16 lanes, is the channel set S_r = {R i + r}.
+// mfma(X_r, X_s) is then the 16 x 16 block of products between S_r and S_s: a fixed PERMUTATION of the C x C matrix, R (R + 1) / 2 blocks
+// (3 / 10 = the number of canonical tile pairs), un-permuted once per workgroup when the partials are written.  No ds_write, no
+// ds_read, no barrier in the pixel loop (the kernel above spends its time in the LDS-read -> MFMA chain: 1.6 TB/s at 24 % matrix-core
+// busy, profiles/r04a_*), 16 loads per wave and 64-pixel block in flight.
+// Arithmetic = the F32 variant's, to the bit for C = 32: the same 64-pixel blocks (block b of a chunk belongs to wave b & 3), the same
+// step order inside a block, the same (w0 + w1) + (w2 + w3) combination of the waves and the same chunking -- only WHICH lane holds a
+// product differs, and x_a x_b = x_b x_a.  For C = 64 the kernel above cuts its 96-pixel tiles into blocks of 64 + 32 pixels; here
+// every block is 64 (raw sums within ~1e-8, the F32 variant's own noise level).
+template <int R>
+__global__ __launch_bounds__(256, 2) void moments_reg_kernel(MomArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NPR = R * (R + 1) / 2, C = 16 * R, T = R;    // T tiles of 16 channels; NP = T (T + 1) / 2 = NPR canonical pairs
+  typedef float vecR __attribute__((ext_vector_type(R)));
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cl = lane & 15, k = lane >> 4;
+  const long p0 = (long)blockIdx.x * a.chunk, p1 = min(a.npix, p0 + a.chunk);
+  f64x4 acc[NPR];
+  double s[R];
+#pragma unroll
+  for (int j = 0; j < NPR; ++j) acc[j] = f64x4{0., 0., 0., 0.};
+#pragma unroll
+  for (int r = 0; r < R; ++r) s[r] = 0.;
+  const bool windowed = a.wwin != a.wfull;
+  for (long pb = p0 + 64 * wave; pb < p1; pb += 256) {
+    // the block's 16 loads, all issued before the first product (unconditional: addresses clamped, out-of-range pixels zeroed below)
+    vecR v[16];
+    long q = pb + k;
+    long row = 0; int col = 0;
+    if (windowed) { row = q / a.wwin; col = (int)(q - row * a.wwin); }
+#pragma unroll
+    for (int st = 0; st < 16; ++st) {
+      long qq = q + 4 * st;
+      long g;
+      if (windowed) {
+        long rr = row; int cc = col + 4 * st;
+        while (cc >= a.wwin) { cc -= a.wwin; ++rr; }
+        if (qq >= p1) { const long ql = p1 - 1; rr = ql / a.wwin; cc = (int)(ql - rr * a.wwin); }
+        g = rr * a.wfull + a.x0 + cc;
+      } else {
+        g = qq < p1 ? qq : p1 - 1;
+      }
+      v[st] = *reinterpret_cast<const vecR*>(a.x + g * C + R * cl);
+    }
+    f32x4 f[NPR];
+    float t[R];
+#pragma unroll
+    for (int j = 0; j < NPR; ++j) f[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < R; ++r) t[r] = 0.f;
+#pragma unroll
+    for (int st = 0; st < 16; ++st) {
+      const bool ok = q + 4 * st < p1;
+      float x[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) { x[r] = ok ? v[st][r] : 0.f; t[r] += x[r]; }
+      int j = 0;
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int c2 = r; c2 < R; ++c2, ++j) f[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[r], x[c2], f[j], 0, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < NPR; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[j][e] += (double)f[j][e];
+#pragma unroll
+    for (int r = 0; r < R; ++r) s[r] += (double)t[r];
+  }
+  // ---- the four waves' partial sets -> canonical tile pairs, through TWO LDS sets: waves 0 / 2 write sets A / B, waves 1 / 3 add theirs,
+  // the result is A + B = (w0 + w1) + (w2 + w3) -- the kernel above's order -- in 2 x (NP x 256 + C) doubles (12 / 41 KB) instead of 4 sets
+  constexpr int nsq = NPR * 256, ns = C;
+  double* red = reinterpret_cast<double*>(smem);          // [2][nsq]
+  double* reds = red + (size_t)2 * nsq;                   // [2][ns]
+  double* mine = red + (size_t)(wave >> 1) * nsq;
+  double* mines = reds + (size_t)(wave >> 1) * ns;
+  auto pair_of = [](int I, int J) { return I * T - I * (I - 1) / 2 + (J - I); };   // canonical index of tile pair I <= J
+#pragma unroll
+  for (int phase = 0; phase < 2; ++phase) {
+    if ((wave & 1) == phase) {
+      const bool add = phase == 1;
+      auto put = [&](int idx, double val) { mine[idx] = add ? mine[idx] + val : val; };   // every canonical entry: exactly one lane of a wave
+      int j = 0;
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int c2 = r; c2 < R; ++c2, ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            // D layout of the fp32 instruction: row i = 4 (lane >> 4) + e, column jj = lane & 15
+            const int ch_a = R * (4 * k + e) + r, ch_b = R * cl + c2;
+            const int I = ch_a >> 4, J = ch_b >> 4, ia = ch_a & 15, ib = ch_b & 15;
+            const double val = acc[j][e];
+            if (I < J) put(pair_of(I, J) * 256 + ia * 16 + ib, val);
+            else if (I > J) { if (r != c2) put(pair_of(J, I) * 256 + ib * 16 + ia, val); }   // (r == r blocks hold the mirrored entry themselves)
+            else {
+              put(pair_of(I, I) * 256 + ia * 16 + ib, val);
+              if (r != c2) put(pair_of(I, I) * 256 + ib * 16 + ia, val);
+            }
+          }
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        double v2 = s[r];
+        v2 += __shfl_xor(v2, 16);
+        v2 += __shfl_xor(v2, 32);
+        if (k == 0) mines[R * cl + r] = add ? mines[R * cl + r] + v2 : v2;
+      }
+    }
+    __syncthreads();
+  }
+  for (int e = tid; e < nsq; e += 256) a.part_sq[(size_t)blockIdx.x * nsq + e] = red[e] + red[nsq + e];
+  for (int e = tid; e < ns; e += 256) a.part_sum[(size_t)blockIdx.x * ns + e] = reds[e] + reds[ns + e];
+}
+
 // ---- level 1 of the 16x cascade: moments of relu1_1 = relu(conv11(image)) WITHOUT the feature map in HBM (level1.hip).
 // A persistent workgroup walks 32 x 8 image tiles: conv11 (f16x3, l1_conv_group) writes the tile's 256 x C features
 // into the LDS tile the pair loop above consumes (pixel split: every wave owns all three tile pairs for a quarter of
@@ -506,6 +624,25 @@ hipError_t launch_moments(const float* feat, int C, int h, int wfull, int x0, in
   a.wfull = wfull; a.x0 = x0; a.wwin = x1 - x0;
   a.part_sq = reinterpret_cast<double*>(ws);
   a.part_sum = a.part_sq + (size_t)a.NPC * a.NP * 256;
+  // big shallow maps with fp32 block products: operands straight from the loads' registers (moments_reg_kernel); WCT_MOM_REG=0: the LDS kernel
+  static const int reg_env = [] { const char* e = wct_debug_env("WCT_MOM_REG"); return e ? atoi(e) : 1; }();
+  if (reg_env && f32_products && (C == 32 || C == 64)) {
+    // same chunking as the LDS kernel (chunks are multiples of its tile MP; here they must be multiples of 256: four waves x 64 pixels)
+    a.chunk = (a.chunk + 255) / 256 * 256;
+    a.NPC = (int)((npix + a.chunk - 1) / a.chunk);
+    if (ws_bytes < ((size_t)a.NPC * a.NP * 256 + (size_t)a.NPC * a.T * 16) * sizeof(double)) return hipErrorOutOfMemory;
+    a.part_sum = a.part_sq + (size_t)a.NPC * a.NP * 256;
+    const size_t ldsr = ((size_t)2 * a.NP * 256 + 2 * C) * sizeof(double);      // 12.5 / 42 KB
+    auto kr = C == 32 ? moments_reg_kernel<2> : moments_reg_kernel<4>;
+    if (ldsr > 48 * 1024) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kr), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsr);
+      if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kr, dim3((unsigned)a.NPC), dim3(256), ldsr, s, a);
+    const long ne = (long)a.NP * 256 + a.T * 16;
+    hipLaunchKernelGGL(moments_reduce_kernel, dim3((unsigned)((ne + 15) / 16)), dim3(256), 0, s, a, sum, sumsq);
+    return hipGetLastError();
+  }
   size_t lds = (size_t)a.MP * a.Cs * sizeof(float);
   if (a.pixsplit) lds = std::max(lds, ((size_t)4 * a.NP * 256 + 4 * a.T * 16) * sizeof(double));
   const int nld = (a.MP * (C / 4) + 255) / 256;
