@@ -97,6 +97,24 @@ def test_e2e_config2_full_size(torch_cuda, wct16, oracle, weights16x, golden, ki
     assert rh["lattice_p9999"] <= GATE / 2                     # and it is not a near miss everywhere: 99.99 % of the pixels within 5e-4
 
 
+def test_e2e_config2_exact_fp32_mode_under_the_gate(torch_cuda, weights16x, golden):
+    """The reference's own arithmetic class (VERDICT r4 task 3): `wct_set_conv_mode(0)` -- exact-fp32 MFMA products in every convolution, as the
+    reference's plain fp32 nn.Conv2d (model_cd.py:724-743) -- on the TIMED frame against the reference's own pixels (G13 noise) at the literal
+    1e-3, beside the f16x3 default (test_e2e_config2_full_size).  bench.py times the same mode as passes.cfg2_fp32_exact."""
+    torch = torch_cuda
+    from wct_hip import WCT
+    g = golden("g13_cfg2_noise.npz")
+    c, s = cfg2_frames("noise")
+    assert abs(float(c.sum(dtype=np.float64)) - float(g["content.checksum"])) < 1e-6
+    eng = WCT(types.SimpleNamespace(mode="16x", alpha=1.0), weights=weights16x)
+    eng.set_conv_mode("fp32")
+    got = eng.stylize(cu(torch, c), cu(torch, s)).cpu().numpy()[0]
+    assert eng.saturation_count() == 0          # (exact fp32 has no range limit: the counter cannot move)
+    r = compare_to_fixture(got, g)
+    _report("e2e cfg2 noise, exact-fp32 mode", hip_vs_reference=r["max"], hip_p9999=r["lattice_p9999"], hip_frac_gt_1e3=r["lattice_frac_gt_gate"], limit=GATE)
+    assert r["max"] <= GATE and r["lattice_p9999"] <= GATE / 2 and r["down16_max"] <= GATE / 4
+
+
 def test_e2e_config2_reference_uhd_pair(torch_cuda, wct16, oracle, weights16x, golden):
     """Config 2 on the reference's OWN sample data: content/UHD_content/green_park-wallpaper-3840x2160.jpg (`--UHD`,
     README.md:41-44) + style/in1.jpg (2048x2048) -- the JPEG files are committed as fixtures, the expected output comes from
