@@ -25,6 +25,7 @@
 #include "wct_common.h"
 #include "conv_f16_dev.h"
 #include <algorithm>
+#include <utility>
 #include <cstdlib>
 
 namespace {
@@ -409,6 +410,187 @@ __global__ __launch_bounds__(256, 2) void moments_reg_kernel(MomArgs a) {
   for (int e = tid; e < ns; e += 256) a.part_sum[(size_t)blockIdx.x * ns + e] = reds[e] + reds[ns + e];
 }
 
+// ---- round 5: the WIDE maps (C a multiple of 128: 128 / 256 / 512, --mode original and the deep 16x levels), channel-BLOCKED.
+// The LDS kernel above gives a wave up to six tile pairs and splits C (C / 16 + 1) / 2 tile pairs over pair groups that each re-read the
+// whole C-vector of every pixel: 22 passes over the map at C = 512 (measured 452 us for 240 x 134 x 512: L2 traffic, 25 % of the fp64
+// matrix-core peak).  Here a workgroup owns a PAIR OF 128-CHANNEL BLOCKS (BI <= BJ: 1 / 3 / 10 block pairs) for a pixel chunk and reads only
+// those 2 x 128 channels; lane (cl, k) loads channels 8 cl .. 8 cl + 7 of each block for pixel 4 step + k (16 lanes x 32 B = the block,
+// contiguous), component r of a block across the 16 lanes is the channel set {8 i + r}, and mfma(A_r, B_s) is one 16 x 16 block of the
+// 128 x 128 block pair -- operands straight from the loads' registers as in moments_reg_kernel, 64 component pairs (36 on a diagonal block
+// pair: r <= s) dealt to the four waves, 16 (9) accumulators each, every wave over ALL pixels of the chunk.  Passes over the map:
+// (C / 128 + 1) / 2 = 2.5 at C = 512.  Every canonical entry is written by exactly one lane of one wave: no cross-wave reduction.
+// F32 = false: fp64 products (v_cvt_f64_f32 in registers, v_mfma_f64_16x16x4_f64), every step straight into the fp64 accumulators.
+// F32 = true : fp32 products, 64-pixel blocks summed in fp32, block totals in fp64 (the F32 variant's arithmetic; block boundaries at
+//              multiples of 64 pixels from the chunk start).  Sums (not second moments) come from the diagonal block pairs.
+// the j-th component pair (r, s) of wave `wave`: pairs enumerated r-major (diagonal block pair: s >= r only), dealt round robin to the four
+// waves.  constexpr: the operand registers of every MFMA are then compile-time choices (a run-time index would put the operands in scratch)
+constexpr int blk_pair(bool diag, int wave, int j, bool want_s) {
+  int idx = 0, n = 0;
+  for (int r = 0; r < 8; ++r)
+    for (int c2 = diag ? r : 0; c2 < 8; ++c2, ++idx)
+      if ((idx & 3) == wave) { if (n == j) return want_s ? c2 : r; ++n; }
+  return -1;
+}
+constexpr int blk_pairs(bool diag) { return diag ? 9 : 16; }
+// every product of a step, the operand choices as constant expressions (fold over the pair index)
+template <bool DIAG, int WAVE, int... J>
+__device__ __forceinline__ void blk_products_f64(const double (&da)[8], const double (&db)[8], f64x4* acc, std::integer_sequence<int, J...>) {
+  ((acc[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(da[blk_pair(DIAG, WAVE, J, false)], db[blk_pair(DIAG, WAVE, J, true)], acc[J], 0, 0, 0)), ...);
+}
+template <bool DIAG, int WAVE, int... J>
+__device__ __forceinline__ void blk_products_f32(const float (&xa)[8], const float (&xb)[8], f32x4* f, std::integer_sequence<int, J...>) {
+  ((f[J] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[blk_pair(DIAG, WAVE, J, false)], xb[blk_pair(DIAG, WAVE, J, true)], f[J], 0, 0, 0)), ...);
+}
+
+template <bool F32, bool DIAG, int WAVE>
+__device__ __forceinline__ void moments_blk_body(const MomArgs& a, int BI, int BJ) {
+  constexpr int R = 8, NPW = blk_pairs(DIAG);
+  const int lane = threadIdx.x & 63;
+  const int cl = lane & 15, k = lane >> 4;
+  const int C = a.C, T = a.T;
+  const long p0 = (long)blockIdx.x * a.chunk, p1 = min(a.npix, p0 + a.chunk);
+  f64x4 acc[NPW];
+  f32x4 f[F32 ? NPW : 1];
+  double sd[R];
+  float sf[R];
+#pragma unroll
+  for (int j = 0; j < NPW; ++j) acc[j] = f64x4{0., 0., 0., 0.};
+#pragma unroll
+  for (int r = 0; r < R; ++r) { sd[r] = 0.; sf[r] = 0.f; }
+  if constexpr (F32) {
+#pragma unroll
+    for (int j = 0; j < NPW; ++j) f[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const bool windowed = a.wwin != a.wfull;
+  const float* xa = a.x + BI * 128 + R * cl;
+  const float* xb = a.x + BJ * 128 + R * cl;
+  auto gidx = [&](long q) -> long {
+    const long qc = q < p1 ? q : p1 - 1;
+    if (!windowed) return qc;
+    const long row = qc / a.wwin;
+    return row * a.wfull + a.x0 + (qc - row * a.wwin);
+  };
+  constexpr int DEP = 2;                                      // steps of loads in flight ahead of the products
+  f32x4 va[DEP][2], vb[DEP][2];
+  auto fetch = [&](long q, int slot) {
+    const long g = gidx(q) * C;
+    va[slot][0] = *reinterpret_cast<const f32x4*>(xa + g);
+    va[slot][1] = *reinterpret_cast<const f32x4*>(xa + g + 4);
+    if constexpr (!DIAG) {
+      vb[slot][0] = *reinterpret_cast<const f32x4*>(xb + g);
+      vb[slot][1] = *reinterpret_cast<const f32x4*>(xb + g + 4);
+    }
+  };
+#pragma unroll
+  for (int d = 0; d < DEP; ++d) fetch(p0 + k + 4 * d, d);
+  long step = 0;
+  for (long q = p0 + k; q - k < p1; q += 4 * DEP) {
+#pragma unroll
+    for (int d = 0; d < DEP; ++d) {
+      const long qq = q + 4 * d;
+      const bool ok = qq < p1;                               // (steps past the chunk's end multiply zeros)
+      float xa_[R], xb_[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        xa_[r] = ok ? va[d][r >> 2][r & 3] : 0.f;
+        if constexpr (DIAG) xb_[r] = xa_[r];
+        else xb_[r] = ok ? vb[d][r >> 2][r & 3] : 0.f;
+      }
+      fetch(qq + 4 * DEP, d);                                 // refill the slot just read (addresses clamped; zeroed at use)
+      if constexpr (F32) {
+        if constexpr (DIAG) {
+#pragma unroll
+          for (int r = 0; r < R; ++r) sf[r] += xa_[r];
+        }
+        blk_products_f32<DIAG, WAVE>(xa_, xb_, f, std::make_integer_sequence<int, NPW>{});
+        ++step;
+        if ((step & 15) == 0) {                               // a 64-pixel block is complete
+#pragma unroll
+          for (int j = 0; j < NPW; ++j) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[j][e] += (double)f[j][e];
+            f[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+          }
+          if constexpr (DIAG) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) { sd[r] += (double)sf[r]; sf[r] = 0.f; }
+          }
+        }
+      } else {
+        double da[R], db[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) { da[r] = (double)xa_[r]; db[r] = DIAG ? da[r] : (double)xb_[r]; }
+        if constexpr (DIAG) {
+#pragma unroll
+          for (int r = 0; r < R; ++r) sd[r] += da[r];
+        }
+        blk_products_f64<DIAG, WAVE>(da, db, acc, std::make_integer_sequence<int, NPW>{});
+      }
+    }
+  }
+  if constexpr (F32) {                                        // the last, partial block
+#pragma unroll
+    for (int j = 0; j < NPW; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[j][e] += (double)f[j][e];
+#pragma unroll
+    for (int r = 0; r < R; ++r) sd[r] += (double)sf[r];
+  }
+  // ---- partials in the canonical format [chunk][tile pair I <= J][16 x 16]; D layout: row = mom_row<F32>(lane >> 4, e), column = lane & 15
+  auto pair_of = [&](int I, int J) { return I * T - I * (I - 1) / 2 + (J - I); };
+  double* dst = a.part_sq + (size_t)blockIdx.x * a.NP * 256;
+  auto emit = [&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+    constexpr int r = blk_pair(DIAG, WAVE, j, false), c2 = blk_pair(DIAG, WAVE, j, true);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int ch_a = BI * 128 + R * mom_row<F32>(k, e) + r, ch_b = BJ * 128 + R * cl + c2;
+      const int I = ch_a >> 4, J = ch_b >> 4, ia = ch_a & 15, ib = ch_b & 15;
+      const double val = acc[j][e];
+      if (I < J) dst[(size_t)pair_of(I, J) * 256 + ia * 16 + ib] = val;
+      else if (I > J) { if (r != c2) dst[(size_t)pair_of(J, I) * 256 + ib * 16 + ia] = val; }   // (only on a diagonal block pair; r == r blocks hold the mirror themselves)
+      else {
+        dst[(size_t)pair_of(I, I) * 256 + ia * 16 + ib] = val;
+        if (r != c2) dst[(size_t)pair_of(I, I) * 256 + ib * 16 + ia] = val;
+      }
+    }
+  };
+  [&]<int... J>(std::integer_sequence<int, J...>) { (emit(std::integral_constant<int, J>{}), ...); }(std::make_integer_sequence<int, NPW>{});
+  if constexpr (DIAG && WAVE == 0) {                          // channel sums of block BI: every wave holds them, wave 0 writes
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      double v2 = sd[r];
+      v2 += __shfl_xor(v2, 16);
+      v2 += __shfl_xor(v2, 32);
+      if (k == 0) a.part_sum[(size_t)blockIdx.x * T * 16 + BI * 128 + R * cl + r] = v2;
+    }
+  }
+}
+
+template <bool F32>
+__global__ __launch_bounds__(256, 2) void moments_blk_kernel(MomArgs a) {
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nblk = a.C >> 7;
+  int BI = 0, rem = (int)blockIdx.y;                          // blockIdx.y enumerates the block pairs BI <= BJ
+  while (rem >= nblk - BI) { rem -= nblk - BI; ++BI; }
+  const int BJ = BI + rem;
+  if (BI == BJ) {
+    switch (wave) {
+      case 0: moments_blk_body<F32, true, 0>(a, BI, BJ); break;
+      case 1: moments_blk_body<F32, true, 1>(a, BI, BJ); break;
+      case 2: moments_blk_body<F32, true, 2>(a, BI, BJ); break;
+      default: moments_blk_body<F32, true, 3>(a, BI, BJ); break;
+    }
+  } else {
+    switch (wave) {
+      case 0: moments_blk_body<F32, false, 0>(a, BI, BJ); break;
+      case 1: moments_blk_body<F32, false, 1>(a, BI, BJ); break;
+      case 2: moments_blk_body<F32, false, 2>(a, BI, BJ); break;
+      default: moments_blk_body<F32, false, 3>(a, BI, BJ); break;
+    }
+  }
+}
+
 // ---- level 1 of the 16x cascade: moments of relu1_1 = relu(conv11(image)) WITHOUT the feature map in HBM (level1.hip).
 // A persistent workgroup walks 32 x 8 image tiles: conv11 (f16x3, l1_conv_group) writes the tile's 256 x C features
 // into the LDS tile the pair loop above consumes (pixel split: every wave owns all three tile pairs for a quarter of
@@ -606,11 +788,22 @@ MomArgs plan(int C, long npix) {
   return a;
 }
 
+// chunking of moments_blk_kernel: ~1024 workgroups over all block pairs, chunks multiples of 64 pixels
+void blk_plan(int C, long npix, long& chunk, int& npc_out) {
+  const int nb = C >> 7, nbp = nb * (nb + 1) / 2;
+  long npc_target = 512;      // workgroups over all block pairs (two per CU); every chunk costs NP x 2 KB of partials: not more
+  if (const char* e = wct_debug_env("WCT_MOM_BLK_WGS")) npc_target = atol(e);
+  const long npc = std::max(1L, std::min(npc_target / nbp, (npix + 255) / 256));
+  chunk = ((npix + npc - 1) / npc + 63) / 64 * 64;
+  npc_out = (int)((npix + chunk - 1) / chunk);
+}
 }  // namespace
 
 size_t moments_workspace_bytes(int C, long npix) {
   MomArgs a = plan(C, npix);
-  return ((size_t)a.NPC * a.NP * 256 + (size_t)a.NPC * a.T * 16) * sizeof(double);
+  int npc = a.NPC;
+  if (C >= 512 && (C & 127) == 0) { long ch; int n2; blk_plan(C, npix, ch, n2); npc = std::max(npc, n2); }
+  return ((size_t)npc * a.NP * 256 + (size_t)npc * a.T * 16) * sizeof(double);
 }
 
 hipError_t launch_moments(const float* feat, int C, int h, int wfull, int x0, int x1, double* sum, double* sumsq,
@@ -639,6 +832,21 @@ hipError_t launch_moments(const float* feat, int C, int h, int wfull, int x0, in
       if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(kr, dim3((unsigned)a.NPC), dim3(256), ldsr, s, a);
+    const long ne = (long)a.NP * 256 + a.T * 16;
+    hipLaunchKernelGGL(moments_reduce_kernel, dim3((unsigned)((ne + 15) / 16)), dim3(256), 0, s, a, sum, sumsq);
+    return hipGetLastError();
+  }
+  // wide maps: channel-blocked, operands from registers (moments_blk_kernel); WCT_MOM_BLK=0: the LDS kernel
+  static const int blk_env = [] { const char* e = wct_debug_env("WCT_MOM_BLK"); return e ? atoi(e) : 1; }();
+  // measured (tools/experiments/mom_reg_ab.py blk): C = 512 at 240 x 134: 369 -> 237 us; C = 256: 1.05x; C = 128 and maps of a few hundred pixels: SLOWER
+  // (every chunk writes NP x 2 KB of partials) -> C >= 512 and >= 4096 pixels only.  (fp32 block products: 16 + 16 accumulator sets per wave do
+  // not fit 256 VGPRs; the LDS kernel keeps those maps.)
+  if (blk_env && !f32_products && C >= 512 && (C & 127) == 0 && npix >= 4096) {
+    const int nb = C >> 7, nbp = nb * (nb + 1) / 2;
+    blk_plan(C, npix, a.chunk, a.NPC);
+    if (ws_bytes < ((size_t)a.NPC * a.NP * 256 + (size_t)a.NPC * a.T * 16) * sizeof(double)) return hipErrorOutOfMemory;
+    a.part_sum = a.part_sq + (size_t)a.NPC * a.NP * 256;
+    hipLaunchKernelGGL(moments_blk_kernel<false>, dim3((unsigned)a.NPC, (unsigned)nbp), dim3(256), 0, s, a);
     const long ne = (long)a.NP * 256 + a.T * 16;
     hipLaunchKernelGGL(moments_reduce_kernel, dim3((unsigned)((ne + 15) / 16)), dim3(256), 0, s, a, sum, sumsq);
     return hipGetLastError();

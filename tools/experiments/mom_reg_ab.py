@@ -2,8 +2,12 @@
 ab_equal.py: runs itself twice (WCT_DEBUG=1 WCT_MOM_REG=0 / 1), compares raw sums and times the calls.  python tools/experiments/mom_reg_ab.py"""
 import os, subprocess, sys, types
 REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-CASES = [(32, 1080, 1920, 0, None), (32, 1024, 1024, 0, None), (64, 540, 960, 0, None), (64, 512, 512, 0, None), (32, 1080, 1920, 640, 1237), (64, 540, 960, 3, 701),
+MODE = "blk" if "blk" in sys.argv[1:] else "reg"
+ENVVAR = {"reg": "WCT_MOM_REG", "blk": "WCT_MOM_BLK"}[MODE]
+CASES_BLK = [(512, 134, 240, 0, None), (512, 67, 120, 0, None), (512, 134, 240, 16, 231), (512, 128, 128, 0, None), (512, 100, 77, 3, 70)]
+CASES = CASES_BLK if MODE == "blk" else [(32, 1080, 1920, 0, None), (32, 1024, 1024, 0, None), (64, 540, 960, 0, None), (64, 512, 512, 0, None), (32, 1080, 1920, 640, 1237), (64, 540, 960, 3, 701),
          (32, 300, 333, 0, None), (64, 270, 487, 5, 480)]
+CASES = CASES_BLK if MODE == "blk" else CASES
 if len(sys.argv) > 2 and sys.argv[1] == "--run":
     sys.path[:0] = [REPO, os.path.join(REPO, "collaborative-distillation_amd")]
     import numpy as np, torch
@@ -30,7 +34,7 @@ if len(sys.argv) > 2 and sys.argv[1] == "--run":
 else:
     import numpy as np
     for tag, v in (("lds", "0"), ("reg", "1")):
-        subprocess.check_call([sys.executable, __file__, "--run", "/tmp/momab_%s.npz" % tag], env=dict(os.environ, WCT_DEBUG="1", WCT_MOM_REG=v))
+        subprocess.check_call([sys.executable, __file__, "--run", "/tmp/momab_%s.npz" % tag] + sys.argv[1:], env=dict(os.environ, **{"WCT_DEBUG": "1", ENVVAR: v}))
     a, b = np.load("/tmp/momab_lds.npz"), np.load("/tmp/momab_reg.npz")
     rel = lambda x, y: float(np.abs(x - y).max() / np.abs(y).max())
     for i, (C, h, wd, x0, x1) in enumerate(CASES):
