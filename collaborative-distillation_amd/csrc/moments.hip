@@ -424,27 +424,33 @@ __global__ __launch_bounds__(256, 2) void moments_reg_kernel(MomArgs a) {
 //              multiples of 64 pixels from the chunk start).  Sums (not second moments) come from the diagonal block pairs.
 // the j-th component pair (r, s) of wave `wave`: pairs enumerated r-major (diagonal block pair: s >= r only), dealt round robin to the four
 // waves.  constexpr: the operand registers of every MFMA are then compile-time choices (a run-time index would put the operands in scratch)
-constexpr int blk_pair(bool diag, int wave, int j, bool want_s) {
+constexpr int blk_pair(bool diag, int nw, int wave, int j, bool want_s) {
   int idx = 0, n = 0;
   for (int r = 0; r < 8; ++r)
     for (int c2 = diag ? r : 0; c2 < 8; ++c2, ++idx)
-      if ((idx & 3) == wave) { if (n == j) return want_s ? c2 : r; ++n; }
+      if (idx % nw == wave) { if (n == j) return want_s ? c2 : r; ++n; }
   return -1;
 }
-constexpr int blk_pairs(bool diag) { return diag ? 9 : 16; }
-// every product of a step, the operand choices as constant expressions (fold over the pair index)
-template <bool DIAG, int WAVE, int... J>
-__device__ __forceinline__ void blk_products_f64(const double (&da)[8], const double (&db)[8], f64x4* acc, std::integer_sequence<int, J...>) {
-  ((acc[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(da[blk_pair(DIAG, WAVE, J, false)], db[blk_pair(DIAG, WAVE, J, true)], acc[J], 0, 0, 0)), ...);
+constexpr int blk_pairs(bool diag, int nw, int wave) {      // component pairs of wave `wave` of `nw`
+  int idx = 0, n = 0;
+  for (int r = 0; r < 8; ++r)
+    for (int c2 = diag ? r : 0; c2 < 8; ++c2, ++idx)
+      if (idx % nw == wave) ++n;
+  return n;
 }
-template <bool DIAG, int WAVE, int... J>
+// every product of a step, the operand choices as constant expressions (fold over the pair index)
+template <bool DIAG, int NW, int WAVE, int... J>
+__device__ __forceinline__ void blk_products_f64(const double (&da)[8], const double (&db)[8], f64x4* acc, std::integer_sequence<int, J...>) {
+  ((acc[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(da[blk_pair(DIAG, NW, WAVE, J, false)], db[blk_pair(DIAG, NW, WAVE, J, true)], acc[J], 0, 0, 0)), ...);
+}
+template <bool DIAG, int NW, int WAVE, int... J>
 __device__ __forceinline__ void blk_products_f32(const float (&xa)[8], const float (&xb)[8], f32x4* f, std::integer_sequence<int, J...>) {
-  ((f[J] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[blk_pair(DIAG, WAVE, J, false)], xb[blk_pair(DIAG, WAVE, J, true)], f[J], 0, 0, 0)), ...);
+  ((f[J] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[blk_pair(DIAG, NW, WAVE, J, false)], xb[blk_pair(DIAG, NW, WAVE, J, true)], f[J], 0, 0, 0)), ...);
 }
 
-template <bool F32, bool DIAG, int WAVE>
+template <bool F32, bool DIAG, int NW, int WAVE>
 __device__ __forceinline__ void moments_blk_body(const MomArgs& a, int BI, int BJ) {
-  constexpr int R = 8, NPW = blk_pairs(DIAG);
+  constexpr int R = 8, NPW = blk_pairs(DIAG, NW, WAVE);
   const int lane = threadIdx.x & 63;
   const int cl = lane & 15, k = lane >> 4;
   const int C = a.C, T = a.T;
@@ -502,7 +508,7 @@ __device__ __forceinline__ void moments_blk_body(const MomArgs& a, int BI, int B
 #pragma unroll
           for (int r = 0; r < R; ++r) sf[r] += xa_[r];
         }
-        blk_products_f32<DIAG, WAVE>(xa_, xb_, f, std::make_integer_sequence<int, NPW>{});
+        blk_products_f32<DIAG, NW, WAVE>(xa_, xb_, f, std::make_integer_sequence<int, NPW>{});
         ++step;
         if ((step & 15) == 0) {                               // a 64-pixel block is complete
 #pragma unroll
@@ -524,7 +530,7 @@ __device__ __forceinline__ void moments_blk_body(const MomArgs& a, int BI, int B
 #pragma unroll
           for (int r = 0; r < R; ++r) sd[r] += da[r];
         }
-        blk_products_f64<DIAG, WAVE>(da, db, acc, std::make_integer_sequence<int, NPW>{});
+        blk_products_f64<DIAG, NW, WAVE>(da, db, acc, std::make_integer_sequence<int, NPW>{});
       }
     }
   }
@@ -541,7 +547,7 @@ __device__ __forceinline__ void moments_blk_body(const MomArgs& a, int BI, int B
   double* dst = a.part_sq + (size_t)blockIdx.x * a.NP * 256;
   auto emit = [&](auto jc) {
     constexpr int j = decltype(jc)::value;
-    constexpr int r = blk_pair(DIAG, WAVE, j, false), c2 = blk_pair(DIAG, WAVE, j, true);
+    constexpr int r = blk_pair(DIAG, NW, WAVE, j, false), c2 = blk_pair(DIAG, NW, WAVE, j, true);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int ch_a = BI * 128 + R * mom_row<F32>(k, e) + r, ch_b = BJ * 128 + R * cl + c2;
@@ -567,28 +573,28 @@ __device__ __forceinline__ void moments_blk_body(const MomArgs& a, int BI, int B
   }
 }
 
-template <bool F32>
-__global__ __launch_bounds__(256, 2) void moments_blk_kernel(MomArgs a) {
+// NW waves per workgroup: 4 for the fp64 form (16 / 9 accumulator sets per wave), 8 for the fp32-block form (8 / 5 sets of fp32 AND fp64 accumulators)
+template <bool F32, int NW>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void moments_blk_kernel(MomArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int nblk = a.C >> 7;
   int BI = 0, rem = (int)blockIdx.y;                          // blockIdx.y enumerates the block pairs BI <= BJ
   while (rem >= nblk - BI) { rem -= nblk - BI; ++BI; }
   const int BJ = BI + rem;
-  if (BI == BJ) {
-    switch (wave) {
-      case 0: moments_blk_body<F32, true, 0>(a, BI, BJ); break;
-      case 1: moments_blk_body<F32, true, 1>(a, BI, BJ); break;
-      case 2: moments_blk_body<F32, true, 2>(a, BI, BJ); break;
-      default: moments_blk_body<F32, true, 3>(a, BI, BJ); break;
-    }
-  } else {
-    switch (wave) {
-      case 0: moments_blk_body<F32, false, 0>(a, BI, BJ); break;
-      case 1: moments_blk_body<F32, false, 1>(a, BI, BJ); break;
-      case 2: moments_blk_body<F32, false, 2>(a, BI, BJ); break;
-      default: moments_blk_body<F32, false, 3>(a, BI, BJ); break;
-    }
+#define WCT_BLK_CASE(W) case W: if (BI == BJ) moments_blk_body<F32, true, NW, W>(a, BI, BJ); else moments_blk_body<F32, false, NW, W>(a, BI, BJ); break;
+  switch (wave) {
+    WCT_BLK_CASE(0) WCT_BLK_CASE(1) WCT_BLK_CASE(2)
+    default:
+      if constexpr (NW == 4) { if (BI == BJ) moments_blk_body<F32, true, NW, 3>(a, BI, BJ); else moments_blk_body<F32, false, NW, 3>(a, BI, BJ); }
+      else {
+        switch (wave) {
+          WCT_BLK_CASE(3) WCT_BLK_CASE(4) WCT_BLK_CASE(5) WCT_BLK_CASE(6)
+          default: if (BI == BJ) moments_blk_body<F32, true, NW, 7>(a, BI, BJ); else moments_blk_body<F32, false, NW, 7>(a, BI, BJ); break;
+        }
+      }
+      break;
   }
+#undef WCT_BLK_CASE
 }
 
 // ---- level 1 of the 16x cascade: moments of relu1_1 = relu(conv11(image)) WITHOUT the feature map in HBM (level1.hip).
@@ -802,7 +808,7 @@ void blk_plan(int C, long npix, long& chunk, int& npc_out) {
 size_t moments_workspace_bytes(int C, long npix) {
   MomArgs a = plan(C, npix);
   int npc = a.NPC;
-  if (C >= 512 && (C & 127) == 0) { long ch; int n2; blk_plan(C, npix, ch, n2); npc = std::max(npc, n2); }
+  if (C >= 256 && (C & 127) == 0) { long ch; int n2; blk_plan(C, npix, ch, n2); npc = std::max(npc, n2); }
   return ((size_t)npc * a.NP * 256 + (size_t)npc * a.T * 16) * sizeof(double);
 }
 
@@ -838,15 +844,19 @@ hipError_t launch_moments(const float* feat, int C, int h, int wfull, int x0, in
   }
   // wide maps: channel-blocked, operands from registers (moments_blk_kernel); WCT_MOM_BLK=0: the LDS kernel
   static const int blk_env = [] { const char* e = wct_debug_env("WCT_MOM_BLK"); return e ? atoi(e) : 1; }();
-  // measured (tools/experiments/mom_reg_ab.py blk): C = 512 at 240 x 134: 369 -> 237 us; C = 256: 1.05x; C = 128 and maps of a few hundred pixels: SLOWER
-  // (every chunk writes NP x 2 KB of partials) -> C >= 512 and >= 4096 pixels only.  (fp32 block products: 16 + 16 accumulator sets per wave do
-  // not fit 256 VGPRs; the LDS kernel keeps those maps.)
-  if (blk_env && !f32_products && C >= 512 && (C & 127) == 0 && npix >= 4096) {
+  // measured (tools/experiments/mom_reg_ab.py blk), fp64 form: C = 512 at 240 x 134: 369 -> 237 us; C = 256: 1.05x; C = 128 and maps of a few hundred
+  // pixels: SLOWER (every chunk writes NP x 2 KB of partials) -> C >= 512 and >= 4096 pixels.  fp32-block form (eight waves): C >= 256.
+  const bool blk64 = !f32_products && C >= 512 && (C & 127) == 0 && npix >= 4096;
+  // fp32-block form (eight waves): measured C = 128: 0.64-0.8x, C = 256: 1.08-1.15x, C = 512: 1.63x -- but its raw sums sit 1.4-4x further from fp64 than the
+  // LDS kernel's (7e-9 against 2e-9 at C = 256) and config 3's level-isolated check at C = 256 moved from 4.8e-6 to 6.9e-5: experiments only (WCT_MOM_BLK=2)
+  const bool blk32 = f32_products && C >= 256 && (C & 127) == 0 && blk_env == 2;
+  if (blk_env && (blk64 || blk32)) {
     const int nb = C >> 7, nbp = nb * (nb + 1) / 2;
     blk_plan(C, npix, a.chunk, a.NPC);
     if (ws_bytes < ((size_t)a.NPC * a.NP * 256 + (size_t)a.NPC * a.T * 16) * sizeof(double)) return hipErrorOutOfMemory;
     a.part_sum = a.part_sq + (size_t)a.NPC * a.NP * 256;
-    hipLaunchKernelGGL(moments_blk_kernel<false>, dim3((unsigned)a.NPC, (unsigned)nbp), dim3(256), 0, s, a);
+    if (f32_products) hipLaunchKernelGGL((moments_blk_kernel<true, 8>), dim3((unsigned)a.NPC, (unsigned)nbp), dim3(512), 0, s, a);
+    else hipLaunchKernelGGL((moments_blk_kernel<false, 4>), dim3((unsigned)a.NPC, (unsigned)nbp), dim3(256), 0, s, a);
     const long ne = (long)a.NP * 256 + a.T * 16;
     hipLaunchKernelGGL(moments_reduce_kernel, dim3((unsigned)((ne + 15) / 16)), dim3(256), 0, s, a, sum, sumsq);
     return hipGetLastError();

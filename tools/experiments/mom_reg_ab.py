@@ -4,7 +4,8 @@ import os, subprocess, sys, types
 REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 MODE = "blk" if "blk" in sys.argv[1:] else "reg"
 ENVVAR = {"reg": "WCT_MOM_REG", "blk": "WCT_MOM_BLK"}[MODE]
-CASES_BLK = [(512, 134, 240, 0, None), (512, 67, 120, 0, None), (512, 134, 240, 16, 231), (512, 128, 128, 0, None), (512, 100, 77, 3, 70)]
+CASES_BLK = [(512, 134, 240, 0, None), (512, 67, 120, 0, None), (512, 134, 240, 16, 231), (512, 128, 128, 0, None), (512, 100, 77, 3, 70),
+             (128, 536, 960, 0, None), (256, 268, 480, 0, None), (128, 270, 480, 0, None), (128, 256, 256, 0, None), (256, 268, 480, 9, 400), (128, 536, 960, 100, 333), (512, 256, 300, 0, None)]
 CASES = CASES_BLK if MODE == "blk" else [(32, 1080, 1920, 0, None), (32, 1024, 1024, 0, None), (64, 540, 960, 0, None), (64, 512, 512, 0, None), (32, 1080, 1920, 640, 1237), (64, 540, 960, 3, 701),
          (32, 300, 333, 0, None), (64, 270, 487, 5, 480)]
 CASES = CASES_BLK if MODE == "blk" else CASES
