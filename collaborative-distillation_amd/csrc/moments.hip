@@ -438,6 +438,8 @@ constexpr int blk_pairs(bool diag, int nw, int wave) {      // component pairs o
       if (idx % nw == wave) ++n;
   return n;
 }
+template <typename F, int... J>
+__device__ __forceinline__ void blk_for_each(F&& fn, std::integer_sequence<int, J...>) { (fn(std::integral_constant<int, J>{}), ...); }
 // every product of a step, the operand choices as constant expressions (fold over the pair index)
 template <bool DIAG, int NW, int WAVE, int... J>
 __device__ __forceinline__ void blk_products_f64(const double (&da)[8], const double (&db)[8], f64x4* acc, std::integer_sequence<int, J...>) {
@@ -561,7 +563,7 @@ __device__ __forceinline__ void moments_blk_body(const MomArgs& a, int BI, int B
       }
     }
   };
-  [&]<int... J>(std::integer_sequence<int, J...>) { (emit(std::integral_constant<int, J>{}), ...); }(std::make_integer_sequence<int, NPW>{});
+  blk_for_each(emit, std::make_integer_sequence<int, NPW>{});
   if constexpr (DIAG && WAVE == 0) {                          // channel sums of block BI: every wave holds them, wave 0 writes
 #pragma unroll
     for (int r = 0; r < R; ++r) {
