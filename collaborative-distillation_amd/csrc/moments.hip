@@ -850,7 +850,8 @@ hipError_t launch_moments(const float* feat, int C, int h, int wfull, int x0, in
   // pixels: SLOWER (every chunk writes NP x 2 KB of partials) -> C >= 512 and >= 4096 pixels.  fp32-block form (eight waves): C >= 256.
   const bool blk64 = !f32_products && C >= 512 && (C & 127) == 0 && npix >= 4096;
   // fp32-block form (eight waves): measured C = 128: 0.64-0.8x, C = 256: 1.08-1.15x, C = 512: 1.63x -- but its raw sums sit 1.4-4x further from fp64 than the
-  // LDS kernel's (7e-9 against 2e-9 at C = 256) and config 3's level-isolated check at C = 256 moved from 4.8e-6 to 6.9e-5: experiments only (WCT_MOM_BLK=2)
+  // LDS kernel's (7e-9 against 2e-9 at C = 256) and config 3's level-isolated check at C = 256 moved from 4.8e-6 to 6.9e-5: experiments only (WCT_MOM_BLK=2).
+  // (Why: at C >= 256 the LDS kernel's tile is 16 pixels, so ITS fp32 blocks are 16 pixels, not 64: a block's error grows as n^1.5, their number as 1/n.)
   const bool blk32 = f32_products && C >= 256 && (C & 127) == 0 && blk_env == 2;
   if (blk_env && (blk64 || blk32)) {
     const int nb = C >> 7, nbp = nb * (nb + 1) / 2;
