@@ -6,7 +6,7 @@
 set -e
 cd "$(dirname "$0")"
 SRC="conv3x3 conv3x3_f16 conv3x3_sp level1 moments solve misc resize wct_api"
-HDR="csrc/wct_common.h csrc/conv_f16_dev.h ../include/wct_hip.h build.sh"
+HDR="csrc/wct_common.h csrc/conv_f16_dev.h csrc/wct_sharded_impl.h ../include/wct_hip.h build.sh"
 OUT=${WCT_OUT:-libwct_hip.so}
 OBJ=build/obj${WCT_DEFS:+_$(echo "$WCT_DEFS" | md5sum | cut -c1-8)}
 mkdir -p "$OBJ"
@@ -27,7 +27,7 @@ for p in $pids; do wait $p || fail=1; done
 [ $fail -eq 0 ] || { echo "compile failed"; exit 1; }
 if [ -n "$pids" ] || [ ! -f "$OUT" ]; then
   objs=""; for s in $SRC; do objs="$objs $OBJ/$s.o"; done
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -fPIC -shared -o "$OUT" $objs
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -fPIC -shared -o "$OUT" $objs -ldl
   echo "built $(pwd)/$OUT"
 else
   echo "libwct_hip.so up to date"

@@ -1,6 +1,7 @@
 // Small helper kernels: layout changes at the API boundary and weight preparation for the fused apply.
 #include "wct_common.h"
 #include <type_traits>
+#include <algorithm>
 
 namespace {
 
@@ -448,5 +449,27 @@ __global__ void counter_to_f64_kernel(const unsigned* counter, double* dst) { *d
 
 hipError_t launch_counter_to_f64(const unsigned* counter, double* dst, hipStream_t s) {
   hipLaunchKernelGGL(counter_to_f64_kernel, dim3(1), dim3(1), 0, s, counter, dst);
+  return hipGetLastError();
+}
+
+// ---- pitched block copy (wct_api.hip wct_stylize_sharded: level crops, halo packing and assembly of planar images; 3 planes of H rows
+//      are 3H rows of one pitch).  One float per thread and grid-stride: the blocks are 2 ... 1600 columns wide, HBM-bound, a few us.
+namespace {
+__global__ __launch_bounds__(256) void copy_block_kernel(const float* __restrict__ src, long src_pitch, float* __restrict__ dst, long dst_pitch,
+                                                         long rows, int width) {
+  const long total = rows * width;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long r = i / width;
+    const int c = (int)(i - r * width);
+    dst[r * dst_pitch + c] = src[r * src_pitch + c];
+  }
+}
+}  // namespace
+
+hipError_t launch_copy_block(const float* src, long src_pitch, float* dst, long dst_pitch, long rows, int width, hipStream_t s) {
+  if (rows <= 0 || width <= 0) return hipSuccess;
+  const long total = rows * width;
+  const unsigned blocks = (unsigned)std::min<long>((total + 255) / 256, 256L * 64);
+  hipLaunchKernelGGL(copy_block_kernel, dim3(blocks), dim3(256), 0, s, src, src_pitch, dst, dst_pitch, rows, width);
   return hipGetLastError();
 }

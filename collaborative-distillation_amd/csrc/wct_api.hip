@@ -12,6 +12,7 @@
 #include <cstring>
 #include <dlfcn.h>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -77,6 +78,7 @@ struct Lane {
 struct wct_ctx {
   int device = 0;
   Lane main, side;
+  hipEvent_t ev_join = nullptr;   // side -> main (wct_style_moments, wct_stylize_sharded: the style strips' sums are ready)
   hipEvent_t ev_fork = nullptr, ev_style[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   int eig_skip = 0, eig_calls = 0;
   int foldgemm = 1;   // 1: the wide models' folds as fp64 matrix-core GEMMs (debug key "foldgemm"; 0: misc.hip fold_block_kernel)
@@ -123,7 +125,13 @@ struct wct_ctx {
   void* comm = nullptr;
   bool comm_owned = false;
   int comm_ranks = 0, comm_rank = 0;
-  DevBuf packed;      // wct_level_sharded: [sum C | sumsq C*C | range flag] fp64, all-reduced in place
+  DevBuf packed;      // wct_level_sharded / wct_stylize_sharded: [sum C | sumsq C*C | range flag | style sums of levels 5..1] fp64, all-reduced in place
+  // how the context talks to its peers (wct_comm_init / _attach: RCCL on `comm`; wct_comm_attach_collectives: the caller's transport)
+  wct_collectives coll{};
+  bool coll_set = false, coll_rccl = false;
+  // wct_stylize_sharded: the level's cropped input, the decoded strip, the next level's assembled input (exchange mode), the four edge blocks
+  // (send left | send right | recv left | recv right), the rank's style strip, a level's style statistics in transit, (M | b) in transit
+  DevBuf shIn, shOut, shNext, shEdge, shStyle, shStats, shMb;
   // profiling
   bool prof = false;
   std::vector<ProfRec> recs;
@@ -138,11 +146,17 @@ struct RcclApi {
   int (*CommInitRank)(void**, int, NcclUid, int) = nullptr;
   int (*CommDestroy)(void*) = nullptr;
   int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  int (*Broadcast)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;   // (send, recv, count, datatype, root, comm, stream)
+  int (*Send)(const void*, size_t, int, int, void*, hipStream_t) = nullptr;               // (buf, count, datatype, peer, comm, stream)
+  int (*Recv)(void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
   const char* (*GetErrorString)(int) = nullptr;
   std::string path;
 };
 static RcclApi g_rccl;
-constexpr int NCCL_FLOAT64 = 8, NCCL_SUM = 0;    // nccl.h: ncclDataType_t ncclFloat64 = 8, ncclRedOp_t ncclSum = 0
+static std::mutex g_rccl_mutex;                  // wct_comm_load may be called from several contexts' threads
+constexpr int NCCL_FLOAT64 = 8, NCCL_INT8 = 0, NCCL_SUM = 0;    // nccl.h: ncclDataType_t ncclFloat64 = 8, ncclInt8 = ncclChar = 0; ncclRedOp_t ncclSum = 0
 
 namespace {
 
@@ -986,6 +1000,7 @@ int wct_create(int device, wct_ctx** out) {
   for (Lane* ln : {&c->main, &c->side})
     ok = ok && hipMalloc(reinterpret_cast<void**>(&ln->coop), 64) == hipSuccess && hipMemset(ln->coop, 0, 64) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess;
+  ok = ok && hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) == hipSuccess;
   for (int l = 1; l <= 5 && ok; ++l) ok = hipEventCreateWithFlags(&c->ev_style[l], hipEventDisableTiming) == hipSuccess;
   ok = ok && hipMalloc(reinterpret_cast<void**>(&c->sat_dev), 256) == hipSuccess && hipMemset(c->sat_dev, 0, 256) == hipSuccess;
   ok = ok && hipHostMalloc(reinterpret_cast<void**>(&c->sat_host), 64, hipHostMallocDefault) == hipSuccess;
@@ -1020,6 +1035,8 @@ void wct_destroy(wct_ctx* ctx) {
     if (ctx->ev_style[l]) (void)hipEventDestroy(ctx->ev_style[l]);
   }
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+  if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+  for (DevBuf* b : {&ctx->shIn, &ctx->shOut, &ctx->shNext, &ctx->shEdge, &ctx->shStyle, &ctx->shStats, &ctx->shMb}) release(*b);
 
   if (ctx->side.stream) (void)hipStreamDestroy(ctx->side.stream);
   if (ctx->sat_dev) (void)hipFree(ctx->sat_dev);
@@ -1528,6 +1545,12 @@ int wct_content_decode(wct_ctx* ctx, int level, const double* M, const double* b
   return range_readback(ctx);
 }
 
+}  // extern "C"
+
+// the column-sharded cascade and its transport table (wct_stylize_sharded, wct_comm_attach_collectives, ...): same translation unit
+#include "wct_sharded_impl.h"
+
+extern "C" {
 
 // ---------------------------------------------------------------------------------------------------------------------
 // RCCL inside the boundary ("multi-GPU variant takes an ncclComm_t").  One level of a column-sharded cascade is ONE call:
@@ -1543,25 +1566,44 @@ int rccl_ready(wct_ctx* ctx) {
 }  // namespace
 
 int wct_comm_load(const char* path) {
+  std::lock_guard<std::mutex> lock(g_rccl_mutex);
   if (g_rccl.AllReduce) return WCT_OK;
-  const char* cands[] = {path, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so"};
+  // an explicit path is THE library the host process uses (torch's bundled librccl.so): if it cannot be opened, fail -- mapping a second,
+  // different RCCL into the process silently is worse than an error.  Without a path: the loader's search path, then /opt/rocm.
+  const char* search[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so"};
   void* h = nullptr;
-  for (const char* c : cands) {
-    if (!c || !*c) continue;
-    h = dlopen(c, RTLD_NOW | RTLD_LOCAL);      // a library the process has already mapped is reused, not loaded twice
-    if (h) { g_rccl.path = c; break; }
+  if (path && *path) {
+    h = dlopen(path, RTLD_NOW | RTLD_LOCAL);      // a library the process has already mapped is reused, not loaded twice
+    if (h) g_rccl.path = path;
+  } else {
+    for (const char* c : search) {
+      h = dlopen(c, RTLD_NOW | RTLD_LOCAL);
+      if (h) { g_rccl.path = c; break; }
+    }
   }
   if (!h) return WCT_ERR_STATE;
-  g_rccl.lib = h;
-  g_rccl.GetUniqueId = reinterpret_cast<decltype(g_rccl.GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
-  g_rccl.CommInitRank = reinterpret_cast<decltype(g_rccl.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
-  g_rccl.CommDestroy = reinterpret_cast<decltype(g_rccl.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
-  g_rccl.GetErrorString = reinterpret_cast<decltype(g_rccl.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
-  auto ar = reinterpret_cast<decltype(g_rccl.AllReduce)>(dlsym(h, "ncclAllReduce"));
-  if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy || !ar) { g_rccl = RcclApi(); return WCT_ERR_STATE; }
-  g_rccl.AllReduce = ar;
+  RcclApi api;
+  api.lib = h;
+  api.path = g_rccl.path;
+  api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
+  api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
+  api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
+  api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+  api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(dlsym(h, "ncclAllReduce"));
+  api.Broadcast = reinterpret_cast<decltype(api.Broadcast)>(dlsym(h, "ncclBroadcast"));
+  api.Send = reinterpret_cast<decltype(api.Send)>(dlsym(h, "ncclSend"));
+  api.Recv = reinterpret_cast<decltype(api.Recv)>(dlsym(h, "ncclRecv"));
+  api.GroupStart = reinterpret_cast<decltype(api.GroupStart)>(dlsym(h, "ncclGroupStart"));
+  api.GroupEnd = reinterpret_cast<decltype(api.GroupEnd)>(dlsym(h, "ncclGroupEnd"));
+  if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllReduce || !api.Broadcast || !api.Send || !api.Recv || !api.GroupStart || !api.GroupEnd) {
+    g_rccl.path.clear();
+    return WCT_ERR_STATE;
+  }
+  g_rccl = api;
   return WCT_OK;
 }
+
+const char* wct_comm_library(void) { return g_rccl.AllReduce ? g_rccl.path.c_str() : ""; }
 
 int wct_comm_unique_id(unsigned char* id128) {
   if (!g_rccl.AllReduce || !id128) return WCT_ERR_STATE;
@@ -1573,13 +1615,15 @@ int wct_comm_init(wct_ctx* ctx, int nranks, int rank, const unsigned char* id128
   WCT_GUARD(ctx);
   if (int rc = rccl_ready(ctx)) return rc;
   if (!id128 || nranks < 1 || rank < 0 || rank >= nranks) return fail(ctx, WCT_ERR_INVALID, "comm_init: bad arguments (nranks %d, rank %d)", nranks, rank);
-  if (ctx->comm) return fail(ctx, WCT_ERR_STATE, "comm_init: the context already has a communicator");
+  if (ctx->comm || ctx->coll_set) return fail(ctx, WCT_ERR_STATE, "comm_init: the context already has a communicator");
   NcclUid uid;
   memcpy(uid.b, id128, 128);
   void* comm = nullptr;
   const int r = g_rccl.CommInitRank(&comm, nranks, uid, rank);     // collective over the job's ranks; the context's device is current
   if (r != 0 || !comm) return fail(ctx, WCT_ERR_HIP, "ncclCommInitRank(%d ranks, rank %d): %s", nranks, rank, g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "error");
   ctx->comm = comm; ctx->comm_owned = true; ctx->comm_ranks = nranks; ctx->comm_rank = rank;
+  shard::install_rccl(ctx);
+  ctx->coll_set = true;
   return WCT_OK;
 }
 
@@ -1588,8 +1632,10 @@ int wct_comm_attach(wct_ctx* ctx, void* nccl_comm, int nranks, int rank) {
   WCT_GUARD(ctx);
   if (int rc = rccl_ready(ctx)) return rc;
   if (!nccl_comm || nranks < 1 || rank < 0 || rank >= nranks) return fail(ctx, WCT_ERR_INVALID, "comm_attach: bad arguments");
-  if (ctx->comm) return fail(ctx, WCT_ERR_STATE, "comm_attach: the context already has a communicator");
+  if (ctx->comm || ctx->coll_set) return fail(ctx, WCT_ERR_STATE, "comm_attach: the context already has a communicator");
   ctx->comm = nccl_comm; ctx->comm_owned = false; ctx->comm_ranks = nranks; ctx->comm_rank = rank;
+  shard::install_rccl(ctx);
+  ctx->coll_set = true;
   return WCT_OK;
 }
 
@@ -1601,6 +1647,7 @@ int wct_comm_destroy(wct_ctx* ctx) {
     (void)g_rccl.CommDestroy(ctx->comm);
   }
   ctx->comm = nullptr; ctx->comm_owned = false; ctx->comm_ranks = 0; ctx->comm_rank = 0;
+  ctx->coll = wct_collectives{}; ctx->coll_set = false; ctx->coll_rccl = false;
   return WCT_OK;
 }
 
@@ -1608,12 +1655,10 @@ int wct_level_sharded(wct_ctx* ctx, int level, const float* content, int H, int 
                       float* out, int* Ho, int* Wo, double* range_total) {
   if (!ctx) return WCT_ERR_INVALID;
   WCT_GUARD(ctx);
-  if (int rc = rccl_ready(ctx)) return rc;
-  if (!ctx->comm) return fail(ctx, WCT_ERR_STATE, "level_sharded: no communicator (wct_comm_init / wct_comm_attach)");
+  if (!ctx->coll_set) return fail(ctx, WCT_ERR_STATE, "level_sharded: no communicator (wct_comm_init / wct_comm_attach / wct_comm_attach_collectives)");
   if (!valid_level(level) || !content || !out || !(n_total >= 1.0)) return fail(ctx, WCT_ERR_INVALID, "level_sharded: bad arguments");
   Module& me = ctx->mod[WCT_KIND_ENC][level];
   if (!me.loaded) return fail(ctx, WCT_ERR_STATE, "encoder %d not loaded", level);
-  if (ctx->wide_model) return fail(ctx, WCT_ERR_STATE, "level_sharded: the wide models' deferred solves synchronise the host per call; use the split-level entries");
   if (!ctx->eigS[level].p) return fail(ctx, WCT_ERR_STATE, "level_sharded: no style statistics for level %d (wct_style_prepare / wct_style_import)", level);
   const int C = me.layers.back().d.cout;
   const size_t npk = (size_t)C * C + C + 1;
@@ -1624,10 +1669,7 @@ int wct_level_sharded(wct_ctx* ctx, int level, const float* content, int H, int 
   int h = 0, w = 0;
   if (int rc = wct_content_encode(ctx, level, content, H, W, x0, x1, pk, pk + C, &h, &w)) return rc;
   HIPCHK(ctx, launch_counter_to_f64(ctx->sat_dev, pk + C + (size_t)C * C, ctx->main.stream));
-  {
-    const int r = g_rccl.AllReduce(pk, pk, npk, NCCL_FLOAT64, NCCL_SUM, ctx->comm, ctx->main.stream);
-    if (r != 0) return fail(ctx, WCT_ERR_HIP, "ncclAllReduce(%zu doubles): %s", npk, g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "error");
-  }
+  COLLCHK(ctx, "all-reduce (content moments)", ctx->coll.all_reduce_sum_f64(ctx->coll.user, pk, npk, ctx->main.stream));
   if (range_total) HIPCHK(ctx, hipMemcpyAsync(range_total, pk + C + (size_t)C * C, sizeof(double), hipMemcpyDeviceToDevice, ctx->main.stream));
   double *M, *b;
   if (int rc = mb_view(ctx, &M, &b)) return rc;

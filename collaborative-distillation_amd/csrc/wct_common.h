@@ -128,6 +128,10 @@ hipError_t launch_resize_u8(const uint8_t* in, int H, int W, int oH, int oW, con
                             const int* bounds_v_shifted, const int* kk_v, int ksize_v, int row0, int rows, uint8_t* tmp, uint8_t* out,
                             float* planar, hipStream_t s);
 
+// ---- pitched block copy of floats (rows x width; the sharded cascade's level crops, halo packing and assembly: a planar 3 x H x W image is
+//      3H rows of pitch W)
+hipError_t launch_copy_block(const float* src, long src_pitch, float* dst, long dst_pitch, long rows, int width, hipStream_t s);
+
 // ---- layout
 hipError_t launch_nhwc_to_nchw(const float* in, float* out, int C, int npix, hipStream_t s);
 hipError_t launch_nchw_to_nhwc(const float* in, float* out, int C, int npix, hipStream_t s);

@@ -22,7 +22,8 @@ SYMBOLS = [
     "wct_load_module", "wct_feature_shape", "wct_encode", "wct_decode", "wct_moments", "wct_solve",
     "wct_apply", "wct_transform", "wct_decode_affine", "wct_style_transfer_level", "wct_stylize",
     "wct_style_prepare", "wct_content_encode", "wct_content_solve", "wct_content_decode",
-    "wct_comm_load", "wct_comm_unique_id", "wct_comm_init", "wct_comm_attach", "wct_comm_destroy", "wct_level_sharded",
+    "wct_comm_load", "wct_comm_library", "wct_comm_unique_id", "wct_comm_init", "wct_comm_attach", "wct_comm_destroy", "wct_level_sharded",
+    "wct_comm_attach_collectives", "wct_comm_info", "wct_comm_selftest", "wct_shard_geometry", "wct_stylize_sharded", "wct_style_moments", "wct_style_solve",
     "wct_style_prepare_levels", "wct_style_stats_count", "wct_style_export", "wct_style_import", "wct_stylize_prepared",
     "wct_u8_to_planar", "wct_planar_to_u8", "wct_stylize_u8", "wct_resize_shape", "wct_resize_u8", "wct_resize_u8_to_planar",
     "wct_workspace_bytes", "wct_reserve", "wct_set_conv_mode", "wct_set_numpy_variant", "wct_set_overlap", "wct_profile_enable", "wct_profile_reset", "wct_profile_read",
@@ -37,6 +38,25 @@ class WctLayer(ctypes.Structure):
 class WctProfEntry(ctypes.Structure):
     _fields_ = [("name", ctypes.c_char * 48), ("ms", c_double), ("flops", c_double), ("bytes", c_double),
                 ("launches", c_long)]
+
+
+class WctP2P(ctypes.Structure):
+    _fields_ = [("peer", c_int), ("is_send", c_int), ("buf", c_void_p), ("bytes", c_size_t)]
+
+
+ALL_REDUCE_FN = ctypes.CFUNCTYPE(c_int, c_void_p, c_void_p, c_size_t, c_void_p)          # (user, buf, count, stream)
+BROADCAST_FN = ctypes.CFUNCTYPE(c_int, c_void_p, c_void_p, c_size_t, c_int, c_void_p)    # (user, buf, bytes, root, stream)
+SENDRECV_FN = ctypes.CFUNCTYPE(c_int, c_void_p, POINTER(WctP2P), c_int, c_void_p)        # (user, ops, n_ops, stream)
+
+
+class WctCollectives(ctypes.Structure):
+    """include/wct_hip.h wct_collectives: the transport table of wct_stylize_sharded (wct_comm_attach_collectives)."""
+    _fields_ = [("user", c_void_p), ("all_reduce_sum_f64", ALL_REDUCE_FN), ("broadcast", BROADCAST_FN), ("sendrecv", SENDRECV_FN)]
+
+
+HALO_MODES = {"auto": 0, "recompute": 1, "exchange": 2}
+STYLE_MODES = {"auto": 0, "owner": 1, "strips": 2, "replicate": 3}
+SHARD_BROADCAST_MAP = 1
 
 
 class WctError(RuntimeError):
@@ -92,6 +112,14 @@ def load() -> ctypes.CDLL:
     lib.wct_content_solve.argtypes = [c_void_p, c_int, c_double, vp, vp, c_float, vp, vp]
     lib.wct_content_decode.argtypes = [c_void_p, c_int, vp, vp, vp, ip, ip]
     lib.wct_comm_load.argtypes = [c_char_p]
+    lib.wct_comm_library.restype = c_char_p
+    lib.wct_comm_attach_collectives.argtypes = [c_void_p, POINTER(WctCollectives), c_int, c_int]
+    lib.wct_comm_info.argtypes = [c_void_p, ip, ip]
+    lib.wct_comm_selftest.argtypes = [c_void_p]
+    lib.wct_shard_geometry.argtypes = [c_int, c_int, c_int, c_int, ip, ip, ip, ip, ip]
+    lib.wct_stylize_sharded.argtypes = [c_void_p, vp, c_int, c_int, c_int, c_int, vp, c_int, c_int, c_float, c_int, c_int, c_int, vp, ip, ip, vp]
+    lib.wct_style_moments.argtypes = [c_void_p, c_int, vp, c_int, c_int, c_int, c_int, vp, vp]
+    lib.wct_style_solve.argtypes = [c_void_p, c_int, c_double, vp, vp]
     lib.wct_comm_unique_id.argtypes = [ctypes.c_char_p]
     lib.wct_comm_init.argtypes = [c_void_p, c_int, c_int, ctypes.c_char_p]
     lib.wct_comm_attach.argtypes = [c_void_p, c_void_p, c_int, c_int]

@@ -23,9 +23,17 @@ coupling is (n, SUM x, SUM x x^T) of the content feature map (util_wct.py:68-70)
   * moments are accumulated over OWNED columns only and summed with one all-reduce (fp64, C*C + C values:
     132 KB at C = 128, latency-bound on xGMI) per level;
   * the style side (five encodes + moments + matrix square roots, a third of a single-GPU step) depends only on the
-    style image: level L's style statistics are computed by rank (5 - L) mod world on its side stream, overlapping that
-    rank's content work, and broadcast -- C*C + C fp64 values per level, 132 KB at C = 128 -- instead of every rank
-    repeating all five levels;
+    style image (`style_mode`):
+      "strips"     the style image is cut into column strips exactly like the content: every rank encodes ITS strip + the
+                   ENCODER's receptive field (STYLE_HALO = 80 / 32 / 12 / 4 / 1 columns per interior side at level 5..1) at every
+                   level and sums raw moments over its owned feature columns -- the same statistic as the content's, summed the same
+                   way: the five levels' sums ride in the level-5 all-reduce of the content moments (no extra collective) and every
+                   rank takes the five matrix square roots itself.  Per-rank style work is 1 / world of the style side (+ margins:
+                   1.3x at 256-column strips) on EVERY rank;
+      "owner"      level L's style statistics are computed whole by rank (5 - L) mod world on its side stream and broadcast
+                   (C*C + C fp64 values per level, 132 KB at C = 128); rank 0 carries level 5 = 45.6 % of the style FLOPs;
+      "replicate"  every rank repeats all five levels (no communication; styles too narrow to cut);
+      "auto"       strips when the style is at least 64 columns per rank wide, else replicate;
   * the colouring map (M, b): every rank now holds the same global content moments (the all-reduce returns identical bits
     everywhere) and the same style statistics, and the solver is deterministic, so every rank solves for itself and folds
     the SAME matrices into its decoder -- two collectives per level.  `broadcast_map=True` keeps the other arrangement
@@ -34,6 +42,11 @@ coupling is (n, SUM x, SUM x x^T) of the content feature map (util_wct.py:68-70)
 
 The orchestration is backend-agnostic: `engine` is a wct_hip.WCT on the GPU (RCCL = torch.distributed "nccl"),
 and tests run the same code under gloo with a CPU checker as the engine.
+
+`c_cascade=True` hands the WHOLE of the above to the library: ONE call per frame (include/wct_hip.h wct_stylize_sharded --
+geometry, crops, style side, collectives on the engine's own RCCL communicator, neighbour exchange, all on the context's streams).
+The Python orchestration in this file then is the CHECKER of that path: same geometry, same arithmetic, bit-identical results
+(tests/test_sharded_gpu.py).
 """
 from __future__ import annotations
 
@@ -44,6 +57,10 @@ import torch
 
 #: composite encode->decode receptive-field margin per side, in image columns of that level
 LEVEL_HALO = {5: 160, 4: 72, 3: 24, 2: 10, 1: 2}
+#: the ENCODER's receptive field alone (style strips: 70 / 30 / 10 / 4 / 1 columns, rounded up to a multiple of 2^(L-1))
+STYLE_HALO = {5: 80, 4: 32, 3: 12, 2: 4, 1: 1}
+#: style_mode "auto": strips from this many style columns per rank
+STYLE_STRIPS_MIN_COLS_PER_RANK = 64
 #: cumulative halo needed at the INPUT of level L (multiples of 2^(L-1); A_L - LEVEL_HALO[L] >= A_{L-1})
 CUM_HALO = {5: 272, 4: 112, 3: 40, 2: 16, 1: 6}
 #: strips narrower than this take the neighbour exchange under halo_mode="auto"
@@ -75,19 +92,38 @@ def ext_bounds(own: Tuple[int, int], W: int, halo: int) -> Tuple[int, int]:
 class ShardedStylizer:
     def __init__(self, engine, dist, H: int, W_total: int, Hs: int, Ws: int, rank: Optional[int] = None,
                  world: Optional[int] = None, alpha: float = 1.0, broadcast_map: bool = False, halo_mode: str = "auto",
-                 c_collectives: Optional[bool] = None):
+                 c_collectives: Optional[bool] = None, style_mode: str = "auto", c_cascade: bool = False):
         self.e, self.dist = engine, dist
         self.broadcast_map = broadcast_map
         # c_collectives: a level's encode -> all-reduce -> solve -> decode chain as ONE library call on the engine's own RCCL communicator
         # (engine.comm_init(dist); include/wct_hip.h wct_level_sharded) instead of three calls + torch.distributed.all_reduce + tensor glue.
         # None = whenever the engine has a communicator (and every rank solves for itself: not with broadcast_map).  Bit-identical.
+        # c_cascade: the WHOLE frame as one library call (wct_stylize_sharded); opt-in, needs the engine's communicator as well.
         has = bool(getattr(engine, "has_comm", False))
-        self.c_collectives = (has and not broadcast_map) if c_collectives is None else bool(c_collectives)
+        self.c_cascade = bool(c_cascade)
+        self.c_collectives = (has and not broadcast_map and not self.c_cascade) if c_collectives is None else bool(c_collectives)
         if self.c_collectives and (not has or broadcast_map):
             raise ValueError("c_collectives needs engine.comm_init(dist) and broadcast_map=False")
+        if self.c_cascade and not has:
+            raise ValueError("c_cascade needs a communicator or transport on the engine (engine.comm_init(dist) / comm_attach_collectives)")
         self.t_range_wait = 0.0     # seconds stylize_strip() has spent WAITING for an old frame's range flag (not enqueueing): bench.py splits on it
         self.rank = dist.get_rank() if rank is None else rank
         self.world = dist.get_world_size() if world is None else world
+        if (self.c_collectives or self.c_cascade) and not getattr(dist, "emulates_peers", False):
+            # the library all-reduces over ITS communicator while n_total and the strip geometry come from (world, rank): a communicator
+            # over another group would hand every rank part of the moments under the full n_total -- silently wrong pictures
+            info = tuple(engine.comm_info())
+            if info != (self.world, self.rank):
+                raise ValueError("the engine's communicator is rank %d of %d, this job is rank %d of %d: the library's collectives would "
+                                 "run over another group than the strip geometry assumes" % (info[1], info[0], self.rank, self.world))
+        if style_mode not in ("auto", "owner", "strips", "replicate"):
+            raise ValueError("style_mode must be auto, owner, strips or replicate")
+        if self.world == 1:
+            style_mode = "replicate"
+        elif style_mode == "auto":
+            style_mode = "strips" if Ws >= STYLE_STRIPS_MIN_COLS_PER_RANK * self.world else "replicate"
+        self.style_mode = style_mode
+        self.style_bounds = strip_bounds(Ws, self.world) if style_mode == "strips" else None
         self.H, self.W, self.Hs, self.Ws = H, W_total, Hs, Ws
         self.alpha = alpha
         self.bounds = strip_bounds(W_total, self.world)
@@ -105,6 +141,10 @@ class ShardedStylizer:
         if broadcast_map and getattr(dist, "emulates_peers", False):
             raise ValueError("a peer-emulating measurement group (tools/sharded_standins.LoopbackGroup) emulates the style-statistics "
                              "broadcasts only: broadcast_map=True is not supported by it")
+        if self.c_cascade:
+            g = engine.shard_geometry(W_total, self.world, self.rank, self.halo_mode)    # the library's geometry must be this file's
+            if (g[0], g[1]) != self.own or (g[2], g[3]) != self.input_columns() or g[4] != self.halo_mode:
+                raise RuntimeError("wct_shard_geometry %r disagrees with sharded.py (%r, %r, %s)" % (g, self.own, self.input_columns(), self.halo_mode))
         self._range = []            # [(pinned host value, event)], oldest first: node-wide f16x3 clamp totals of past stylize_strip calls
 
     def input_columns(self) -> Tuple[int, int]:
@@ -202,10 +242,54 @@ class ShardedStylizer:
         if strict is not None:
             e.strict_range = False
         try:
+            if self.c_cascade:
+                return self._stylize_strip_c(content_ext, style, range_flag)
             return self._stylize_strip(content_ext, style, range_flag)
         finally:
             if strict is not None:
                 e.strict_range = strict
+
+    def _note_range(self, flag):
+        """Queue the frame's node-wide clamp total (device, 1 double) for check_range(): an asynchronous copy to pinned host memory + an event."""
+        host = torch.zeros(1, dtype=torch.float64).pin_memory()
+        host.copy_(flag, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._range.append((host, ev))
+
+    def _stylize_strip_c(self, content_ext, style, range_flag):
+        """The frame as ONE library call (wct_stylize_sharded)."""
+        x0, x1 = self.input_columns()
+        flag = torch.empty(1, dtype=torch.float64, device=content_ext.device) if range_flag is not None else None
+        out = self.e.stylize_sharded(content_ext, style, self.W, x0, x1, alpha=self.alpha, halo_mode=self.halo_mode, style_mode=self.style_mode,
+                                     broadcast_map=self.broadcast_map, range_total=flag)
+        if flag is not None:
+            self._note_range(flag)
+        return out
+
+    def _style_strip_moments(self, style):
+        """style_mode "strips": this rank's raw style moments of every level as flat fp64 parts [sum_5, sumsq_5, sum_4, ...]."""
+        e = self.e
+        s0, s1 = self.style_bounds[self.rank]
+        img = style if style.dim() == 3 else style[0]
+        parts = []
+        for L in (5, 4, 3, 2, 1):
+            sh = L - 1
+            lo, hi = ext_bounds((s0, s1), self.Ws, STYLE_HALO[L])
+            f0 = (s0 - lo) >> sh
+            f1 = -1 if s1 >= self.Ws else (s1 - lo) >> sh
+            s, ss = e.style_moments(L, img[..., lo:hi].contiguous(), f0, f1)
+            parts += [s.reshape(-1), ss.reshape(-1)]
+        return parts
+
+    def _style_strip_solve(self, flat):
+        """`flat`: the all-reduced concatenation of _style_strip_moments' parts -> every level's style statistics inside the engine."""
+        o = 0
+        for L in (5, 4, 3, 2, 1):
+            sh = L - 1
+            C = self._style_C[L]
+            self.e.style_solve(L, float((self.Hs >> sh) * (self.Ws >> sh)), flat[o:o + C], flat[o + C:o + C + C * C].reshape(C, C))
+            o += C + C * C
 
     def _stylize_strip(self, content_ext, style, range_flag):
         e, dist = self.e, self.dist
@@ -218,7 +302,19 @@ class ShardedStylizer:
         assert img.shape[-1] == hi - lo, "expected columns [%d,%d) of the content" % (lo, hi)
         world, rank = self.world, self.rank
         owner = lambda lvl: (5 - lvl) % world           # rank 0 (the solver) owns level 5, the first one it needs
-        e.style_prepare(style, levels=[lvl for lvl in (5, 4, 3, 2, 1) if owner(lvl) == rank])
+        strips, owner_mode = self.style_mode == "strips", self.style_mode == "owner"
+        style_parts = None
+        if strips:
+            style_parts = self._style_strip_moments(style)
+            self._style_C = {L: int(style_parts[2 * i].numel()) for i, L in enumerate((5, 4, 3, 2, 1))}
+            if self.c_collectives:
+                flat = torch.cat(style_parts)                          # the per-level library call carries the content moments only
+                dist.all_reduce(flat)
+                self._style_strip_solve(flat)
+        elif owner_mode:
+            e.style_prepare(style, levels=[lvl for lvl in (5, 4, 3, 2, 1) if owner(lvl) == rank])
+        else:
+            e.style_prepare(style, levels=[5, 4, 3, 2, 1])
         for L in (5, 4, 3, 2, 1):
             sh = L - 1
             if hasattr(dist, "set_level"):
@@ -233,7 +329,7 @@ class ShardedStylizer:
             f1 = -1 if own[1] >= W_cur else (own[1] - lo) >> sh        # last strip: to the (floored) end
             if self.c_collectives:
                 # the level's style statistics first (import is all the solver needs), then the whole level in one call
-                if self.world > 1:
+                if self.world > 1 and owner_mode:
                     if rank == owner(L):
                         stats = e.style_export(L)
                     else:
@@ -258,13 +354,18 @@ class ShardedStylizer:
             parts = [sum_c.reshape(-1), sumsq_c.reshape(-1)]
             if range_flag is not None:
                 parts.append(range_flag())                             # this rank's f16x3 clamp counter so far: summed over the ranks below
+            n_own = sum(int(p.numel()) for p in parts)
+            if strips and L == 5:
+                parts += style_parts                                   # the five levels' style sums ride in the same all-reduce
             packed = torch.cat(parts)
             if self.world > 1:
-                dist.all_reduce(packed)                                # SUM, fp64, C*C + C (+ 1) values
+                dist.all_reduce(packed)                                # SUM, fp64, C*C + C (+ 1) values (+ the style sums at level 5)
             if range_flag is not None:
-                flags.append(packed[C + C * C:])
+                flags.append(packed[C + C * C:C + C * C + 1])
+            if strips and L == 5:
+                self._style_strip_solve(packed[n_own:])
             solvers = (0,) if self.broadcast_map else range(self.world)   # ranks that need the level's style statistics
-            if self.world > 1 and any(r != owner(L) for r in solvers):
+            if self.world > 1 and owner_mode and any(r != owner(L) for r in solvers):
                 if rank == owner(L):
                     stats = e.style_export(L)
                 else:
@@ -294,9 +395,5 @@ class ShardedStylizer:
                 hi = lo + int(img.shape[-1])
         if flags:
             # levels 5..2 are covered by later all-reduces (the counter is cumulative); level 1's decode by the next frame's
-            host = torch.zeros(1, dtype=torch.float64).pin_memory()
-            host.copy_(flags[-1], non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record()
-            self._range.append((host, ev))
+            self._note_range(flags[-1])
         return img[..., own[0] - lo:own[1] - lo].contiguous()

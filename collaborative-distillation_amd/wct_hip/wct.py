@@ -506,7 +506,7 @@ class WCT:
         import os as _os
         path = _os.path.join(_os.path.dirname(torch.__file__), "lib", "librccl.so")
         if self._lib.wct_comm_load(path.encode() if _os.path.exists(path) else None) != 0:
-            raise RuntimeError("libwct_hip: librccl.so could not be loaded (tried %s and the loader's search path)" % path)
+            raise RuntimeError("libwct_hip: librccl.so could not be loaded (%s)" % (path if _os.path.exists(path) else "the loader's search path, /opt/rocm/lib"))
         rank, world = dist.get_rank(), dist.get_world_size()
         buf = ctypes.create_string_buffer(128)
         if rank == 0:
@@ -523,6 +523,91 @@ class WCT:
     def comm_destroy(self) -> None:
         self._chk(self._lib.wct_comm_destroy(self._ctx))
         self.has_comm = False
+        self._coll_keep = None
+
+    def comm_info(self):
+        """(nranks, rank) of the communicator / transport the context holds; (0, 0) without one."""
+        n, r = c_int(), c_int()
+        self._chk(self._lib.wct_comm_info(self._ctx, byref(n), byref(r)))
+        return n.value, r.value
+
+    def comm_attach_collectives(self, all_reduce, broadcast, sendrecv, nranks: int, rank: int) -> None:
+        """Install a caller-supplied transport for stylize_sharded / level_sharded (include/wct_hip.h wct_collectives): three Python
+        callables `all_reduce(buf_ptr, count, stream) -> int`, `broadcast(buf_ptr, nbytes, root, stream) -> int`,
+        `sendrecv(ops, stream) -> int` with ops = [(peer, is_send, buf_ptr, nbytes)]; device pointers and the HIP stream arrive as
+        integers, 0 = success.  (Test infrastructure drives the C cascade through rank threads this way; a production transport would be C.)"""
+        def _sr(user, ops, n, stream):
+            return int(sendrecv([(ops[i].peer, ops[i].is_send, ops[i].buf, ops[i].bytes) for i in range(n)], stream))
+        table = _lib.WctCollectives(None, _lib.ALL_REDUCE_FN(lambda user, buf, count, stream: int(all_reduce(buf, count, stream))),
+                                    _lib.BROADCAST_FN(lambda user, buf, nbytes, root, stream: int(broadcast(buf, nbytes, root, stream))),
+                                    _lib.SENDRECV_FN(_sr))
+        self._chk(self._lib.wct_comm_attach_collectives(self._ctx, byref(table), int(nranks), int(rank)))
+        self._coll_keep = table          # the C side copied the table; the callback thunks must outlive it
+        self.has_comm = True
+
+    def comm_selftest(self) -> None:
+        """Exercise the context's transport between the job's ranks with known data (all-reduce, broadcast, ring and neighbour
+        send / recv) and raise if anything comes back wrong (wct_comm_selftest; collective: every rank calls it)."""
+        self._stream()
+        self._chk(self._lib.wct_comm_selftest(self._ctx))
+
+    def shard_geometry(self, W_total: int, nranks: int, rank: int, halo_mode: str = "auto"):
+        """-> (own0, own1, in0, in1, resolved halo mode) of `rank` in an `nranks`-strip job over a W_total-wide content (wct_shard_geometry)."""
+        v = [c_int() for _ in range(5)]
+        rc = self._lib.wct_shard_geometry(int(W_total), int(nranks), int(rank), _lib.HALO_MODES[halo_mode], *[byref(x) for x in v])
+        if rc != 0:
+            raise ValueError("shard_geometry: width %d cannot be cut into %d strips under halo mode %r" % (W_total, nranks, halo_mode))
+        return v[0].value, v[1].value, v[2].value, v[3].value, {0: "auto", 1: "recompute", 2: "exchange"}[v[4].value]
+
+    @torch.no_grad()
+    def stylize_sharded(self, content_ext: torch.Tensor, style: torch.Tensor, W_total: int, in0: int, in1: int, alpha: Optional[float] = None,
+                        halo_mode: str = "auto", style_mode: str = "auto", broadcast_map: bool = False,
+                        range_total: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """The WHOLE column-sharded cascade in ONE library call (wct_stylize_sharded): this rank's strip + level-5 margin in
+        (columns [in0, in1) of the W_total-wide content, see shard_geometry), its owned columns of the stylised image out
+        ([1, 3, H', own_w']).  Geometry, crops, the style side (strips / owner / replicate), the per-level all-reduce, the optional
+        broadcasts and the neighbour exchange all run inside the library on the context's communicator (comm_init) or transport."""
+        alpha = self.alpha if alpha is None else float(alpha)
+        c, s = self._img(content_ext), self._img(style)
+        H, Win = int(c.shape[1]), int(c.shape[2])
+        if Win != in1 - in0:
+            raise ValueError("stylize_sharded: content_ext has %d columns, [in0, in1) = [%d, %d)" % (Win, in0, in1))
+        nr, rk = self.comm_info()
+        own0, own1 = self.shard_geometry(W_total, max(nr, 1), rk, halo_mode)[:2]
+        if out is None:
+            out = torch.empty(3 * H * (own1 - own0), device=c.device, dtype=torch.float32)
+        elif out.dtype != torch.float32 or not out.is_cuda or not out.is_contiguous() or out.numel() < 3 * H * (own1 - own0):
+            raise ValueError("out must be a contiguous fp32 CUDA tensor with at least %d values" % (3 * H * (own1 - own0)))
+        ho, wo = c_int(), c_int()
+        self._stream()
+        self._chk(self._lib.wct_stylize_sharded(self._ctx, c.data_ptr(), H, int(W_total), int(in0), int(in1), s.data_ptr(), int(s.shape[1]), int(s.shape[2]),
+                                                alpha, _lib.HALO_MODES[halo_mode], _lib.STYLE_MODES[style_mode], _lib.SHARD_BROADCAST_MAP if broadcast_map else 0,
+                                                out.data_ptr(), byref(ho), byref(wo), range_total.data_ptr() if range_total is not None else None))
+        self._style_keep = s
+        return out.view(-1)[: 3 * ho.value * wo.value].view(1, 3, ho.value, wo.value)
+
+    @torch.no_grad()
+    def style_moments(self, level: int, style_strip: torch.Tensor, x0: int = 0, x1: int = -1):
+        """Encoder of a STRIP of the style image + raw fp64 moments over its feature columns [x0, x1) -> (sum[C], sumsq[C, C]) on the
+        context's side stream, visible to the caller's stream (wct_style_moments; the style side of sharded.py's "strips" mode)."""
+        x = self._img(style_strip)
+        self._style_keep = x
+        C = model_zoo.feature_channels(self.mode, level)
+        s = torch.empty(C, device=x.device, dtype=torch.float64)
+        ss = torch.empty(C, C, device=x.device, dtype=torch.float64)
+        self._stream()
+        self._chk(self._lib.wct_style_moments(self._ctx, level, x.data_ptr(), int(x.shape[1]), int(x.shape[2]), int(x0), int(x1), s.data_ptr(), ss.data_ptr()))
+        return s, ss
+
+    @torch.no_grad()
+    def style_solve(self, level: int, n_s: float, sum_s: torch.Tensor, sumsq_s: torch.Tensor) -> None:
+        """Global style moments of a level -> cov_s^(1/2), mu_s inside the context (what style_prepare leaves), on the side stream."""
+        C = model_zoo.feature_channels(self.mode, level)
+        sum_s, sumsq_s = self._dev_f64(sum_s, C, "sum_s"), self._dev_f64(sumsq_s, C * C, "sumsq_s")
+        self._solve_keep = getattr(self, "_solve_keep", {})
+        self._solve_keep[level] = (sum_s, sumsq_s)       # read asynchronously by the side stream
+        self._stream()
+        self._chk(self._lib.wct_style_solve(self._ctx, level, float(n_s), sum_s.data_ptr(), sumsq_s.data_ptr()))
 
     @torch.no_grad()
     def level_sharded(self, level: int, img: torch.Tensor, x0: int, x1: int, n_total: float, alpha: Optional[float] = None,

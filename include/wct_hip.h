@@ -176,9 +176,11 @@ int wct_content_decode(wct_ctx* ctx, int level, const double* M, const double* b
 
 /* The multi-GPU variant of one level BEHIND the boundary ("multi-GPU variant takes an ncclComm_t"; the reference is
  * single-GPU, WCT.py:97,110 -- nothing to replace but styleTransfer() itself, WCT.py:98-106, run on a column strip).
- *   wct_comm_load        dlopen the RCCL the host process uses (path of librccl.so; NULL: "librccl.so.1", "librccl.so",
- *                        /opt/rocm/lib/librccl.so) and resolve ncclGetUniqueId / ncclCommInitRank / ncclAllReduce / ncclCommDestroy.
- *                        libwct_hip.so itself links against no communication library; single-GPU callers never load one.
+ *   wct_comm_load        dlopen the RCCL the host process uses and resolve ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclAllReduce /
+ *                        ncclBroadcast / ncclSend / ncclRecv / ncclGroupStart / ncclGroupEnd.  A non-NULL path is THE library to use: if it
+ *                        cannot be opened the call fails (no second RCCL is mapped behind the caller's back); NULL searches "librccl.so.1",
+ *                        "librccl.so", /opt/rocm/lib/librccl.so.  libwct_hip.so itself links against no communication library;
+ *                        single-GPU callers never load one.  wct_comm_library returns the path that was loaded ("" before).
  *   wct_comm_unique_id   ncclGetUniqueId into 128 caller bytes (rank 0; the caller ships them to the other ranks, e.g. through the
  *                        rendezvous it already has)
  *   wct_comm_init        ncclCommInitRank on the context's device: the context then OWNS a communicator over `nranks` contexts
@@ -193,14 +195,99 @@ int wct_content_decode(wct_ctx* ctx, int level, const double* M, const double* b
  *                        -> (M, b) folded into the decoder's first conv -> decoder -> out (3 x Ho x Wo).  range_total (device, one
  *                        double, may be NULL) receives the node-wide clamp count.  Same arithmetic in the same order as
  *                        wct_content_encode / all-reduce / wct_content_solve / wct_content_decode: bit-identical to that path.
- *                        --mode 16x only (the wide models' deferred solves read back per call: use the split-level entries). */
+ *                        With feature maps wider than 128 channels (--mode original) each solve reads one flag back (host synchronisation),
+ *                        as in the split-level entries. */
 int wct_comm_load(const char* librccl_path);
+const char* wct_comm_library(void);
 int wct_comm_unique_id(unsigned char* id128);
 int wct_comm_init(wct_ctx* ctx, int nranks, int rank, const unsigned char* id128);
 int wct_comm_attach(wct_ctx* ctx, void* nccl_comm, int nranks, int rank);
 int wct_comm_destroy(wct_ctx* ctx);
 int wct_level_sharded(wct_ctx* ctx, int level, const float* content, int H, int W, int x0, int x1, double n_total, float alpha,
                       float* out, int* Ho, int* Wo, double* range_total);
+
+/* The WHOLE column-sharded cascade behind the boundary: WCT.py:120-125 (levels 5 -> 1 of styleTransfer, WCT.py:98-106) run by `nranks`
+ * contexts -- one per GPU / process -- on column strips of ONE content image.  The reference is single-GPU (WCT.py:97,110); what
+ * makes the path shardable is that every operator of it is local except the content (and style) statistics (util_wct.py:68-70,94-96).
+ * Everything is enqueued on the context's stream(s): strip geometry and per-level crops, the style side, encoders, owned-column
+ * moments, the collectives, matrix functions, fold, decoders, the neighbour exchange.  No host synchronisation, no allocation after the
+ * first call of a size (--mode 16x; the wide models' C > 128 solves read one flag back per solve, as the split-level entries do).
+ *
+ * Collectives.  The cascade talks to its peers through a wct_collectives table (below).  wct_comm_init / wct_comm_attach install the
+ * RCCL one (ncclAllReduce / ncclBroadcast / ncclGroupStart + ncclSend + ncclRecv + ncclGroupEnd on the context's communicator and
+ * stream); wct_comm_attach_collectives installs a caller-supplied transport (another communication library; the test suite's
+ * in-process world that moves device buffers between rank threads).  All functions are asynchronous on `stream` and return 0 or an
+ * error code of the transport; buffers are device memory.
+ *
+ * Geometry (wct_shard_geometry, a pure function): rank r owns content columns [own0, own1) (origins are multiples of 16, so every
+ * pooling grid coincides with the untiled image's; the last strip takes the remainder) and must be GIVEN columns [in0, in1) = its strip
+ * plus the level-5 margin of the halo mode towards the image interior:
+ *   WCT_HALO_EXCHANGE   every level runs on own +- (160, 72, 24, 10, 2) columns (level 5..1: the composite encode->decode receptive
+ *                       field) and, between levels, neighbours exchange the (72, 24, 10, 2) outermost OWNED columns of the image just
+ *                       decoded -- two messages per level boundary, 3 x H x margin floats (<= 3.5 MB at H = 4096);
+ *   WCT_HALO_RECOMPUTE  cumulative margins (272, 112, 40, 16, 6), no exchange;
+ *   WCT_HALO_AUTO       exchange for strips narrower than 2560 columns (and at least 144), recompute otherwise.
+ * With those margins a strip's owned columns are bit-identical to the untiled level given the same (M, b).
+ *
+ * Style side (style_mode; the style image is given WHOLE to every rank, as the reference gives it to every level, WCT.py:121-125):
+ *   WCT_STYLE_STRIPS     the style image is cut into column strips like the content: rank r encodes its strip + the ENCODER's
+ *                        receptive field (80, 32, 12, 4, 1 columns at level 5..1) at every level, raw moments over its owned feature
+ *                        columns; the five levels' sums travel in ONE all-reduce together with the level-5 content moments; every rank
+ *                        then takes the five matrix square roots on its side stream.  Per-rank style work = 1/nranks (+ margins);
+ *   WCT_STYLE_OWNER      level L's style side is computed whole by rank (5 - L) mod nranks and broadcast (C*C + C doubles per level);
+ *   WCT_STYLE_REPLICATE  every rank computes all five levels (no communication; tiny styles);
+ *   WCT_STYLE_AUTO       strips when the style is at least 64 columns per rank wide, else replicate.
+ * WCT_SHARD_BROADCAST_MAP: rank 0 alone solves for the colouring map and broadcasts (M [C*C], b [C]) doubles per level; default: every
+ * rank solves for itself (the all-reduce returns identical bits everywhere and the solver is deterministic).
+ *
+ * Per level: ONE all-reduce of [sum C | sumsq C*C | f16x3 range flag] doubles (level 5: + the style sums in strips mode), the optional
+ * broadcasts above, and in exchange mode one grouped send/recv pair per neighbour.
+ *
+ *   content_ext   columns [in0, in1) of the content, planar 3 x H x (in1 - in0)
+ *   style         the whole style image, planar 3 x Hs x Ws
+ *   out_owned     receives this rank's owned columns of the result, planar 3 x Ho x Wo (Ho = 16 floor(H / 16); Wo = own1 - own0,
+ *                 less what floor pooling cut off the last strip); must hold 3 * H * (own1 - own0) floats
+ *   range_total   device, one double, may be NULL: the node-wide count of f16x3 clamps as of the last all-reduce (wct_range_flag_f64)
+ * Results are those of the split-level entries driven by wct_hip/sharded.py over the same transport, bit for bit. */
+typedef struct wct_p2p {
+  int peer;       /* rank */
+  int is_send;    /* 1: send `bytes` from buf to peer; 0: receive `bytes` from peer into buf */
+  void* buf;
+  size_t bytes;
+} wct_p2p;
+typedef struct wct_collectives {
+  void* user;
+  int (*all_reduce_sum_f64)(void* user, double* buf, size_t count, void* hip_stream);       /* in place, every rank */
+  int (*broadcast)(void* user, void* buf, size_t bytes, int root, void* hip_stream);        /* in place, every rank */
+  int (*sendrecv)(void* user, const wct_p2p* ops, int n_ops, void* hip_stream);             /* ONE group: all ops posted together */
+} wct_collectives;
+#define WCT_HALO_AUTO 0
+#define WCT_HALO_RECOMPUTE 1
+#define WCT_HALO_EXCHANGE 2
+#define WCT_STYLE_AUTO 0
+#define WCT_STYLE_OWNER 1
+#define WCT_STYLE_STRIPS 2
+#define WCT_STYLE_REPLICATE 3
+#define WCT_SHARD_BROADCAST_MAP 1   /* flags */
+int wct_comm_attach_collectives(wct_ctx* ctx, const wct_collectives* coll, int nranks, int rank);
+/* nranks / rank of the communicator or transport the context holds (0 / 0: none) */
+int wct_comm_info(const wct_ctx* ctx, int* nranks, int* rank);
+/* Known data through all three functions of the context's transport between the job's ranks (all-reduce; broadcast from the last rank;
+ * a ring send / recv; the cascade's grouped neighbour exchange), checked on the host: 0, or WCT_ERR_HIP naming what came back wrong.
+ * Collective over the job (every rank calls it), synchronises the stream: a set-up time check (bench.py runs it before timing). */
+int wct_comm_selftest(wct_ctx* ctx);
+/* halo_mode may be WCT_HALO_AUTO; *halo_mode_resolved (may be NULL) receives what it resolves to for this width and rank count */
+int wct_shard_geometry(int W_total, int nranks, int rank, int halo_mode, int* own0, int* own1, int* in0, int* in1, int* halo_mode_resolved);
+int wct_stylize_sharded(wct_ctx* ctx, const float* content_ext, int H, int W_total, int in0, int in1, const float* style, int Hs, int Ws,
+                        float alpha, int halo_mode, int style_mode, int flags, float* out_owned, int* Ho, int* Wo, double* range_total);
+/* The two halves of WCT_STYLE_STRIPS for callers that run the collectives themselves (wct_hip/sharded.py over torch.distributed):
+ *   wct_style_moments  encoder of `style_strip` (3 x Hs x Ws_strip: the rank's style columns + margins) + raw moments over feature columns
+ *                      [x0, x1) (x1 < 0: to the end) into sum[C], sumsq[C*C] (device f64) on the context's SIDE stream; the caller's
+ *                      stream is made to wait for them (so that a collective enqueued next sees them)
+ *   wct_style_solve    global (n_s, sum, sumsq) of the style feature map -> cov_s^(1/2), mu_s inside the context (what
+ *                      wct_style_prepare leaves for the level), on the side stream behind everything enqueued on the caller's */
+int wct_style_moments(wct_ctx* ctx, int level, const float* style_strip, int Hs, int Ws_strip, int x0, int x1, double* sum, double* sumsq);
+int wct_style_solve(wct_ctx* ctx, int level, double n_s, const double* sum_s, const double* sumsq_s);
 
 /* replaces the cascade of WCT.py:120-125 (levels 5..1, num_run times).  out must hold 3*H*W floats. */
 int wct_stylize(wct_ctx* ctx, const float* content, int H, int W, const float* style, int Hs, int Ws, float alpha,

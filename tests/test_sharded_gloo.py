@@ -25,7 +25,7 @@ class OracleEngine:
         from oracle import wct_oracle
         self.o = wct_oracle
         self.m = wct_oracle.Modules("16x", weights)
-        self.style_moments = {}
+        self.style_stats = {}
         self.cF = None
 
     @staticmethod
@@ -38,7 +38,16 @@ class OracleEngine:
     def style_prepare(self, style, levels=(5, 4, 3, 2, 1)):
         s = (style[0] if style.dim() == 4 else style).numpy()
         for L in levels:
-            self.style_moments[L] = self._raw(self.m.encode(L, s))
+            self.style_stats[L] = self._raw(self.m.encode(L, s))
+
+    # style_mode "strips": raw moments of a STRIP of the style over its owned feature columns, then the all-reduced totals come back
+    def style_moments(self, level, strip, x0=0, x1=-1):
+        s = (strip[0] if strip.dim() == 4 else strip).numpy()
+        _, sm, ss = self._raw(self.m.encode(level, np.ascontiguousarray(s)), x0, x1)
+        return torch.from_numpy(sm), torch.from_numpy(ss)
+
+    def style_solve(self, level, n_s, sum_s, sumsq_s):
+        self.style_stats[level] = (float(n_s), sum_s.numpy().copy(), sumsq_s.numpy().copy())
 
     # the level's style statistics as one fp64 vector (this checker ships raw moments: n | sum[C] | sumsq[C*C])
     def style_stats_count(self, level):
@@ -47,13 +56,13 @@ class OracleEngine:
         return 1 + C + C * C
 
     def style_export(self, level):
-        n, s, ss = self.style_moments[level]
+        n, s, ss = self.style_stats[level]
         return torch.from_numpy(np.concatenate([[n], s, ss.reshape(-1)]).astype(np.float64))
 
     def style_import(self, level, stats):
         v = stats.numpy()
         C = int(round((-1 + (1 + 4 * (v.size - 1)) ** 0.5) / 2))
-        self.style_moments[level] = (float(v[0]), v[1:1 + C].copy(), v[1 + C:].reshape(C, C).copy())
+        self.style_stats[level] = (float(v[0]), v[1:1 + C].copy(), v[1 + C:].reshape(C, C).copy())
 
     def content_encode(self, level, img, x0=0, x1=-1):
         x = (img[0] if img.dim() == 4 else img).numpy()
@@ -66,7 +75,7 @@ class OracleEngine:
             mu = s / n
             return mu, (ss - n * np.outer(mu, mu)) / (n - 1)
         mu_c, cov_c = mc(n_c, sum_c.numpy(), sumsq_c.numpy())
-        n_s, s_s, ss_s = self.style_moments[level]
+        n_s, s_s, ss_s = self.style_stats[level]
         mu_s, cov_s = mc(n_s, s_s, ss_s)
         M, b = self.o.affine_from_moments(mu_c, cov_c, mu_s, cov_s, alpha)
         return torch.from_numpy(M), torch.from_numpy(b)
@@ -87,7 +96,7 @@ class OracleEngine:
         return torch.from_numpy(self.m.decode(level, y))[None]
 
 
-def _worker(rank, world, port, H, W, out_path, broadcast_map=False, halo_mode="recompute"):
+def _worker(rank, world, port, H, W, out_path, broadcast_map=False, halo_mode="recompute", style_mode="owner", style_w=96):
     for p in (REPO, PKG):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -103,9 +112,9 @@ def _worker(rank, world, port, H, W, out_path, broadcast_map=False, halo_mode="r
         eng.o.set_num_threads(2)
         rng = np.random.default_rng(5)
         content = rng.random((3, H, W), dtype=np.float32)
-        style = rng.random((3, 80, 96), dtype=np.float32)
-        sh = ShardedStylizer(eng, dist, H, W, 80, 96, alpha=1.0, broadcast_map=broadcast_map, halo_mode=halo_mode)
-        assert sh.halo_mode == halo_mode
+        style = rng.random((3, 80, style_w), dtype=np.float32)
+        sh = ShardedStylizer(eng, dist, H, W, 80, style_w, alpha=1.0, broadcast_map=broadcast_map, halo_mode=halo_mode, style_mode=style_mode)
+        assert sh.halo_mode == halo_mode and sh.style_mode == style_mode
         x0, x1 = sh.input_columns()
         strip = sh.stylize_strip(torch.from_numpy(np.ascontiguousarray(content[:, :, x0:x1])), torch.from_numpy(style))
         parts = [None] * world
@@ -125,24 +134,30 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("world,H,W,bmap,halo", [
-    (2, 64, 1280, False, "recompute"), (3, 48, 1925, False, "recompute"),
-    (6, 32, 1152, False, "recompute"),   # 6 ranks: every level's style side on another rank, rank 5 none
-    (3, 48, 1925, True, "recompute"),    # rank 0 solves and broadcasts (M, b)
-    (3, 48, 1925, False, "exchange"),    # exact per-level margins + neighbour exchange of the decoded edge columns;
-    (6, 32, 1157, True, "exchange"),     # 1157 -> 1152 columns after level 5: the last strip shrinks before it is sent
-    (8, 32, 1290, False, "exchange")])   # BASELINE configs[3]'s topology: 8 strips, neighbour exchange (1290 -> 1280 columns)
-def test_sharded_equals_untiled(tmp_path, oracle, weights16x, world, H, W, bmap, halo):
+@pytest.mark.parametrize("world,H,W,bmap,halo,smode,sw", [
+    (2, 64, 1280, False, "recompute", "owner", 96), (3, 48, 1925, False, "recompute", "owner", 96),
+    (6, 32, 1152, False, "recompute", "owner", 96),   # 6 ranks: every level's style side on another rank, rank 5 none
+    (3, 48, 1925, True, "recompute", "owner", 96),    # rank 0 solves and broadcasts (M, b)
+    (3, 48, 1925, False, "exchange", "owner", 96),    # exact per-level margins + neighbour exchange of the decoded edge columns;
+    (6, 32, 1157, True, "exchange", "owner", 96),     # 1157 -> 1152 columns after level 5: the last strip shrinks before it is sent
+    (8, 32, 1290, False, "exchange", "owner", 96),    # BASELINE configs[3]'s topology: 8 strips, neighbour exchange (1290 -> 1280 columns)
+    # the STYLE cut into column strips like the content (every rank: its strip + the encoder's receptive field at every level, sums in the
+    # level-5 all-reduce): 2 ranks; 3 ranks over a width that floor pooling shrinks (333 -> 320 feature-aligned columns at level 5) with
+    # rank 0 solving and broadcasting (M, b); 8 ranks x 40 columns (narrower than the level-5 margin of 80: strips reach across
+    # several neighbours); every rank repeating the whole style side
+    (2, 64, 1280, False, "recompute", "strips", 96), (3, 48, 1925, True, "exchange", "strips", 333),
+    (8, 32, 1290, False, "exchange", "strips", 320), (3, 48, 1925, False, "recompute", "replicate", 96)])
+def test_sharded_equals_untiled(tmp_path, oracle, weights16x, world, H, W, bmap, halo, smode, sw):
     out = str(tmp_path / "sharded.npy")
-    mp.spawn(_worker, args=(world, _free_port(), H, W, out, bmap, halo), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), H, W, out, bmap, halo, smode, sw), nprocs=world, join=True)
     got = np.load(out)
     rng = np.random.default_rng(5)
     content = rng.random((3, H, W), dtype=np.float32)
-    style = rng.random((3, 80, 96), dtype=np.float32)
+    style = rng.random((3, 80, sw), dtype=np.float32)
     # untiled run of the SAME engine (world = 1): isolates the sharding logic from algorithmic differences
     from wct_hip.sharded import ShardedStylizer
     eng = OracleEngine(weights16x)
-    one = ShardedStylizer(eng, None, H, W, 80, 96, rank=0, world=1)
+    one = ShardedStylizer(eng, None, H, W, 80, sw, rank=0, world=1)
     ref = one.stylize_strip(torch.from_numpy(content), torch.from_numpy(style)).numpy()
     assert got.shape == ref.shape              # W = 1925 shrinks to 1920 at level 5
     assert got.shape[3] == (W // 16) * 16 and got.shape[2] == (H // 16) * 16
@@ -172,6 +187,13 @@ def test_strip_bounds():
     assert ShardedStylizer(None, None, 4096, 10240, 2048, 2048, rank=3, world=8).halo_mode == "exchange"
     assert ShardedStylizer(None, None, 2160, 3840 * 8, 2048, 2048, rank=3, world=8).halo_mode == "recompute"
     assert ShardedStylizer(None, None, 4096, 10240, 2048, 2048, rank=3, world=8).input_columns() == (3840 - 160, 5120 + 160)
+    # style side: strips from 64 style columns per rank, else every rank repeats it; one rank has nothing to share
+    from wct_hip.sharded import STYLE_HALO
+    assert ShardedStylizer(None, None, 4096, 10240, 2048, 2048, rank=3, world=8).style_mode == "strips"
+    assert ShardedStylizer(None, None, 4096, 10240, 2048, 2048, rank=3, world=8).style_bounds[3] == (768, 1024)
+    assert ShardedStylizer(None, None, 4096, 10240, 300, 260, rank=3, world=8).style_mode == "replicate"
+    assert ShardedStylizer(None, None, 4096, 10240, 2048, 2048, rank=0, world=1).style_mode == "replicate"
+    assert all(STYLE_HALO[L] % (1 << (L - 1)) == 0 and STYLE_HALO[L] <= LEVEL_HALO[L] for L in (5, 4, 3, 2, 1))
     with pytest.raises(ValueError):
         ShardedStylizer(None, None, 64, 400, 64, 64, rank=0, world=4, halo_mode="exchange")
 
@@ -192,7 +214,7 @@ def _replica_worker(rank, world, port, out_dir):
         style = np.random.default_rng(2).random((3, 48, 64), dtype=np.float32)
         content = np.random.default_rng(10 + rank).random((3, 32 + 16 * rank, 48), dtype=np.float32)   # a different image per rank
         out = ReplicaStylizer(eng, dist).stylize(torch.from_numpy(content), torch.from_numpy(style))
-        assert sorted(eng.style_moments) == [1, 2, 3, 4, 5]
+        assert sorted(eng.style_stats) == [1, 2, 3, 4, 5]
         np.save(os.path.join(out_dir, "r%d.npy" % rank), out.numpy())
     finally:
         dist.destroy_process_group()
