@@ -129,6 +129,7 @@ struct wct_ctx {
   // how the context talks to its peers (wct_comm_init / _attach: RCCL on `comm`; wct_comm_attach_collectives: the caller's transport)
   wct_collectives coll{};
   bool coll_set = false, coll_rccl = false;
+  bool shard_emulate = false;   // MEASUREMENT ONLY (debug key "shard_emulate"): comm_ranks / comm_rank are an emulated job's, the real communicator has ONE rank
   // wct_stylize_sharded: the level's cropped input, the decoded strip, the next level's assembled input (exchange mode), the four edge blocks
   // (send left | send right | recv left | recv right), the rank's style strip, a level's style statistics in transit, (M | b) in transit
   DevBuf shIn, shOut, shNext, shEdge, shStyle, shStats, shMb;
@@ -1123,6 +1124,18 @@ int wct_debug_set(wct_ctx* ctx, const char* key, double value) {
     if (!getenv("WCT_DEBUG")) return fail(ctx, WCT_ERR_INVALID, "debug_set: 'eig_skip' produces wrong results by design (timing experiment); set WCT_DEBUG to allow it");
     ctx->eig_skip = (int)value; ctx->eig_calls = 0;
   }
+  else if (!strcmp(key, "shard_emulate")) {
+    // MEASUREMENT ONLY (bench.py passes.cfg4_rank_sim): this context, holding a ONE-rank communicator, runs wct_stylize_sharded with the
+    // geometry of rank (value % 100) of a (value / 100)-rank job; every peer is itself (a received margin is the equally wide block it
+    // sends the other way), the all-reduces see its own sums only -- what ONE rank of the job executes, with other numbers.  0: off.
+    if (!getenv("WCT_DEBUG")) return fail(ctx, WCT_ERR_INVALID, "debug_set: 'shard_emulate' produces wrong results by design (timing experiment); set WCT_DEBUG to allow it");
+    const int v = (int)value, world = v / 100, rank = v % 100;
+    if (v == 0) { if (ctx->shard_emulate) { ctx->shard_emulate = false; ctx->comm_ranks = 1; ctx->comm_rank = 0; } return WCT_OK; }
+    if (!ctx->coll_set || (ctx->comm_ranks != 1 && !ctx->shard_emulate)) return fail(ctx, WCT_ERR_STATE, "debug_set: 'shard_emulate' needs a ONE-rank communicator on the context");
+    if (world < 2 || rank >= world) return fail(ctx, WCT_ERR_INVALID, "debug_set: 'shard_emulate' = 100 * ranks + rank");
+    ctx->shard_emulate = true; ctx->comm_ranks = world; ctx->comm_rank = rank;
+    return WCT_OK;
+  }
   else if (!strcmp(key, "side_priority")) {
     // priority of the style-side stream relative to the default: 0 = default, 1 = lowest (style kernels only fill the
     // content cascade's gaps), -1 = highest
@@ -1647,7 +1660,7 @@ int wct_comm_destroy(wct_ctx* ctx) {
     (void)g_rccl.CommDestroy(ctx->comm);
   }
   ctx->comm = nullptr; ctx->comm_owned = false; ctx->comm_ranks = 0; ctx->comm_rank = 0;
-  ctx->coll = wct_collectives{}; ctx->coll_set = false; ctx->coll_rccl = false;
+  ctx->coll = wct_collectives{}; ctx->coll_set = false; ctx->coll_rccl = false; ctx->shard_emulate = false;
   return WCT_OK;
 }
 

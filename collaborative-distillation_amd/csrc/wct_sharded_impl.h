@@ -130,6 +130,8 @@ int check_job(wct_ctx* ctx, Job& j, int W_total, int Ws, int halo_mode, int styl
   if (j.style_mode == WCT_STYLE_STRIPS && !shard::strip_bounds(Ws, j.world, j.sxs))
     return fail(ctx, WCT_ERR_INVALID, "stylize_sharded: style width %d too small for %d strips (use WCT_STYLE_REPLICATE)", Ws, j.world);
   j.bmap = (flags & WCT_SHARD_BROADCAST_MAP) != 0 && j.world > 1;
+  if (ctx->shard_emulate && (j.bmap || j.style_mode == WCT_STYLE_OWNER))
+    return fail(ctx, WCT_ERR_INVALID, "stylize_sharded: the one-rank emulation of a job (debug key shard_emulate) has no peers to receive broadcasts from");
   return WCT_OK;
 }
 
@@ -413,6 +415,8 @@ int wct_stylize_sharded(wct_ctx* ctx, const float* content_ext, int H, int W_tot
       }
       if (left_w) ops[n++] = wct_p2p{rank - 1, 0, recvL, (size_t)rows * left_w * sizeof(float)};
       if (right_w) ops[n++] = wct_p2p{rank + 1, 0, recvR, (size_t)rows * right_w * sizeof(float)};
+      if (ctx->shard_emulate)
+        for (int i = 0; i < n; ++i) ops[i].peer = 0;      // every peer is this rank: recv k <- send k (equal widths)
       if (n) COLLCHK(ctx, "neighbour exchange (send / recv)", co.sendrecv(co.user, ops, n, st));
       float* next = reinterpret_cast<float*>(ctx->shNext.p);
       const int Wn = left_w + my_w + right_w;

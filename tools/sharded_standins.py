@@ -121,6 +121,17 @@ class InProcessWorld:
         return InProcessGroup(self, rank)
 
 
+class _DevPtr:
+    """A raw device pointer as something torch.as_tensor() wraps without copying (__cuda_array_interface__)."""
+
+    def __init__(self, ptr: int, count: int, typestr: str):
+        self.__cuda_array_interface__ = {"shape": (int(count),), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+
+
+def dev_tensor(ptr: int, count: int, dtype) -> torch.Tensor:
+    return torch.as_tensor(_DevPtr(ptr, count, {torch.float64: "<f8", torch.float32: "<f4", torch.uint8: "|u1"}[dtype]), device="cuda")
+
+
 class InProcessGroup:
     isend, irecv = "isend", "irecv"
 
@@ -143,6 +154,35 @@ class InProcessGroup:
 
     def barrier(self):
         self.w._bar.wait()
+
+    def c_transport(self):
+        """This group as the three callables of wct_hip.WCT.comm_attach_collectives (include/wct_hip.h wct_collectives): the library's own
+        cascade (wct_stylize_sharded) then talks to its peers -- the other rank threads -- through exactly the collectives above.  The
+        callbacks run on the rank's thread inside the library call, whose stream is the thread's current stream."""
+        def guard(fn):
+            def run(*a):
+                try:
+                    fn(*a)
+                    return 0
+                except BaseException as e:      # noqa: BLE001  an exception must not unwind through the C frames
+                    self.error = e
+                    try:
+                        self.w._bar.abort()
+                    except Exception:           # noqa: BLE001
+                        pass
+                    return 1
+            return run
+
+        def all_reduce(ptr, count, stream):
+            self.all_reduce(dev_tensor(ptr, count, torch.float64))
+
+        def broadcast(ptr, nbytes, root, stream):
+            self.broadcast(dev_tensor(ptr, nbytes, torch.uint8), src=root)
+
+        def sendrecv(ops, stream):
+            self.batch_isend_irecv([(self.isend if is_send else self.irecv, dev_tensor(ptr, nbytes // 4, torch.float32), peer)
+                                    for peer, is_send, ptr, nbytes in ops])
+        return guard(all_reduce), guard(broadcast), guard(sendrecv)
 
     def _event(self):
         if self.w.sync_every:
@@ -226,7 +266,8 @@ class InProcessGroup:
 def run_in_process(world: int, make_engine, content: torch.Tensor, style: torch.Tensor, sync_every: bool = False, **kw):
     """Stylise `content` [3, H, W] as a `world`-rank column-strip job inside this process (InProcessWorld): returns (the
     assembled image [1, 3, H', W'], the per-rank groups).  `make_engine()` is called once per rank (each rank owns a context);
-    kw goes to ShardedStylizer (halo_mode, broadcast_map, alpha)."""
+    kw goes to ShardedStylizer (halo_mode, broadcast_map, alpha, style_mode).  c_cascade=True: every rank's frame is ONE library call
+    (wct_stylize_sharded) whose transport table is this world's collectives (InProcessGroup.c_transport)."""
     import threading
     H, W = int(content.shape[-2]), int(content.shape[-1])
     wd = InProcessWorld(world, sync_every)
@@ -243,6 +284,8 @@ def run_in_process(world: int, make_engine, content: torch.Tensor, style: torch.
             torch.cuda.set_device(dev)
             with torch.cuda.stream(streams[r]):
                 streams[r].wait_event(ready)
+                if kw.get("c_cascade"):
+                    engines[r].comm_attach_collectives(*groups[r].c_transport(), world, r)
                 sh = ShardedStylizer(engines[r], groups[r], H, W, int(style.shape[-2]), int(style.shape[-1]), **kw)
                 x0, x1 = sh.input_columns()
                 outs[r] = (sh.own, sh.stylize_strip(content[:, :, x0:x1].contiguous(), style))
@@ -255,6 +298,7 @@ def run_in_process(world: int, make_engine, content: torch.Tensor, style: torch.
         t.start()
     for t in threads:
         t.join()
+    errs = [getattr(g, "error", None) for g in groups] + errs      # what a transport callback swallowed inside the C frames comes first
     first = next((e for e in errs if e is not None and not isinstance(e, threading.BrokenBarrierError)), None) or next((e for e in errs if e is not None), None)
     if first is not None:
         raise first
