@@ -477,26 +477,67 @@ def main():
         return np.ascontiguousarray(np.concatenate(parts, axis=2))
 
     collectives_used = [None]
+    sharded_checks = {}         # N > 1: first-contact verdicts of the library's own cascade, per configuration
 
-    def make_step(cfg, eng):
-        """-> (step(), megapixels of the whole frame, description, content on the device)"""
-        fh, fw = {"cfg2": (H, W * world), "cfg3": (H3, W3), "cfg4": (H4, W4)}[cfg]
+    def all_ranks_agree(ok):
+        """True only if `ok` holds on EVERY rank (one MIN all-reduce; every rank calls it)."""
+        t = torch.tensor([1.0 if ok else 0.0], device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(t.item() > 0.5)
+
+    def c_transport_ready(eng):
+        """The engine's transport for wct_stylize_sharded: its own RCCL communicator over the job's ranks (the product path), checked with
+        known data (wct_comm_selftest) -- or, when the ranks share one GPU over gloo (1-GPU box: RCCL refuses two ranks on a device), the
+        torch.distributed adapter of tools/sharded_standins.py, so that the same C cascade runs there.  -> description, or raises."""
+        if not getattr(eng, "has_comm", False):
+            if backend == "nccl":
+                eng.comm_init(dist)
+            else:
+                from tools.sharded_standins import dist_transport
+                eng.comm_attach_collectives(*dist_transport(dist), world, rank)
+        eng.comm_selftest()
+        return ("library: wct_stylize_sharded, ONE call per frame, RCCL on the context's own communicator" if backend == "nccl" else
+                "library: wct_stylize_sharded, ONE call per frame, over a %s adapter (ranks share a GPU)" % backend)
+
+    def make_step(cfg, eng, fh=None, fw=None, frame=None):
+        """-> (step(), megapixels of the whole frame, description, content on the device).  N > 1: the frame through the library's own
+        sharded cascade (wct_stylize_sharded) unless WCT_C_CASCADE=0 or its first contact fails -- transport self-test, then ONE frame
+        through it and through wct_hip/sharded.py's orchestration over torch.distributed must agree BIT FOR BIT on every rank; otherwise
+        the torch.distributed path is timed and the line says why (config.collectives)."""
+        if fh is None:
+            fh, fw = {"cfg2": (H, W * world), "cfg3": (H3, W3), "cfg4": (H4, W4)}[cfg]
         if world > 1:
             from wct_hip.sharded import ShardedStylizer
-            # WCT_C_COLLECTIVES=1: the per-level all-reduce inside the library on its own RCCL communicator (wct_level_sharded; bit-identical,
-            # ~25 % less host time per frame on the one-GPU rank simulation).  Off by default: it has never run between two devices, and
-            # the driver's scaling run should not be its first contact; a failure to set it up falls back to torch.distributed and says so
-            if os.environ.get("WCT_C_COLLECTIVES") == "1" and backend == "nccl" and not getattr(eng, "has_comm", False):
-                try:
-                    eng.comm_init(dist)
-                except Exception as e:      # noqa: BLE001
-                    sys.stderr.write("bench.py: comm_init failed (%r): per-level collectives stay with torch.distributed\n" % (e,))
-            runner = ShardedStylizer(eng, dist, fh, fw, hs_, ws_, halo_mode=args.halo_mode)
-            collectives_used[0] = "library (wct_level_sharded, own RCCL communicator)" if runner.c_collectives else "torch.distributed"
+            runner = ShardedStylizer(eng, dist, fh, fw, hs_, ws_, halo_mode=args.halo_mode, c_collectives=False)
             x0, x1 = runner.input_columns()                                # own strip + halo of the halo mode
-            content = cu(frame_columns(x0, x1, cfg))
-            return (lambda: runner.stylize_strip(content, style)), fh * fw / 1e6, \
-                "%dx%d content in %d column strips (halo: %s), %dx%d style" % (fw, fh, world, runner.halo_mode, ws_, hs_), content
+            content = cu(frame(x0, x1) if frame is not None else frame_columns(x0, x1, cfg))
+            used = "torch.distributed (wct_hip/sharded.py orchestration of the split-level entries)"
+            if os.environ.get("WCT_C_CASCADE", "1") != "0":
+                ok, why, runner_c = True, None, None
+                try:
+                    note = c_transport_ready(eng)
+                    runner_c = ShardedStylizer(eng, dist, fh, fw, hs_, ws_, halo_mode=args.halo_mode, c_cascade=True)
+                    a = runner_c.stylize_strip(content, style)
+                    b = runner.stylize_strip(content, style)
+                    runner_c.check_range()
+                    runner.check_range()
+                    ok = bool(torch.equal(a, b))
+                    why = None if ok else "C cascade differs from the torch.distributed path by %.3e" % float((a - b).abs().max())
+                    del a, b
+                except Exception as e:      # noqa: BLE001
+                    ok, why = False, repr(e)
+                    sys.stderr.write("bench.py rank %d: C cascade first contact failed: %r\n" % (rank, e))
+                agreed = all_ranks_agree(ok)
+                sharded_checks[cfg if frame is None else "g16"] = {"c_cascade_bitwise_equals_torch_distributed": agreed, "rank0_note": why}
+                if agreed:
+                    runner, used = runner_c, note
+                else:
+                    used += " -- the library's cascade was NOT used: " + (why or "another rank's first-contact check failed")
+            collectives_used[0] = used
+            desc = "%dx%d content in %d column strips (halo: %s; style side: %s), %dx%d style" % (fw, fh, world, runner.halo_mode, runner.style_mode, ws_, hs_)
+            step = lambda: runner.stylize_strip(content, style)     # noqa: E731
+            step.runner = runner
+            return step, fh * fw / 1e6, desc, content
         content = cu(frame_columns(0, fw, cfg))
         eng.reserve(fh, fw, hs_, ws_)
         out = torch.empty((3, fh, fw), device="cuda")
@@ -574,6 +615,7 @@ def main():
         return round(ts[len(ts) // 2], 3), round(ts[0], 3), round(ts[-1], 3)
 
     step, mp, desc, content = make_step(args.config, wct)
+    collectives_timed = collectives_used[0]
     wct.saturation_count(reset=True)
     tele = Telemetry(dev) if rank == 0 else None
     for _ in range(args.warmup):
@@ -588,6 +630,28 @@ def main():
 
     # ---- roofline leg (rank 0 records; every rank runs the steps: they contain collectives)
     profile, roof, _ = kernel_profile(wct, step, record=(rank == 0))
+
+    def sharded_vs_untiled(runner, strip_in, cfg, fw, frame=None):
+        """N > 1 parity, part (b): this rank's owned strip of the sharded frame against the UNTILED frame computed on this same GPU by the
+        single-GPU cascade (no further collective: every rank builds the whole frame itself).  -> max over ranks of max|d| / max|untiled|."""
+        out = runner.stylize_strip(strip_in, style)
+        runner.check_range()
+        full = cu(frame(0, fw) if frame is not None else frame_columns(0, fw, cfg))
+        ref = wct16.stylize(full, style)
+        a = runner.own[0]
+        err = float((out - ref[..., a:a + out.shape[-1]]).abs().max() / ref.abs().max())
+        del full, ref, out
+        t = torch.tensor([err], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    sharded_parity = None
+    if world > 1 and not args.steps_only:
+        fw_ = {"cfg2": W * world, "cfg4": W4}[args.config]
+        # bound: the sharded tests' -- 5e-4; 1e-3 on the 4096-row config-4 frame (tests/test_sharded_gpu.py: sharded and untiled (M, b) differ
+        # by ~1e-8 in the moments, which the five whitenings of a 42 MP noise frame amplify further than those of an 8 MP one)
+        sharded_parity = {"timed_frame_strips_vs_untiled_same_gpu": sharded_vs_untiled(step.runner, content, args.config, fw_),
+                          "limit": 1e-3 if args.config == "cfg4" else 5e-4}
     del step
 
     # ---- extra passes (never `value`)
@@ -599,7 +663,8 @@ def main():
         step4, mp4, desc4, content4 = make_step("cfg4", wct)
         k4 = max(3, args.steps // 2)
         dt4 = timed(step4, k4, 2)
-        passes["cfg4_strong"] = {"workload": desc4, "ms_per_frame": round(dt4 / k4 * 1e3, 3), "MPs": round(mp4 * k4 / dt4, 1), "scaling": "strong"}
+        passes["cfg4_strong"] = {"workload": desc4, "ms_per_frame": round(dt4 / k4 * 1e3, 3), "MPs": round(mp4 * k4 / dt4, 1), "scaling": "strong",
+                                 "collectives": collectives_used[0], "strips_vs_untiled_same_gpu": sharded_vs_untiled(step4.runner, content4, "cfg4", W4)}
         del step4, content4
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
@@ -820,6 +885,45 @@ def main():
             parity["reference_uhd_pair"] = up
             parity_ok = parity_ok and up["ok"]
         parity_ok = bool(parity_ok)
+    elif world > 1 and extra:
+        # N > 1: a throughput line must carry a correctness signal too (VERDICT r5 missing #4).  Three checks, every rank takes part:
+        #   (a) first contact: the library's cascade == wct_hip/sharded.py over torch.distributed, bit for bit on every rank (make_step);
+        #   (b) every rank's owned strip of the TIMED frame against the untiled frame computed on its own GPU, <= 5e-4 (the sharded tests' bound);
+        #   (c) BASELINE configs[3]'s geometry against THE REFERENCE'S OWN PIXELS: G16's 10240x512 frame in N strips, <= 1e-3
+        parity = {"gate": "N > 1: library cascade bitwise == torch.distributed orchestration (first contact, every rank); every rank's strip of the "
+                          "timed frame vs the untiled frame on its own GPU <= 5e-4; G16 (10240x512 in N strips) vs the reference's pixels <= 1e-3; "
+                          "no f16x3 saturation", "f16x3_saturated_threads": int(saturated), "first_contact": sharded_checks}
+        parity.update(sharded_parity or {})
+        ok = saturated == 0 and sharded_parity is not None and sharded_parity["timed_frame_strips_vs_untiled_same_gpu"] <= sharded_parity["limit"]
+        if "cfg4_strong" in passes:
+            ok = ok and passes["cfg4_strong"]["strips_vs_untiled_same_gpu"] <= 1e-3      # (the 4096-row frame: the sharded tests' bound at that size)
+        if os.environ.get("WCT_C_CASCADE", "1") != "0":
+            ok = ok and all(v["c_cascade_bitwise_equals_torch_distributed"] for v in sharded_checks.values())
+        g16 = load_fixture("g16_cfg4_geometry.npz")
+        if g16 is not None:
+            from tests.fixture_compare import cfg4_geometry_frames
+            c_np, s_np = cfg4_geometry_frames()
+            if tuple(s_np.shape) == tuple(style_np.shape) and np.array_equal(s_np, style_np):
+                step_g, _, _, content_g = make_step("cfg4", wct16, fh=512, fw=10240, frame=lambda a, b: np.ascontiguousarray(c_np[:, :, a:b]))
+                out_g = step_g()
+                step_g.runner.check_range()
+                parts = [None] * world
+                dist.all_gather_object(parts, (step_g.runner.own[0], out_g.cpu().numpy()))
+                g_ok = True
+                if rank == 0:
+                    rg = compare_to_fixture(np.concatenate([p[1] for p in sorted(parts, key=lambda t: t[0])], axis=3)[0], g16)
+                    g_ok = bool(rg["max"] <= GATE)
+                    parity["g16_cfg4_geometry"] = {"hip_vs_reference": rg["max"], "p9999": rg["lattice_p9999"], "limit": GATE, "strips": world, "ok": g_ok,
+                                                   "reference": "G16: util_wct.WCT (real 16x checkpoints, torch CPU) on the 10240x512 seed-5 frame, 983 040 lattice pixels + 8 crops"}
+                ok = all_ranks_agree(ok and g_ok)
+                del step_g, content_g, out_g, parts
+            else:
+                parity["g16_cfg4_geometry"] = {"skipped": "the timed style is not G16's (2048x2048, seed 2)"}
+                ok = all_ranks_agree(ok)
+        else:
+            parity["g16_cfg4_geometry"] = {"error": "tests/golden/g16_cfg4_geometry.npz missing"}
+            ok = all_ranks_agree(False)
+        parity_ok = bool(ok)
     elif saturated:
         parity_ok = False
         parity = {"f16x3_saturated_threads": int(saturated)}
@@ -854,7 +958,7 @@ def main():
                                                    "cfg3": "BASELINE configs[2]", "cfg4": "BASELINE configs[3] (strong scaling)"}[cfg]),
                        "name": ("cfg2" if world == 1 else "cfg2x%d" % world) if cfg == "cfg2" else cfg,
                        "content_total": "%dx%d" % {"cfg2": (W * world, H), "cfg3": (W3, H3), "cfg4": (W4, H4)}[cfg], "parallelism": "content column strips x%d" % world,
-                       "dist_backend": (backend if world > 1 else None), "collectives": collectives_used[0]},
+                       "dist_backend": (backend if world > 1 else None), "collectives": collectives_timed},
             "roofline": roof, "passes": passes or None, "cpu_baseline": cpu, "kernels": profile,
         }
         if parity_ok is False:
@@ -867,14 +971,17 @@ def main():
 
 
 def rank_sim(wct, style, Hf, Wf, strip_of, ms_one_gpu, scaling, world=8, ranks=(0, 3), frames=4):
-    """What ONE rank of the `world`-GPU job executes (ShardedStylizer.stylize_strip on its strip + halos, the style levels it
-    owns, the per-level collectives as launches on a 1-rank RCCL communicator, the neighbour exchange as device copies), timed
-    on this GPU -- twice: `torch_distributed` (three library calls per level + torch.distributed.all_reduce + tensor glue) and
-    `c_collectives` (the level as ONE library call with ncclAllReduce inside, include/wct_hip.h wct_level_sharded).
+    """What ONE rank of the `world`-GPU job executes (its strip + halos, its share of the style side, the per-level collectives as
+    launches on a 1-rank RCCL communicator, the neighbour exchange with itself as the neighbour), timed on this GPU.
+    Three arrangements per rank: `torch_distributed_owner` = round 5's (Python orchestration, style levels dealt out whole: rank 0 carries level
+    5 = 45.6 % of the style FLOPs), `torch_distributed` = the same orchestration with the STYLE cut into column strips too (round 6), `c_cascade` =
+    the whole frame as ONE library call (wct_stylize_sharded, style strips, collectives issued by the library on a 1-rank RCCL communicator with
+    the rank's geometry emulated: debug key shard_emulate).
     `host_enqueue_ms`: wall time until stylize_strip has returned for every frame = `pure_enqueue_ms` (Python + torch.distributed +
     ctypes orchestration, nothing waited for) + `range_flag_wait_ms` (stylize_strip reads the node-wide f16x3 flag of frame k - 2 at a
     FIXED lag, ADVICE r3, and blocks until that frame's read-back has landed: GPU time, not orchestration -- VERDICT r4 weak #6);
-    `ms_per_frame`: the same frames with the final sync (the better of the two paths bounds the prediction).  The slowest rank bounds
+    `ms_per_frame`: the same frames with the final sync (the better of the two round-6 paths bounds the prediction;
+    `predicted_efficiency_round5_arrangement` is the same figure for round 5's arrangement).  The slowest rank bounds
     the N-GPU frame time: no link time, no skew -- the compute-only scaling prediction.
     strip_of(x0, x1) -> device tensor of content columns [x0, x1); scaling "strong": ms_one_gpu is the WHOLE frame on one GPU;
     "weak": ms_one_gpu is one GPU's own 1/world of the frame (its N = 1 step)."""
@@ -897,51 +1004,68 @@ def rank_sim(wct, style, Hf, Wf, strip_of, ms_one_gpu, scaling, world=8, ranks=(
     stats = {L: wct.style_export(L).clone() for L in (5, 4, 3, 2, 1)}
     torch.cuda.synchronize()
     res = {"world": world, "frame": "%dx%d" % (Wf, Hf), "scaling": scaling, "halo_mode": None, "collectives": note, "ranks": {}}
-    worst = 0.0
+    worst, worst_owner = 0.0, 0.0
     hs, ws = int(style.shape[-2]), int(style.shape[-1])
-    # the level chain as ONE library call with RCCL inside (wct_level_sharded) needs a communicator on the engine: one rank here
+    # the frame as ONE library call with RCCL inside (wct_stylize_sharded) needs a communicator on the engine: one rank here, given the
+    # GEOMETRY of rank r of the job by debug key "shard_emulate" (WCT_DEBUG-gated: its peers are itself -- right work, other numbers)
     c_ok = False
     if real is not None:
         try:
             if not getattr(wct, "has_comm", False):
                 wct.comm_init(real)
+            wct.comm_selftest()
             c_ok = True
         except Exception as e:      # noqa: BLE001
-            res["c_collectives_error"] = repr(e)
+            res["c_cascade_error"] = repr(e)
+    had_debug = os.environ.get("WCT_DEBUG")
     for r in ranks:
         entry = {}
-        for tag, c_coll in (("torch_distributed", False), ("c_collectives", True)):
-            if c_coll and not c_ok:
+        for tag, smode, c_cas in (("torch_distributed_owner", "owner", False), ("torch_distributed", "strips", False), ("c_cascade", "strips", True)):
+            if c_cas and not c_ok:
                 continue
             grp = LoopbackGroup(r, world, real)
             grp.style_stats = stats
-            sh = ShardedStylizer(wct, grp, Hf, Wf, hs, ws, halo_mode="auto", c_collectives=c_coll)
-            res["halo_mode"] = sh.halo_mode
-            x0, x1 = sh.input_columns()
-            strip = strip_of(x0, x1)
-            for _ in range(2):
-                sh.stylize_strip(strip, style)
-            torch.cuda.synchronize()
-            sh.t_range_wait = 0.0
-            t0 = time.perf_counter()
-            for _ in range(frames):
-                out = sh.stylize_strip(strip, style)
-            t1 = time.perf_counter()
-            torch.cuda.synchronize()
-            t2 = time.perf_counter()
+            if c_cas:
+                os.environ["WCT_DEBUG"] = "1"
+                wct.debug_set("shard_emulate", 100 * world + r)
+            try:
+                sh = ShardedStylizer(wct, grp, Hf, Wf, hs, ws, halo_mode="auto", c_collectives=False, style_mode=smode, c_cascade=c_cas)
+                res["halo_mode"] = sh.halo_mode
+                x0, x1 = sh.input_columns()
+                strip = strip_of(x0, x1)
+                for _ in range(2):
+                    sh.stylize_strip(strip, style)
+                torch.cuda.synchronize()
+                sh.t_range_wait = 0.0
+                t0 = time.perf_counter()
+                for _ in range(frames):
+                    out = sh.stylize_strip(strip, style)
+                t1 = time.perf_counter()
+                torch.cuda.synchronize()
+                t2 = time.perf_counter()
+            finally:
+                if c_cas:
+                    wct.debug_set("shard_emulate", 0)
+                    if had_debug is None:
+                        os.environ.pop("WCT_DEBUG", None)
+                    else:
+                        os.environ["WCT_DEBUG"] = had_debug
             assert bool(torch.isfinite(out).all())
             ms = (t2 - t0) / frames * 1e3
             host, wait = (t1 - t0) / frames * 1e3, sh.t_range_wait / frames * 1e3
-            entry[tag] = {"ms_per_frame": round(ms, 3), "host_enqueue_ms": round(host, 3), "range_flag_wait_ms": round(wait, 3),
+            entry[tag] = {"style_side": smode, "ms_per_frame": round(ms, 3), "host_enqueue_ms": round(host, 3), "range_flag_wait_ms": round(wait, 3),
                           "pure_enqueue_ms": round(host - wait, 3), "pure_enqueue_share_of_frame": round((host - wait) / ms, 3)}
             entry.update({"columns_in": x1 - x0, "columns_owned": sh.own[1] - sh.own[0]})
             del strip
-        best = min(v["ms_per_frame"] for k, v in entry.items() if isinstance(v, dict))
+        best = min(v["ms_per_frame"] for k, v in entry.items() if isinstance(v, dict) and k != "torch_distributed_owner")
         entry["ms_per_frame"] = best
         worst = max(worst, best)
+        worst_owner = max(worst_owner, entry["torch_distributed_owner"]["ms_per_frame"])
         res["ranks"][str(r)] = entry
     if c_ok:
         wct.comm_destroy()
+    eff = lambda w_: round(ms_one_gpu / w_ / world, 3) if scaling == "strong" else round(ms_one_gpu / w_, 3)     # noqa: E731
+    res["predicted_efficiency_round5_arrangement"] = eff(worst_owner)     # style levels dealt out whole (rank 0: level 5), Python orchestration
     res["predicted_ms_per_frame"] = round(worst, 3)
     res["predicted_MPs"] = round(Hf * Wf / 1e6 / worst * 1e3, 1)
     if scaling == "strong":

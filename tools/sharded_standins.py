@@ -92,6 +92,59 @@ class LoopbackGroup:
         return [self._Done() for _ in ops]
 
 
+def dist_transport(dist):
+    """torch.distributed as the three callables of wct_hip.WCT.comm_attach_collectives: the library's cascade (wct_stylize_sharded) over a
+    process group the library has no transport of its own for -- gloo between ranks that SHARE one GPU (bench.py / tests on a 1-GPU box; host-staged,
+    synchronising) -- so that the C cascade's geometry and ordering are exercised by multi-process jobs there too.  With "nccl" the engine's own
+    RCCL table (comm_init) is the product path; this adapter is test infrastructure."""
+    stage = dist.get_backend() != "nccl"
+
+    def guard(fn):
+        def run(*a):
+            try:
+                fn(*a)
+                return 0
+            except BaseException as e:      # noqa: BLE001
+                sys.stderr.write("dist_transport: %r\n" % (e,))
+                return 1
+        return run
+
+    def all_reduce(ptr, count, stream):
+        t = dev_tensor(ptr, count, torch.float64)
+        if stage:
+            h = t.cpu()
+            dist.all_reduce(h)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t)
+
+    def broadcast(ptr, nbytes, root, stream):
+        t = dev_tensor(ptr, nbytes, torch.uint8)
+        if stage:
+            h = t.cpu()
+            dist.broadcast(h, src=root)
+            t.copy_(h)
+        else:
+            dist.broadcast(t, src=root)
+
+    def sendrecv(ops, stream):
+        reqs, staged = [], []
+        for peer, is_send, ptr, nbytes in ops:
+            t = dev_tensor(ptr, nbytes // 4, torch.float32)
+            if is_send:
+                reqs.append(dist.P2POp(dist.isend, t.cpu() if stage else t, peer))
+            else:
+                buf = torch.empty(t.shape, dtype=t.dtype) if stage else t
+                staged.append((t, buf))
+                reqs.append(dist.P2POp(dist.irecv, buf, peer))
+        for r in dist.batch_isend_irecv(reqs):
+            r.wait()
+        if stage:
+            for t, buf in staged:
+                t.copy_(buf)
+    return guard(all_reduce), guard(broadcast), guard(sendrecv)
+
+
 class InProcessWorld:
     """ALL ranks of a `world`-rank job as threads of ONE process on ONE device, each with its own engine and its own stream --
     a stand-in for RCCL whose collectives move DEVICE buffers and are ordered by events only (no host staging, no stream or

@@ -50,13 +50,15 @@ for k, name in (("cfg4_rank_sim", "10240×4096 in 8 strips"), ("cfg2x8_rank_sim"
     rs = p.get(k, {})
     if rs:
         lines.append("* One rank's share of the 8-GPU job, timed on one GPU (%s): %s ms per frame → %s predicted%s (compute + orchestration only; no link time, no skew)." % (
-            name, g(rs.get("predicted_ms_per_frame"), "%.2f"), ("%s× one GPU" % g(rs.get("predicted_speedup_vs_1gpu"), "%.2f")) if rs.get("predicted_speedup_vs_1gpu") else ("%s efficiency" % g(rs.get("predicted_efficiency"), "%.3f")), ""))
+            name, g(rs.get("predicted_ms_per_frame"), "%.2f"), ("%s× one GPU" % g(rs.get("predicted_speedup_vs_1gpu"), "%.2f")) if rs.get("predicted_speedup_vs_1gpu") else ("%s efficiency" % g(rs.get("predicted_efficiency"), "%.3f")), " (round 5's arrangement on the same box: %s efficiency)" % g(rs.get("predicted_efficiency_round5_arrangement"), "%.3f") if rs.get("predicted_efficiency_round5_arrangement") else ""))
         for r, e in sorted((rs.get("ranks") or {}).items()):
-            for tag in ("torch_distributed", "c_collectives"):
+            for tag, what in (("torch_distributed_owner", "round 5's arrangement: Python orchestration, style levels dealt out whole"),
+                              ("torch_distributed", "Python orchestration over torch.distributed, style in strips"),
+                              ("c_cascade", "ONE library call per frame, RCCL inside (`wct_stylize_sharded`), style in strips")):
                 t = e.get(tag)
                 if t:
                     lines.append("  * rank %s, %s: %s ms per frame; host %s ms = %s ms pure enqueue (%s of the frame) + %s ms waiting for an old frame's range flag." % (
-                        r, "three calls + torch.distributed per level" if tag == "torch_distributed" else "ONE library call per level, RCCL inside (`wct_level_sharded`)",
+                        r, what,
                         g(t.get("ms_per_frame"), "%.2f"), g(t.get("host_enqueue_ms"), "%.2f"), g(t.get("pure_enqueue_ms"), "%.2f"), g(t.get("pure_enqueue_share_of_frame"), "%.2f"), g(t.get("range_flag_wait_ms"), "%.2f")))
 lines.append("* CPU checker on the same host, the timed frame itself: %s MP/s on %s threads (%s)." % (g(cpu.get("value"), "%.3f"), cpu.get("cores"), cpu.get("kind")))
 ks = d.get("kernels") or []
