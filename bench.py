@@ -191,37 +191,32 @@ def family_peak(name):
 
 
 class Telemetry:
-    """GPU clock / power samples during a timed loop, taken by a CHILD process polling the amdgpu sysfs files every ~2 ms (no thread
+    """GPU clock / power samples during a timed loop, taken by a CHILD process polling the amdgpu sysfs files every ~5 ms (no thread
     of this process: the step loop's enqueue rate must not change) -- so that the 7.3 .. 9.1 ms box-to-box spread of the same build
-    (profiles/r04_box_spread_final_build.txt) can be attributed.  Nothing readable -> {"source": None}."""
+    (profiles/r04_box_spread_final_build.txt) can be attributed.  The child samples only between start() and stop() and appends to a
+    temporary FILE (a pipe nobody drains fills after ~2 s and blocks the writer: ADVICE r5); it is killed at exit whatever happens.
+    Nothing readable -> {"source": None}.  read_sclk(): the device's clock NOW, read by this process (one sysfs read, ~20 us)."""
     CHILD = r"""
-import glob, sys, time
-dev = sys.argv[1]
-def first(pats):
-    for p in pats:
-        g = sorted(glob.glob(p))
-        if g:
-            return g[0]
-    return None
-fp = first([dev + "/hwmon/hwmon*/power1_average", dev + "/hwmon/hwmon*/power1_input"])
-ff = first([dev + "/hwmon/hwmon*/freq1_input"])
-fm = first([dev + "/hwmon/hwmon*/freq2_input"])
-ft = first([dev + "/hwmon/hwmon*/temp2_input", dev + "/hwmon/hwmon*/temp1_input"])
+import sys, time
+fp, ff, fm, ft, out = sys.argv[1:6]
 def rd(f):
     try:
         return int(open(f).read().split()[0])
     except Exception:
         return -1
-print("files", fp, ff, fm, ft, flush=True)
-while True:
-    print(time.time(), rd(fp) if fp else -1, rd(ff) if ff else -1, rd(fm) if fm else -1, rd(ft) if ft else -1, flush=True)
-    time.sleep(0.002)
+sys.stdin.readline()                      # start()
+with open(out, "a", buffering=1) as o:
+    while True:
+        o.write("%f %d %d %d %d\n" % (time.time(), rd(fp), rd(ff), rd(fm), rd(ft)))
+        time.sleep(0.005)
 """
 
     def __init__(self, device_index=0):
+        import atexit
         import glob
         import subprocess
-        self.proc, self.t0 = None, None
+        import tempfile
+        self.proc, self.t0, self.out, self.f_sclk = None, None, None, None
         # the box may expose many amdgpu cards (partitions of a multi-GPU host): find THIS device's sysfs node through its PCI address
         dev = None
         try:
@@ -236,26 +231,65 @@ while True:
             cards = [c for c in sorted(glob.glob("/sys/class/drm/card[0-9]*/device")) if glob.glob(c + "/hwmon/hwmon*")]
             if len(cards) != 1:          # several candidates and no PCI match: a wrong card's numbers are worse than none
                 return
+
             dev = cards[0]
+
+        def first(pats):
+            for pat in pats:
+                g = sorted(glob.glob(dev + pat))
+                if g:
+                    return g[0]
+            return "-"
+        files = [first(["/hwmon/hwmon*/power1_average", "/hwmon/hwmon*/power1_input"]), first(["/hwmon/hwmon*/freq1_input"]),
+                 first(["/hwmon/hwmon*/freq2_input"]), first(["/hwmon/hwmon*/temp2_input", "/hwmon/hwmon*/temp1_input"])]
+        self.f_sclk = files[1] if files[1] != "-" else None
         try:
-            self.proc = subprocess.Popen([sys.executable, "-c", self.CHILD, dev], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
-            self.files = self.proc.stdout.readline().split()[1:]
+            fd, self.out = tempfile.mkstemp(prefix="wct_telemetry_", suffix=".txt")
+            os.close(fd)
+            self.proc = subprocess.Popen([sys.executable, "-c", self.CHILD] + files + [self.out], stdin=subprocess.PIPE, stdout=subprocess.DEVNULL,
+                                         stderr=subprocess.DEVNULL, text=True)
+            atexit.register(self._kill)
         except Exception:     # noqa: BLE001 -- garnish
             self.proc = None
 
+    def _kill(self):
+        if self.proc is not None and self.proc.poll() is None:
+            self.proc.kill()
+        if self.out and os.path.exists(self.out):
+            try:
+                os.unlink(self.out)
+            except OSError:
+                pass
+
+    def read_sclk(self):
+        """MHz, or None."""
+        try:
+            return int(open(self.f_sclk).read().split()[0]) * 1e-6 if self.f_sclk else None
+        except Exception:     # noqa: BLE001
+            return None
+
     def start(self):
         self.t0 = time.time()
+        if self.proc is not None:
+            try:
+                self.proc.stdin.write("go\n")
+                self.proc.stdin.flush()
+            except Exception:     # noqa: BLE001
+                pass
 
     def stop(self):
         t1 = time.time()
         if self.proc is None:
             return {"source": None}
         time.sleep(0.01)
-        self.proc.terminate()
         try:
-            out = self.proc.communicate(timeout=5)[0]
+            self.proc.terminate()
+            self.proc.wait(timeout=5)
+            out = open(self.out).read()
         except Exception:     # noqa: BLE001
             return {"source": None}
+        finally:
+            self._kill()
         rows = [ln.split() for ln in out.splitlines() if ln and ln[0].isdigit()]
         rows = [[float(v) for v in r] for r in rows if len(r) == 5 and self.t0 <= float(r[0]) <= t1]
         if not rows:
@@ -263,7 +297,7 @@ while True:
         col = lambda i, scale: [r[i] * scale for r in rows if r[i] >= 0]   # noqa: E731
         pw, sclk, mclk, temp = col(1, 1e-6), col(2, 1e-6), col(3, 1e-6), col(4, 1e-3)
         avg = lambda v: round(sum(v) / len(v), 1) if v else None   # noqa: E731
-        return {"source": "amdgpu sysfs hwmon of PCI device %s (power1_average | power1_input, freq1_input, freq2_input, temp), %d samples at ~2 ms during the timed steps" % (self.pci, len(rows)),
+        return {"source": "amdgpu sysfs hwmon of PCI device %s (power1_average | power1_input, freq1_input, freq2_input, temp), %d samples at ~5 ms over %.1f s (the timed steps + the sustained block)" % (self.pci, len(rows), t1 - self.t0),
                 "power_W_avg": avg(pw), "power_W_max": round(max(pw), 1) if pw else None, "sclk_MHz_avg": avg(sclk),
                 "sclk_MHz_min": round(min(sclk), 1) if sclk else None, "mclk_MHz_avg": avg(mclk), "temp_C_avg": avg(temp)}
 
@@ -623,8 +657,44 @@ def main():
     if tele:
         tele.start()
     dt = timed(step, args.steps, 0)
-    telemetry = tele.stop() if tele else None
     value = mp * args.steps / dt
+
+    def sustained_block(seconds=2.0, n_fit=60):
+        """Comparable-across-devices figures (VERDICT r5 task 8; the same binary measured 7.27 .. 7.97 ms on four devices at 2.11 .. 2.25 GHz):
+        (1) ms per step of K more steps timed AFTER `seconds` of back-to-back steps (clocks and temperature settled); (2) n_fit steps
+        synchronised one by one with the device clock read beside each -> least squares ms = a + b * (2200 / sclk) and its prediction at
+        2200 MHz (the step is matrix-core / issue bound: time ~ 1 / sclk; the HBM-side share is the intercept).  Every rank runs the
+        steps (collectives); the clock is rank 0's device."""
+        n = max(args.steps, int(seconds / max(dt / args.steps, 1e-4)))
+        for _ in range(n):
+            step()
+        dts = timed(step, args.steps, 0)
+        res = {"ms_per_step_sustained": round(dts / args.steps * 1e3, 3), "after_s_of_back_to_back_steps": round(n * dt / args.steps, 2)}
+        pts = []
+        for _ in range(n_fit):
+            barrier()
+            t0 = time.perf_counter()
+            step()
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) * 1e3
+            f = tele.read_sclk() if tele else None
+            if f:
+                pts.append((2200.0 / f, ms, f))
+        if len(pts) >= 8:
+            x, y = np.array([q[0] for q in pts]), np.array([q[1] for q in pts])
+            res["sclk_MHz_during_fit"] = [round(float(min(q[2] for q in pts)), 0), round(float(max(q[2] for q in pts)), 0)]
+            res["latency_ms_avg_during_fit"] = round(float(y.mean()), 3)
+            # time ~ 1 / sclk for the whole step is the simple model; the fitted line says how much of it the data supports
+            res["latency_ms_scaled_to_2200MHz"] = round(float((y / x).mean()), 3)
+            if float(x.max() - x.min()) > 0.004:          # the clock moved by > 0.4 % over the samples: a slope can be estimated
+                b, a = np.polyfit(x, y, 1)
+                r = float(np.corrcoef(x, y)[0, 1])
+                res["fit_ms_vs_2200_over_sclk"] = {"intercept_ms": round(float(a), 3), "slope_ms": round(float(b), 3), "r": round(r, 3),
+                                                   "latency_ms_at_2200MHz": round(float(a + b), 3)}
+        return res
+
+    sustained = sustained_block() if not args.steps_only else None
+    telemetry = tele.stop() if tele else None
     saturated = wct.saturation_count()      # threads that clamped an activation to the f16x3 range during the timed steps
     lat_med, lat_min, lat_max = latency_median(step, max(10, min(args.steps, 20)))
 
@@ -936,6 +1006,11 @@ def main():
         live = live_pmc(args.config) if live_ok else None
         pm = pmc_traffic(roof["kernel"], live) or pmc_traffic(roof["kernel"])
         roof["traffic"], roof["traffic_source"] = (pm[0], pm[1]) if pm else (None, None)
+        # what ran the timed steps (inside `roofline` so that a record keeping only this object still says what the device did)
+        roof["device"] = {"sclk_MHz_avg": (telemetry or {}).get("sclk_MHz_avg"), "power_W_avg": (telemetry or {}).get("power_W_avg"),
+                          "ms_per_step": round(dt / args.steps * 1e3, 3),
+                          "ms_per_step_sustained": (sustained or {}).get("ms_per_step_sustained"),
+                          "latency_ms_scaled_to_2200MHz": (sustained or {}).get("latency_ms_scaled_to_2200MHz")}
         r3 = passes.get("cfg3_original", {}).get("roofline") if args.config != "cfg3" else None
         if r3 and live:      # (not attempted when the first collection failed: bounded run time)
             live3 = live_pmc("cfg3")
@@ -950,7 +1025,7 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 3), "latency_ms_median": lat_med, "latency_ms_min_max": [lat_min, lat_max],
             "latency_note": "SURVEY 8(d): each frame synchronised on its own, median of >= 10 (a lone call cannot hide its launch "
                             "latency or its style lane's tail behind the next frame); `value` / ms_per_step = K back-to-back steps, one sync",
-            "gpu_telemetry": telemetry, "higher_is_better": True, "scaling": "strong" if cfg == "cfg4" else "weak",
+            "gpu_telemetry": telemetry, "sustained": sustained, "higher_is_better": True, "scaling": "strong" if cfg == "cfg4" else "weak",
             "vs_baseline": None, "dtype": "f32 (f16x3 split-MFMA products, fp32 accumulate)", "data": "synthetic",
             "parity_ok": parity_ok, "parity": parity,
             "config": {"workload": "PytorchWCT/WCT.py --mode %s, 5-level WCT, %s, alpha=1, style-side work included, images resident in HBM; %s"
@@ -1020,7 +1095,8 @@ def rank_sim(wct, style, Hf, Wf, strip_of, ms_one_gpu, scaling, world=8, ranks=(
     had_debug = os.environ.get("WCT_DEBUG")
     for r in ranks:
         entry = {}
-        for tag, smode, c_cas in (("torch_distributed_owner", "owner", False), ("torch_distributed", "strips", False), ("c_cascade", "strips", True)):
+        for tag, smode, c_cas in (("torch_distributed_owner", "owner", False), ("torch_distributed", "strips", False), ("c_cascade_owner", "owner", True),
+                                  ("c_cascade", "strips", True)):
             if c_cas and not c_ok:
                 continue
             grp = LoopbackGroup(r, world, real)

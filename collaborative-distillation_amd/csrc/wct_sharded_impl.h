@@ -130,8 +130,8 @@ int check_job(wct_ctx* ctx, Job& j, int W_total, int Ws, int halo_mode, int styl
   if (j.style_mode == WCT_STYLE_STRIPS && !shard::strip_bounds(Ws, j.world, j.sxs))
     return fail(ctx, WCT_ERR_INVALID, "stylize_sharded: style width %d too small for %d strips (use WCT_STYLE_REPLICATE)", Ws, j.world);
   j.bmap = (flags & WCT_SHARD_BROADCAST_MAP) != 0 && j.world > 1;
-  if (ctx->shard_emulate && (j.bmap || j.style_mode == WCT_STYLE_OWNER))
-    return fail(ctx, WCT_ERR_INVALID, "stylize_sharded: the one-rank emulation of a job (debug key shard_emulate) has no peers to receive broadcasts from");
+  if (ctx->shard_emulate && j.bmap)
+    return fail(ctx, WCT_ERR_INVALID, "stylize_sharded: the one-rank emulation of a job (debug key shard_emulate) has no peer to receive (M, b) from");
   return WCT_OK;
 }
 
@@ -365,9 +365,14 @@ int wct_stylize_sharded(wct_ctx* ctx, const float* content_ext, int H, int W_tot
       (void)wct_style_stats_count(ctx, level, &ns);
       if (int rc = ensure(ctx, ctx->shStats, ns * sizeof(double))) return rc;
       double* stats = reinterpret_cast<double*>(ctx->shStats.p);
-      if (rank == owner(level))
+      if (rank == owner(level) || ctx->shard_emulate) {
+        // (emulation: a level this rank does not own "arrives" as whatever an earlier wct_style_prepare left in the context -- the
+        //  receiver's import + fold run, the link does not)
+        if (ctx->shard_emulate && !ctx->eigS[level].p) return fail(ctx, WCT_ERR_STATE, "stylize_sharded (emulated): run wct_style_prepare once first");
         if (int rc = wct_style_export(ctx, level, stats)) return rc;
-      COLLCHK(ctx, "broadcast (style statistics)", co.broadcast(co.user, stats, ns * sizeof(double), owner(level), st));
+      }
+      if (!ctx->shard_emulate || rank == owner(level))
+        COLLCHK(ctx, "broadcast (style statistics)", co.broadcast(co.user, stats, ns * sizeof(double), ctx->shard_emulate ? 0 : owner(level), st));
       if (rank != owner(level) && (!j.bmap || rank == 0))
         if (int rc = wct_style_import(ctx, level, stats)) return rc;
     }

@@ -55,6 +55,20 @@ def cfg4_geometry_frames():
     return noise_frame(5, 512, 10240), noise_frame(2, 2048, 2048)
 
 
+def cfg4_natural_frames(gold_dir):
+    """G17: config 4's geometry on a NATURAL image -- rows 824..1335 of the reference's UHD sample (the committed G11 JPEG, 3840 wide)
+    repeated side by side and cropped to 10240 x 512, + the reference's style/in1.jpg (2048 x 2048); ToTensor conversion (uint8 / 255).
+    Same function as tools/make_goldens.py::cfg4_natural_content."""
+    import os
+    from PIL import Image
+
+    def load(name):
+        return np.ascontiguousarray(np.asarray(Image.open(os.path.join(gold_dir, name)).convert("RGB"), dtype=np.float32).transpose(2, 0, 1) / np.float32(255))
+
+    c = load("g11_uhd_content_3840x2160.jpg")[:, 824:1336, :]
+    return np.ascontiguousarray(np.concatenate([c, c, c], axis=2)[:, :, :10240]), load("g11_style_2048x2048.jpg")
+
+
 def compare_to_fixture(img, g):
     """img: 3 x H x W result; g: a frame fixture (dict of arrays).  -> dict of errors relative to the reference's maximum."""
     img = np.asarray(img)

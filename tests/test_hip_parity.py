@@ -4,12 +4,15 @@
   (3) size-independent properties at BASELINE.json's full sizes.
 Tolerances: BASELINE.json north_star = 1e-3 relative (max|d|/max|ref|) end to end; individual operators are
 held much tighter (fp32 convs differ from the reference only by summation order)."""
+import os
+import subprocess
+import sys
 import types
 
 import numpy as np
 import pytest
 
-from tests.conftest import rel_err
+from tests.conftest import PKG, REPO, rel_err
 from wct_hip import model_zoo
 
 pytestmark = pytest.mark.gpu
@@ -110,6 +113,60 @@ def test_moments_and_solve_split_form(torch_cuda, wct16, oracle, C, n):
     if n > 4 * C:
         assert info[0] < 40    # well-conditioned content covariance: the GEMM path must have handled it
     assert rel_err(M.cpu().numpy(), Mr) < 1e-8 and rel_err(b.cpu().numpy(), br) < 1e-8
+
+
+@pytest.mark.parametrize("C,h,w,x0,x1", [(512, 80, 64, 3, 62), (512, 134, 240, 0, 240), (512, 67, 120, 7, 120), (256, 90, 100, 4, 97), (256, 134, 240, 0, 240),
+                                         (384, 64, 80, 1, 79)])
+def test_moments_wide_maps_vs_numpy(torch_cuda, wct16, C, h, w, x0, x1):
+    """The wide levels of --mode original (C = 256 / 512): fp64-product moments against an INDEPENDENT fp64 reference (numpy X^T X)
+    at round-off -- C >= 512 with >= 4096 pixels in the window takes the channel-blocked register kernel (moments.hip moments_blk_kernel<false, 4>:
+    every 128 x 128 block pair, diagonal and off-diagonal, windowed and whole maps), C = 256 / 384 and smaller windows the LDS kernel."""
+    torch = torch_cuda
+    g = torch.Generator(device="cuda").manual_seed(C + h)
+    f = torch.relu(torch.randn((1, h, w, C), device="cuda", generator=g) + 0.3)
+    f[..., 1] = 0
+    f[..., C - 3] *= 1e-3
+    wct16.debug_set("mom32", 0)          # fp64 products at every size (the default for maps below 65 536 pixels)
+    try:
+        n, sm, sq = wct16.moments(f, x0, x1)
+    finally:
+        wct16.debug_set("mom32", 1)
+    X = f[0, :, x0:x1].reshape(-1, C).double().cpu().numpy()
+    assert n == X.shape[0]
+    assert rel_err(sm.cpu().numpy(), X.sum(0)) < 1e-13
+    q = sq.cpu().numpy()
+    assert rel_err(q, X.T @ X) < 1e-13 and np.array_equal(q, q.T)
+
+
+def test_moments_blocked_and_lds_kernels_agree():
+    """The same C = 512 moments through the channel-blocked register kernel (default) and the LDS kernel it replaced (WCT_MOM_BLK=0, an
+    environment switch read once per process: two fresh processes), fp64 products: equal to fp64 round-off, windowed and whole."""
+    code = r"""
+import os, sys, types
+sys.path[:0] = [%r, %r]
+import numpy as np, torch
+from wct_hip import WCT, model_zoo
+e = WCT(types.SimpleNamespace(mode='16x', alpha=1.0), weights=model_zoo.load_npz_weights(os.path.join(%r, 'weights', '16x.npz')))
+g = torch.Generator(device='cuda').manual_seed(5)
+f = torch.relu(torch.randn((1, 134, 240, 512), device='cuda', generator=g) + 0.3)
+e.debug_set('mom32', 0)
+out = {}
+for k, (a, b) in {'whole': (0, 240), 'window': (16, 200)}.items():
+    n, s, q = e.moments(f, a, b)
+    out[k + '.s'], out[k + '.q'] = s.cpu().numpy(), q.cpu().numpy()
+np.savez(sys.argv[1], **out)
+""" % (REPO, PKG, PKG)
+    import tempfile
+    res = []
+    with tempfile.TemporaryDirectory() as d:
+        for blk in ("1", "0"):
+            path = os.path.join(d, "m%s.npz" % blk)
+            r = subprocess.run([sys.executable, "-c", code, path], capture_output=True, text=True, timeout=600, env=dict(os.environ, WCT_DEBUG="1", WCT_MOM_BLK=blk))
+            assert r.returncode == 0, r.stderr[-2000:]
+            res.append(dict(np.load(path)))
+    for k in res[0]:
+        assert rel_err(res[0][k], res[1][k]) < 1e-13, k
+    assert not all(np.array_equal(res[0][k], res[1][k]) for k in res[0])     # two different kernels really ran (summation orders differ)
 
 
 @pytest.mark.parametrize("C,h,w", [(32, 540, 960), (64, 270, 480), (128, 300, 260), (256, 270, 262), (512, 135, 512), (24, 0, 0)])

@@ -180,17 +180,23 @@ def test_g10_numpy_variant(oracle, golden):
 
 
 @pytest.mark.skipif(os.environ.get("WCT_SLOW_TESTS") != "1", reason="~8 min of CPU on 8 cores; set WCT_SLOW_TESTS=1 (the GPU suite checks the same on the GPU box's host cores)")
-@pytest.mark.parametrize("name", ["g13_cfg2_noise", "g13_cfg2_smooth", "g14_cfg3_original", "g15_cfg3_conditioned_noise", "g15_cfg3_conditioned_natural", "g16_cfg4_geometry"])
+@pytest.mark.parametrize("name", ["g13_cfg2_noise", "g13_cfg2_smooth", "g14_cfg3_original", "g15_cfg3_conditioned_noise", "g15_cfg3_conditioned_natural", "g16_cfg4_geometry", "g17_cfg4_geometry_natural"])
 def test_oracle_reproduces_the_full_size_reference_fixtures(name):
     """The oracle at BENCHMARK size against the reference's own pixels (tools/make_goldens.py gen_g13 / gen_g14): measured in the
     build container 6.0e-4 (noise), 7.7e-4 (smooth), 2.4e-3 (config 3, generated weights: chaotic) of the reference's maximum."""
     from oracle import wct_oracle
     from tests.conftest import load_golden, PKG
     from tests.conftest import GOLD
-    from tests.fixture_compare import GATE, cfg2_frames, cfg3_frames, cfg3_natural_frames, cfg4_geometry_frames, compare_to_fixture
+    from tests.fixture_compare import GATE, cfg2_frames, cfg3_frames, cfg3_natural_frames, cfg4_geometry_frames, cfg4_natural_frames, compare_to_fixture
     from wct_hip import model_zoo
     g = load_golden(name + ".npz")
-    if name.startswith("g16"):
+    if name.startswith("g17"):
+        # config 4's geometry on a natural image (the reference's UHD sample tiled to 10240 x 512): an order of magnitude of headroom
+        c, s = cfg4_natural_frames(GOLD)
+        assert abs(float(c.sum(dtype=np.float64)) - float(g["content.checksum"])) < 1e-6
+        out = wct_oracle.stylize(wct_oracle.Modules("16x", model_zoo.load_npz_weights(os.path.join(PKG, "weights", "16x.npz"))), c, s, 1.0)
+        limit = 1e-4
+    elif name.startswith("g16"):
         # config 4's geometry (10240 wide = eight 1280-column strips), 512 rows: the reference's own pixels for the sharded job
         c, s = cfg4_geometry_frames()
         assert abs(float(c.sum(dtype=np.float64)) - float(g["content.checksum"])) < 1e-6

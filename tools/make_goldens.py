@@ -607,6 +607,40 @@ def gen_g16():
     print("G16: mean %.6f std %.6f max %.4f  (%.0f s)" % (g["mean"], g["std"], g["max"], time.time() - t0), flush=True)
 
 
+def cfg4_natural_content(gold_dir=GOLD):
+    """G17's content: config 4's WIDTH from a natural image -- rows 824..1335 (512 rows around the horizon) of the reference's UHD sample
+    (the committed G11 JPEG, 3840 wide), repeated side by side and cropped to 10240 columns.  Same function as tests/fixture_compare.py."""
+    c = load_rgb(os.path.join(gold_dir, "g11_uhd_content_3840x2160.jpg"))[:, 824:1336, :]
+    return np.ascontiguousarray(np.concatenate([c, c, c], axis=2)[:, :, :10240])
+
+
+def gen_g17():
+    """G17 (round 6, VERDICT r5 task 7): config 4's geometry on a NATURAL image -- cfg4_natural_content() (10240 x 512) + the reference's
+    style/in1.jpg (2048 x 2048, the committed G11 JPEG) through util_wct.WCT, real 16x checkpoints, torch CPU, WCT.py:120-125 restated.
+    Uniform noise (G16) leaves the reference's own arithmetic ~1e-3 of room; natural images an order of magnitude more, so this frame
+    holds the 8-strip job to a bound with real headroom.  Same crops as G16 (six across strip boundaries)."""
+    import time
+    torch.set_num_threads(8)
+    util_wct = import_reference()
+    wct = util_wct.WCT(ref_args("16x", 1.0))
+    s = load_rgb(os.path.join(GOLD, "g11_style_2048x2048.jpg"))
+    c = cfg4_natural_content()
+    assert c.shape == (3, 512, 10240) and s.shape == (3, 2048, 2048)
+    t0 = time.time()
+    img = t(c[None])
+    for k in (5, 4, 3, 2, 1):
+        img = ref_style_transfer(wct, getattr(wct, "e%d" % k), getattr(wct, "d%d" % k), img, t(s[None]), 1.0)
+        print("G17: level %d done, %.0f s" % (k, time.time() - t0), flush=True)
+    y = img.squeeze(0).numpy()
+    assert y.shape == (3, 512, 10240) and np.isfinite(y).all()
+    g = pack_frame_fixture(y, G16_CROPS)
+    g["content.checksum"] = np.float64(c.sum(dtype=np.float64))
+    g["style.checksum"] = np.float64(s.sum(dtype=np.float64))
+    g["torch"] = np.array(torch.__version__)
+    np.savez_compressed(os.path.join(GOLD, "g17_cfg4_geometry_natural.npz"), **g)
+    print("G17: mean %.6f std %.6f max %.4f  (%.0f s)" % (g["mean"], g["std"], g["max"], time.time() - t0), flush=True)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 2 and sys.argv[1] == "--only" and sys.argv[2] == "g12":
         os.makedirs(GOLD, exist_ok=True)
@@ -615,6 +649,9 @@ if __name__ == "__main__":
         gen_g14()
         gen_g15()
         gen_g16()
+    elif len(sys.argv) > 2 and sys.argv[1] == "--only" and sys.argv[2] == "g17":
+        os.makedirs(GOLD, exist_ok=True)
+        gen_g17()
     elif len(sys.argv) > 2 and sys.argv[1] == "--only" and sys.argv[2] == "g13":
         os.makedirs(GOLD, exist_ok=True)
         gen_g13(tuple(sys.argv[3:]) or ("noise", "smooth"))

@@ -11,16 +11,19 @@ import numpy as np
 from oracle import wct_oracle
 from wct_hip import model_zoo
 from tests.conftest import GOLD, PKG, load_golden
-from tests.fixture_compare import cfg2_frames, cfg3_frames, cfg3_natural_frames, cfg4_geometry_frames, compare_to_fixture
+from tests.fixture_compare import cfg2_frames, cfg3_frames, cfg3_natural_frames, cfg4_geometry_frames, cfg4_natural_frames, compare_to_fixture
 
 OUT = os.path.join(GOLD, "oracle_vs_reference.json")
-names = sys.argv[1:] or ["g13_cfg2_noise", "g13_cfg2_smooth", "g14_cfg3_original", "g15_cfg3_conditioned_noise", "g15_cfg3_conditioned_natural", "g16_cfg4_geometry"]
+names = sys.argv[1:] or ["g13_cfg2_noise", "g13_cfg2_smooth", "g14_cfg3_original", "g15_cfg3_conditioned_noise", "g15_cfg3_conditioned_natural", "g16_cfg4_geometry", "g17_cfg4_geometry_natural"]
 res = json.load(open(OUT)) if os.path.exists(OUT) else {}
 wct_oracle.set_num_threads(os.cpu_count() or 1)
 for name in names:
     g = load_golden(name + ".npz")
     t0 = time.time()
-    if name.startswith("g16"):
+    if name.startswith("g17"):
+        c, s = cfg4_natural_frames(GOLD)
+        mods = wct_oracle.Modules("16x", model_zoo.load_npz_weights(os.path.join(PKG, "weights", "16x.npz")))
+    elif name.startswith("g16"):
         c, s = cfg4_geometry_frames()
         mods = wct_oracle.Modules("16x", model_zoo.load_npz_weights(os.path.join(PKG, "weights", "16x.npz")))
     elif name.startswith("g13"):

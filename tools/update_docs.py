@@ -54,6 +54,7 @@ for k, name in (("cfg4_rank_sim", "10240×4096 in 8 strips"), ("cfg2x8_rank_sim"
         for r, e in sorted((rs.get("ranks") or {}).items()):
             for tag, what in (("torch_distributed_owner", "round 5's arrangement: Python orchestration, style levels dealt out whole"),
                               ("torch_distributed", "Python orchestration over torch.distributed, style in strips"),
+                              ("c_cascade_owner", "ONE library call per frame, RCCL inside (`wct_stylize_sharded`), style levels dealt out whole"),
                               ("c_cascade", "ONE library call per frame, RCCL inside (`wct_stylize_sharded`), style in strips")):
                 t = e.get(tag)
                 if t:
