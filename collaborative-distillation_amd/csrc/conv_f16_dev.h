@@ -411,6 +411,77 @@ __device__ __forceinline__ void c3_block_compute(const u32x4* act, const u32x4* 
   }
 }
 
+// The same with the chunk's sixteen weight operands resident in registers (64 VGPRs): 16 instead of 32 LDS reads per 24 MFMAs, and no
+// weight slab in LDS -- for kernels that run at two waves per SIMD and have the registers (l1_decode_kernel).  Same MFMA order as
+// c3_block_compute: bit-identical.
+struct C3Weights { f16x8 wh[8], wl[8]; };
+__device__ __forceinline__ void c3_load_weights(const u32x4* wgt /* global, [8 ks][hl][kq][16 m] */, int li, int kq, C3Weights& w) {
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) {
+    w.wh[ks] = __builtin_bit_cast(f16x8, wgt[((ks * 2 + 0) * 4 + kq) * 16 + li]);
+    w.wl[ks] = __builtin_bit_cast(f16x8, wgt[((ks * 2 + 1) * 4 + kq) * 16 + li]);
+  }
+}
+template <int NPX = PH_NPX>
+__device__ __forceinline__ void c3_block_compute_w(const u32x4* act, const C3Weights& w, int wave, int li, int kq, f32x4 (&acc)[4]) {
+  const int kh = kq & 1, p = kq >> 1;
+  const u32x4* ah_ = act + (0 * 2 + kh) * NPX + p * 17 + li;
+  const u32x4* al_ = act + (1 * 2 + kh) * NPX + p * 17 + li;
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) {
+    const int off = (wave * 2 + (ks >> 1)) * PH_W + (ks & 1);
+    const f16x8 bh = __builtin_bit_cast(f16x8, ah_[off]);
+    const f16x8 bl = __builtin_bit_cast(f16x8, al_[off]);
+    acc[ks & 3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w.wh[ks], bh, acc[ks & 3], 0, 0, 0);
+    acc[ks & 3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w.wh[ks], bl, acc[ks & 3], 0, 0, 0);
+    acc[ks & 3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w.wl[ks], bh, acc[ks & 3], 0, 0, 0);
+  }
+}
+
+// A chunk of which only the FIRST 8 channels exist (level 1: relu1_1 has 24 = 16 + 8 channels; the second chunk's upper half is padding).
+// The K dimension of a 16x16x32 step is then one whole window ROW: lane group kq = window column kq (4 columns x 8 channels) -- 4 K-steps,
+// 12 MFMAs and 8 operand reads instead of 8 / 24 / 16, and the chunk needs two LDS planes (hi, lo) instead of four.  Weights come out of the
+// SAME block-packed slab (step (wy, column wx) of this form = K-step 2 wy + (wx >> 1), lane group 2 (wx & 1) of the packed one), into 32 VGPRs.
+// The products are those of c3_block_compute on the chunk, summed in another order (fp32 round-off level difference, not bit-identical).
+// act: [hl][NPX] slots (ph_slot), channel half 0 only.
+struct C3HalfWeights { f16x8 wh[4], wl[4]; };
+__device__ __forceinline__ void c3_load_weights_half(const u32x4* wgt, int li, int kq, C3HalfWeights& w) {
+#pragma unroll
+  for (int wy = 0; wy < 4; ++wy) {
+    const int ks = 2 * wy + (kq >> 1), kqp = 2 * (kq & 1);
+    w.wh[wy] = __builtin_bit_cast(f16x8, wgt[((ks * 2 + 0) * 4 + kqp) * 16 + li]);
+    w.wl[wy] = __builtin_bit_cast(f16x8, wgt[((ks * 2 + 1) * 4 + kqp) * 16 + li]);
+  }
+}
+template <int NPX = PH_NPX>
+__device__ __forceinline__ void c3_block_compute_half(const u32x4* act, const C3HalfWeights& w, int wave, int li, int kq, f32x4 (&acc)[4]) {
+  // halo column 2 li + kq of the block row: parity plane (kq & 1), index li + (kq >> 1)
+  const u32x4* ah_ = act + 0 * NPX + (kq & 1) * 17 + (kq >> 1) + li;
+  const u32x4* al_ = act + 1 * NPX + (kq & 1) * 17 + (kq >> 1) + li;
+#pragma unroll
+  for (int wy = 0; wy < 4; ++wy) {
+    const int off = (wave * 2 + wy) * PH_W;
+    const f16x8 bh = __builtin_bit_cast(f16x8, ah_[off]);
+    const f16x8 bl = __builtin_bit_cast(f16x8, al_[off]);
+    acc[wy] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w.wh[wy], bh, acc[wy], 0, 0, 0);
+    acc[wy] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w.wh[wy], bl, acc[wy], 0, 0, 0);
+    acc[wy] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w.wl[wy], bh, acc[wy], 0, 0, 0);
+  }
+}
+// the producer side of that chunk: channels 4 kq .. 4 kq + 3 of its FIRST 8 (lane groups kq = 0, 1; the others hold padding and store nothing)
+// -> 8 bytes in the hi plane and 8 in the lo plane, [hl][npp] slots.  `v` is the pre-activation (ReLU merged with the range clamp).
+__device__ __forceinline__ void store_split4_half(u32x4* planes, int npp, int pix, int kq, const f32x4& v, SatTrack& sat) {
+  if (kq < 2) {
+    u32x2 h, l;
+    sat.m = fmaxf(fmaxf(sat.m, v[0]), v[1]);
+    sat.m = fmaxf(fmaxf(sat.m, v[2]), v[3]);
+    { const HiLo t_ = split2(clamp_relu(v[0]), clamp_relu(v[1])); h[0] = t_.hi; l[0] = t_.lo; }
+    { const HiLo t_ = split2(clamp_relu(v[2]), clamp_relu(v[3])); h[1] = t_.hi; l[1] = t_.lo; }
+    *(reinterpret_cast<u32x2*>(planes + 0 * npp + pix) + kq) = h;
+    *(reinterpret_cast<u32x2*>(planes + 1 * npp + pix) + kq) = l;
+  }
+}
+
 // the lane's output pixel of a tile after c3_block_compute: scale, bias, ReLU, three planar stores
 __device__ __forceinline__ void c3_block_store(const f32x4 (&acc)[4], float inv, const f32x4& bias, float* out, size_t plane, int ty0,
                                                int tx0, int wave, int li, int kq, int H, int W) {

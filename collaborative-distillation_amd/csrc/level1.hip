@@ -188,30 +188,37 @@ __global__ __launch_bounds__(256, 2) void in3_wide_kernel(In3WideArgs a) {
 
 // image -> relu1_1 on the 34 x (TH + 2) halo (LDS, split f16) -> folded decoder conv (24 -> 3) + ReLU -> planar image.
 // TH = 8: 4 waves, two workgroups per CU; TH = 16: 8 waves, one workgroup per CU, halo recompute 1.20 instead of 1.33.
+// Round 6: the folded conv's weight operands live in REGISTERS (96 VGPRs: sixteen for the 16-channel chunk, eight for the 8 real channels
+// of the second, whose K-steps are whole window rows -- conv_f16_dev.h c3_block_compute_w / _half) instead of a 32 KB slab in LDS that every
+// wave re-read per tile, and the second chunk keeps two planes instead of four: per tile and wave 24 operand reads and 36 MFMAs in the second
+// phase instead of 64 and 48, LDS 42 KB (TH = 8: two or three workgroups per CU, whose phases overlap) / 75 KB instead of 87 / 128.
 template <int TH>
 struct L1DecGeo {
   static constexpr int NT = 32 * TH, NWV = TH / 2, HROWS = TH + 2, NPH = FHW * HROWS, NGRP = (NPH + 15) / 16, NG = (NGRP + NWV - 1) / NWV;
   static constexpr int NPI = I2W * (TH + 4), IMGE = NPI + 4, NPX = (HROWS * PH_W + 15) / 16 * 16;
-  static constexpr size_t lds = (size_t)2 * IMGE * 8 + ((size_t)2 * 4 * NPX + 2 * PH_WSLOTS) * 16;   // 86.8 KB (TH = 8: one per CU) / 128.4 KB
+  static constexpr size_t lds = (size_t)2 * IMGE * 8 + (size_t)6 * NPX * 16;   // 42.3 KB (TH = 8) / 74.6 KB (TH = 16)
 };
 
 template <int TH>
-__global__ __launch_bounds__(32 * TH, 1) void l1_decode_kernel(L1DecArgs a) {
+__global__ __launch_bounds__(32 * TH, 2) void l1_decode_kernel(L1DecArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using G = L1DecGeo<TH>;
   constexpr int NT = G::NT, NWV = G::NWV, NPH = G::NPH, NG = G::NG, NPI = G::NPI, NPX = G::NPX;
   u32x2* imgH = reinterpret_cast<u32x2*>(smem);
   u32x2* imgL = imgH + G::IMGE;
-  u32x4* act = reinterpret_cast<u32x4*>(imgL + G::IMGE);   // [2 chunks][4][NPX]  relu1_1 on the halo, pair-major slots (ph_slot)
-  u32x4* wgt = act + 2 * 4 * NPX;                          // [2 chunks][PH_WSLOTS]
+  u32x4* act = reinterpret_cast<u32x4*>(imgL + G::IMGE);   // [4][NPX] channels 0..15 (hl, channel half) | [2][NPX] channels 16..23 (hl): relu1_1 on the halo, pair-major slots (ph_slot)
+  u32x4* act2 = act + 4 * NPX;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, kq = lane >> 4;
   const int ntiles = a.tiles_x * a.tiles_y;
   const unsigned txm = tile_div_magic(a.tiles_x);   // once per workgroup; tile_rc() then stays on the scalar unit
-  for (int e = tid; e < 2 * PH_WSLOTS; e += NT) wgt[e] = a.w2[e];
   if (tid < 4) { imgH[NPI + tid] = u32x2{0u, 0u}; imgL[NPI + tid] = u32x2{0u, 0u}; }
   L1Weights w;
   l1_load_weights(a.c, li, kq, G::IMGE, w);
+  C3Weights w2a;            // the folded decoder conv's operands: registers, loaded once per workgroup from the block-packed slab
+  C3HalfWeights w2b;
+  c3_load_weights(a.w2, li, kq, w2a);
+  c3_load_weights_half(a.w2 + PH_WSLOTS, li, kq, w2b);
   const float inv2 = a.inv2_ptr ? *a.inv2_ptr : a.inv2;
   const f32x4 bias2 = *reinterpret_cast<const f32x4*>(a.b2);
   const size_t plane = (size_t)a.H * a.W;
@@ -262,17 +269,16 @@ __global__ __launch_bounds__(32 * TH, 1) void l1_decode_kernel(L1DecArgs a) {
       }
       f32x4 xs[2];
       l1_conv_pair<false>(imgH, base, w, xs[0], xs[1]);
-#pragma unroll
-      for (int ct = 0; ct < 2; ++ct)
-        store_split4<true>(act + ct * 4 * NPX, NPX, gslot[u], kq, xs[ct], sat);
+      store_split4<true>(act, NPX, gslot[u], kq, xs[0], sat);
+      store_split4_half(act2, NPX, gslot[u], kq, xs[1], sat);
     }
     __syncthreads();
     // ---- folded decoder conv on the two 16-channel chunks, block-packed (conv_f16_dev.h): every lane ends with one output pixel
     f32x4 acc[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-    c3_block_compute<NPX>(act, wgt, wave, li, kq, acc);
-    c3_block_compute<NPX>(act + 4 * NPX, wgt + PH_WSLOTS, wave, li, kq, acc);
+    c3_block_compute_w<NPX>(act, w2a, wave, li, kq, acc);
+    c3_block_compute_half<NPX>(act2, w2b, wave, li, kq, acc);
     c3_block_store(acc, inv2, bias2, a.out, plane, ty0, tx0, wave, li, kq, a.H, a.W);
     if (vn < ntiles) { head_pin(pxr); head_commit<TH>(pxr, imgH, imgL, tid, sat); }
   }
@@ -449,7 +455,9 @@ hipError_t launch_l1_decode(const ConvDesc& e, const ConvDesc& dec0, const float
     hipLaunchKernelGGL(kern, dim3(grid), dim3(G::NT), G::lds, s, a);
     return hipGetLastError();
   };
-  // 32 x 16 tiles (less halo recompute) once they still fill the chip; results do not depend on the tile shape
+  // 32 x 16 tiles (less halo recompute, one workgroup of eight waves per CU) once they still fill the chip, else 32 x 8 tiles, two workgroups of
+  // four waves per CU; results do not depend on the tile shape.  Measured at 4K (round 6, same box, profiles/r06_l1_decode_ab.txt): 32 x 16 one
+  // per CU 0.229 ms, 32 x 8 two per CU 0.246, 32 x 8 one per CU 0.374 (round 5's kernel, weights in LDS: 0.255-0.262).  WCT_L1DEC_TH forces one.
   const bool tall = th_env ? th_env == 16 : ((H + 15) / 16) * a.tiles_x >= 2 * num_cus();
-  return tall ? go(l1_decode_kernel<16>, L1DecGeo<16>{}, 16, 1) : go(l1_decode_kernel<8>, L1DecGeo<8>{}, 8, 1);
+  return tall ? go(l1_decode_kernel<16>, L1DecGeo<16>{}, 16, 1) : go(l1_decode_kernel<8>, L1DecGeo<8>{}, 8, 2);
 }
