@@ -731,6 +731,12 @@ __global__ __launch_bounds__(256, 2) void l1_moments_kernel(L1MomArgs a) {
     a.part_sum[(size_t)blockIdx.x * ns + e] = (reds[e] + reds[ns + e]) + (reds[2 * ns + e] + reds[3 * ns + e]);
 }
 
+// (Round 6, measured and not kept: the big maps' products as FOUR exact split-f16 products per pair on v_mfma_f32_16x16x32_f16 with 32 pixels in the K
+//  dimension -- conv11 transposed so that a lane holds four neighbouring pixels of one channel, [channel][pixel] f16 planes, the channel sums as products
+//  against a matrix of ones: 12 MFMAs of 16 cycles per 32 pixels instead of 16 of 32 cycles, 6 ds_read_b128 instead of 32 ds_read_b32.  Same-box A/B at
+//  4K + 2K style: 0.317-0.320 ms per step against 0.305-0.308 for the fp32 form above, and 1.3e-6 from the fp64 form where the fp32 form sits at ~1e-8
+//  (x' = hi + lo is not x).  The kernel is bound by conv11's epilogue and the LDS stores, not by the pair loop's matrix time.  profiles/r06_l1_moments_f16_ab.txt)
+
 // partial -> final, fixed summation order (bitwise reproducible): a 256-thread block owns 16 consecutive output
 // elements x 16 slices of the chunk index; slices are combined through LDS in slice order.
 __global__ __launch_bounds__(256) void moments_reduce_kernel(MomArgs a, double* sum, double* sumsq) {

@@ -78,7 +78,9 @@ struct Lane {
 struct wct_ctx {
   int device = 0;
   Lane main, side;
-  hipEvent_t ev_join = nullptr;   // side -> main (wct_style_moments, wct_stylize_sharded: the style strips' sums are ready)
+  hipEvent_t ev_join = nullptr;   // side -> main (wct_style_moments: the style strip's sums are ready)
+  hipEvent_t ev_smom[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // wct_stylize_sharded, strips: level L's style sums are ready (side -> main)
+  hipEvent_t ev_sar[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};    // ... and level L's all-reduce has been issued (main -> side)
   hipEvent_t ev_fork = nullptr, ev_style[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   int eig_skip = 0, eig_calls = 0;
   int foldgemm = 1;   // 1: the wide models' folds as fp64 matrix-core GEMMs (debug key "foldgemm"; 0: misc.hip fold_block_kernel)
@@ -1002,7 +1004,9 @@ int wct_create(int device, wct_ctx** out) {
     ok = ok && hipMalloc(reinterpret_cast<void**>(&ln->coop), 64) == hipSuccess && hipMemset(ln->coop, 0, 64) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) == hipSuccess;
-  for (int l = 1; l <= 5 && ok; ++l) ok = hipEventCreateWithFlags(&c->ev_style[l], hipEventDisableTiming) == hipSuccess;
+  for (int l = 1; l <= 5 && ok; ++l)
+    ok = hipEventCreateWithFlags(&c->ev_style[l], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&c->ev_smom[l], hipEventDisableTiming) == hipSuccess &&
+         hipEventCreateWithFlags(&c->ev_sar[l], hipEventDisableTiming) == hipSuccess;
   ok = ok && hipMalloc(reinterpret_cast<void**>(&c->sat_dev), 256) == hipSuccess && hipMemset(c->sat_dev, 0, 256) == hipSuccess;
   ok = ok && hipHostMalloc(reinterpret_cast<void**>(&c->sat_host), 64, hipHostMallocDefault) == hipSuccess;
   ok = ok && hipMalloc(reinterpret_cast<void**>(&c->ok_log), 64 * sizeof(int)) == hipSuccess;
@@ -1034,6 +1038,8 @@ void wct_destroy(wct_ctx* ctx) {
     release(ctx->eigS[l]);
     release(ctx->foldS[l]);
     if (ctx->ev_style[l]) (void)hipEventDestroy(ctx->ev_style[l]);
+    if (ctx->ev_smom[l]) (void)hipEventDestroy(ctx->ev_smom[l]);
+    if (ctx->ev_sar[l]) (void)hipEventDestroy(ctx->ev_sar[l]);
   }
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
   if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);

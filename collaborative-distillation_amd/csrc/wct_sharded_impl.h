@@ -280,20 +280,17 @@ int wct_stylize_sharded(wct_ctx* ctx, const float* content_ext, int H, int W_tot
     if (int rc = ensure(ctx, ctx->shNext, img_floats * sizeof(float))) return rc;
     if (int rc = ensure(ctx, ctx->shEdge, (size_t)4 * 3 * H * shard::LEVEL_HALO[4] * sizeof(float))) return rc;   // sendL | sendR | recvL | recvR
   }
-  size_t npk = 0, style_off[6] = {0, 0, 0, 0, 0, 0};
-  for (int level = 1; level <= 5; ++level) {
+  // one all-reduce buffer PER LEVEL: [sum_c C | sumsq_c C*C | range flag | sum_s C | sumsq_s C*C] -- the style half (strips mode) is written by
+  // the style lane while the content lane is still levels ahead, so the levels' buffers must not alias
+  size_t npk = 0, pk_off[6] = {0, 0, 0, 0, 0, 0}, ntot = 0;
+  for (int level = 5; level >= 1; --level) {
     const size_t C = (size_t)shard::feat_channels(ctx, level);
     npk = std::max(npk, C * C + C + 1);
+    pk_off[level] = ntot;
+    ntot += 2 * (C * C + C) + 1;
   }
-  size_t ntot = npk;
-  if (j.style_mode == WCT_STYLE_STRIPS)
-    for (int level = 5; level >= 1; --level) {
-      const size_t C = (size_t)shard::feat_channels(ctx, level);
-      style_off[level] = ntot;
-      ntot += C * C + C;
-    }
   if (int rc = ensure(ctx, ctx->packed, ntot * sizeof(double))) return rc;
-  double* pk = reinterpret_cast<double*>(ctx->packed.p);
+  double* pk_base = reinterpret_cast<double*>(ctx->packed.p);
   if (j.bmap)
     if (int rc = ensure(ctx, ctx->shMb, npk * sizeof(double))) return rc;
 
@@ -301,19 +298,28 @@ int wct_stylize_sharded(wct_ctx* ctx, const float* content_ext, int H, int W_tot
   if (int rc = fork_side(ctx)) return rc;
   Lane& sl = ctx->overlap ? ctx->side : ctx->main;
   auto owner = [&](int level) { return (5 - level) % world; };
-  if (j.style_mode == WCT_STYLE_STRIPS) {
+  // strips mode: level L's style sums ride in level L's all-reduce, and the style lane takes the level's matrix square root right behind it.
+  // Enqueue order on the style lane: moments of levels 5 and 4 up front, then per content level L: [wait for all-reduce L] solve L, moments of
+  // level L - 2 -- the lane never waits for the content lane with strip work still undone, and the content lane waits for ONE level's sums at a time
+  // (the first form joined all five levels into level 5's all-reduce: the content lane then stood behind the whole style side; measured slower than
+  // dealing the levels out whole at every rank count, profiles/r06_style_arrangement_all_at_level5.txt)
+  auto style_strip_moments = [&](int level) -> int {
     const int s0 = j.sxs[rank], s1 = j.sxs[rank + 1];
-    for (int level = 5; level >= 1; --level) {
-      const int sh = level - 1, hl = shard::STYLE_HALO[level];
-      const int lo = std::max(0, s0 - hl), hi = std::min(Ws, s1 + hl), wstrip = hi - lo;
-      if (int rc = ensure(ctx, ctx->shStyle, (size_t)3 * Hs * wstrip * sizeof(float))) return rc;
-      float* strip = reinterpret_cast<float*>(ctx->shStyle.p);
-      HIPCHK(ctx, launch_copy_block(style + lo, Ws, strip, wstrip, (long)3 * Hs, wstrip, sl.stream));
-      const int f0 = (s0 - lo) >> sh, f1 = s1 >= Ws ? -1 : (s1 - lo) >> sh;
-      const size_t C = (size_t)shard::feat_channels(ctx, level);
-      if (int rc = shard::style_moments_impl(ctx, level, strip, Hs, wstrip, f0, f1, pk + style_off[level], pk + style_off[level] + C)) return rc;
-    }
-    HIPCHK(ctx, hipEventRecord(ctx->ev_join, sl.stream));
+    const int sh = level - 1, hl = shard::STYLE_HALO[level];
+    const int lo = std::max(0, s0 - hl), hi = std::min(Ws, s1 + hl), wstrip = hi - lo;
+    if (int rc = ensure(ctx, ctx->shStyle, (size_t)3 * Hs * (std::min(Ws, s1 + shard::STYLE_HALO[5]) - std::max(0, s0 - shard::STYLE_HALO[5])) * sizeof(float))) return rc;
+    float* strip = reinterpret_cast<float*>(ctx->shStyle.p);
+    HIPCHK(ctx, launch_copy_block(style + lo, Ws, strip, wstrip, (long)3 * Hs, wstrip, sl.stream));
+    const int f0 = (s0 - lo) >> sh, f1 = s1 >= Ws ? -1 : (s1 - lo) >> sh;
+    const size_t C = (size_t)shard::feat_channels(ctx, level);
+    double* ps = pk_base + pk_off[level] + C * C + C + 1;
+    if (int rc = shard::style_moments_impl(ctx, level, strip, Hs, wstrip, f0, f1, ps, ps + C)) return rc;
+    HIPCHK(ctx, hipEventRecord(ctx->ev_smom[level], sl.stream));
+    return WCT_OK;
+  };
+  if (j.style_mode == WCT_STYLE_STRIPS) {
+    if (int rc = style_strip_moments(5)) return rc;
+    if (int rc = style_strip_moments(4)) return rc;
   } else {
     for (int level = 5; level >= 1; --level)
       if (j.style_mode == WCT_STYLE_REPLICATE || owner(level) == rank)
@@ -327,6 +333,7 @@ int wct_stylize_sharded(wct_ctx* ctx, const float* content_ext, int H, int W_tot
     const int sh = level - 1;
     const int C = shard::feat_channels(ctx, level);
     const size_t cc = (size_t)C * C;
+    double* pk = pk_base + pk_off[level];
     // crop the running image to this level's extended strip
     const int nlo = std::max(0, own0 - j.halo[level]), nhi = std::min(Wc, own1 + j.halo[level]);
     if (nlo < lo || nhi > hi) return fail(ctx, WCT_ERR_STATE, "stylize_sharded: level %d needs columns [%d, %d), the running strip holds [%d, %d)", level, nlo, nhi, lo, hi);
@@ -343,18 +350,17 @@ int wct_stylize_sharded(wct_ctx* ctx, const float* content_ext, int H, int W_tot
     if (int rc = wct_content_encode(ctx, level, img, Hc, Win, f0, f1, pk, pk + C, &h, &w)) return rc;
     HIPCHK(ctx, launch_counter_to_f64(ctx->sat_dev, pk + C + cc, st));
     const double n_total = (double)h * (double)(Wc >> sh);                          // feature pixels of the whole image
-    if (level == 5 && j.style_mode == WCT_STYLE_STRIPS) {
-      // ONE all-reduce: the level-5 content sums, the range flag, and the five levels' style sums (contiguous behind them)
-      HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_join, 0));
-      if (world > 1) COLLCHK(ctx, "all-reduce (content level 5 + style moments)", co.all_reduce_sum_f64(co.user, pk, ntot, st));
-      HIPCHK(ctx, hipEventRecord(ctx->ev_fork, st));
-      HIPCHK(ctx, hipStreamWaitEvent(sl.stream, ctx->ev_fork, 0));
-      for (int sl_level = 5; sl_level >= 1; --sl_level) {
-        int hs, ws;
-        level_dims(sl_level, Hs, Ws, hs, ws);
-        const size_t Cs = (size_t)shard::feat_channels(ctx, sl_level);
-        if (int rc = shard::style_solve_impl(ctx, sl_level, (double)hs * ws, pk + style_off[sl_level], pk + style_off[sl_level] + Cs)) return rc;
-      }
+    if (j.style_mode == WCT_STYLE_STRIPS) {
+      // ONE all-reduce per level: the content sums, the range flag, and this level's style sums (contiguous behind them)
+      HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_smom[level], 0));
+      if (world > 1) COLLCHK(ctx, "all-reduce (content + style moments)", co.all_reduce_sum_f64(co.user, pk, 2 * (cc + C) + 1, st));
+      HIPCHK(ctx, hipEventRecord(ctx->ev_sar[level], st));
+      HIPCHK(ctx, hipStreamWaitEvent(sl.stream, ctx->ev_sar[level], 0));
+      int hs, ws;
+      level_dims(level, Hs, Ws, hs, ws);
+      if (int rc = shard::style_solve_impl(ctx, level, (double)hs * ws, pk + cc + C + 1, pk + cc + C + 1 + C)) return rc;
+      if (level - 2 >= 1)
+        if (int rc = style_strip_moments(level - 2)) return rc;
     } else if (world > 1) {
       COLLCHK(ctx, "all-reduce (content moments)", co.all_reduce_sum_f64(co.user, pk, cc + C + 1, st));
     }

@@ -27,8 +27,8 @@ coupling is (n, SUM x, SUM x x^T) of the content feature map (util_wct.py:68-70)
       "strips"     the style image is cut into column strips exactly like the content: every rank encodes ITS strip + the
                    ENCODER's receptive field (STYLE_HALO = 80 / 32 / 12 / 4 / 1 columns per interior side at level 5..1) at every
                    level and sums raw moments over its owned feature columns -- the same statistic as the content's, summed the same
-                   way: the five levels' sums ride in the level-5 all-reduce of the content moments (no extra collective) and every
-                   rank takes the five matrix square roots itself.  Per-rank style work is 1 / world of the style side (+ margins:
+                   way: level L's style sums ride in level L's all-reduce of the content moments (no extra collective) and every
+                   rank takes the level's matrix square root itself right behind it.  Per-rank style work is 1 / world of the style side (+ margins:
                    1.3x at 256-column strips) on EVERY rank;
       "owner"      level L's style statistics are computed whole by rank (5 - L) mod world on its side stream and broadcast
                    (C*C + C fp64 values per level, 132 KB at C = 128); rank 0 carries level 5 = 45.6 % of the style FLOPs;
@@ -282,10 +282,10 @@ class ShardedStylizer:
             parts += [s.reshape(-1), ss.reshape(-1)]
         return parts
 
-    def _style_strip_solve(self, flat):
-        """`flat`: the all-reduced concatenation of _style_strip_moments' parts -> every level's style statistics inside the engine."""
+    def _style_strip_solve(self, flat, levels=(5, 4, 3, 2, 1)):
+        """`flat`: the all-reduced concatenation of _style_strip_moments' parts of `levels` -> those levels' style statistics inside the engine."""
         o = 0
-        for L in (5, 4, 3, 2, 1):
+        for L in levels:
             sh = L - 1
             C = self._style_C[L]
             self.e.style_solve(L, float((self.Hs >> sh) * (self.Ws >> sh)), flat[o:o + C], flat[o + C:o + C + C * C].reshape(C, C))
@@ -355,15 +355,16 @@ class ShardedStylizer:
             if range_flag is not None:
                 parts.append(range_flag())                             # this rank's f16x3 clamp counter so far: summed over the ranks below
             n_own = sum(int(p.numel()) for p in parts)
-            if strips and L == 5:
-                parts += style_parts                                   # the five levels' style sums ride in the same all-reduce
+            if strips:
+                i = 2 * (5 - L)
+                parts += style_parts[i:i + 2]                          # this level's style sums ride in the same all-reduce
             packed = torch.cat(parts)
             if self.world > 1:
-                dist.all_reduce(packed)                                # SUM, fp64, C*C + C (+ 1) values (+ the style sums at level 5)
+                dist.all_reduce(packed)                                # SUM, fp64, C*C + C (+ 1) values (+ the level's style sums)
             if range_flag is not None:
                 flags.append(packed[C + C * C:C + C * C + 1])
-            if strips and L == 5:
-                self._style_strip_solve(packed[n_own:])
+            if strips:
+                self._style_strip_solve(packed[n_own:], levels=(L,))
             solvers = (0,) if self.broadcast_map else range(self.world)   # ranks that need the level's style statistics
             if self.world > 1 and owner_mode and any(r != owner(L) for r in solvers):
                 if rank == owner(L):

@@ -232,15 +232,15 @@ int wct_level_sharded(wct_ctx* ctx, int level, const float* content, int H, int 
  * Style side (style_mode; the style image is given WHOLE to every rank, as the reference gives it to every level, WCT.py:121-125):
  *   WCT_STYLE_STRIPS     the style image is cut into column strips like the content: rank r encodes its strip + the ENCODER's
  *                        receptive field (80, 32, 12, 4, 1 columns at level 5..1) at every level, raw moments over its owned feature
- *                        columns; the five levels' sums travel in ONE all-reduce together with the level-5 content moments; every rank
- *                        then takes the five matrix square roots on its side stream.  Per-rank style work = 1/nranks (+ margins);
+ *                        columns; level L's style sums travel in level L's all-reduce together with the content moments, and every
+ *                        rank takes the level's matrix square root on its side stream right behind it.  Per-rank style work = 1/nranks (+ margins);
  *   WCT_STYLE_OWNER      level L's style side is computed whole by rank (5 - L) mod nranks and broadcast (C*C + C doubles per level);
  *   WCT_STYLE_REPLICATE  every rank computes all five levels (no communication; tiny styles);
  *   WCT_STYLE_AUTO       strips when the style is at least 64 columns per rank wide, else replicate.
  * WCT_SHARD_BROADCAST_MAP: rank 0 alone solves for the colouring map and broadcasts (M [C*C], b [C]) doubles per level; default: every
  * rank solves for itself (the all-reduce returns identical bits everywhere and the solver is deterministic).
  *
- * Per level: ONE all-reduce of [sum C | sumsq C*C | f16x3 range flag] doubles (level 5: + the style sums in strips mode), the optional
+ * Per level: ONE all-reduce of [sum C | sumsq C*C | f16x3 range flag] doubles (+ the level's style sums in strips mode), the optional
  * broadcasts above, and in exchange mode one grouped send/recv pair per neighbour.
  *
  *   content_ext   columns [in0, in1) of the content, planar 3 x H x (in1 - in0)
