@@ -1079,7 +1079,6 @@ def rank_sim(wct, style, Hf, Wf, strip_of, ms_one_gpu, scaling, world=8, ranks=(
     stats = {L: wct.style_export(L).clone() for L in (5, 4, 3, 2, 1)}
     torch.cuda.synchronize()
     res = {"world": world, "frame": "%dx%d" % (Wf, Hf), "scaling": scaling, "halo_mode": None, "collectives": note, "ranks": {}}
-    worst, worst_owner = 0.0, 0.0
     hs, ws = int(style.shape[-2]), int(style.shape[-1])
     # the frame as ONE library call with RCCL inside (wct_stylize_sharded) needs a communicator on the engine: one rank here, given the
     # GEOMETRY of rank r of the job by debug key "shard_emulate" (WCT_DEBUG-gated: its peers are itself -- right work, other numbers)
@@ -1133,15 +1132,21 @@ def rank_sim(wct, style, Hf, Wf, strip_of, ms_one_gpu, scaling, world=8, ranks=(
                           "pure_enqueue_ms": round(host - wait, 3), "pure_enqueue_share_of_frame": round((host - wait) / ms, 3)}
             entry.update({"columns_in": x1 - x0, "columns_owned": sh.own[1] - sh.own[0]})
             del strip
-        best = min(v["ms_per_frame"] for k, v in entry.items() if isinstance(v, dict) and k != "torch_distributed_owner")
-        entry["ms_per_frame"] = best
-        worst = max(worst, best)
-        worst_owner = max(worst_owner, entry["torch_distributed_owner"]["ms_per_frame"])
         res["ranks"][str(r)] = entry
     if c_ok:
         wct.comm_destroy()
     eff = lambda w_: round(ms_one_gpu / w_ / world, 3) if scaling == "strong" else round(ms_one_gpu / w_, 3)     # noqa: E731
-    res["predicted_efficiency_round5_arrangement"] = eff(worst_owner)     # style levels dealt out whole (rank 0: level 5), Python orchestration
+    # a job runs ONE arrangement on all its ranks: its frame time is its SLOWEST simulated rank; the prediction is the best arrangement's
+    tags = sorted({k for e in res["ranks"].values() for k, v in e.items() if isinstance(v, dict)})
+    slowest = {t: max(e[t]["ms_per_frame"] for e in res["ranks"].values() if t in e) for t in tags}
+    res["slowest_rank_ms_by_arrangement"] = {t: round(v, 3) for t, v in slowest.items()}
+    res["predicted_efficiency_by_arrangement"] = {t: eff(v) for t, v in slowest.items()}
+    best_tag = min((t for t in tags if t != "torch_distributed_owner"), key=lambda t: slowest[t])
+    res["arrangement"] = best_tag
+    worst = slowest[best_tag]
+    for e in res["ranks"].values():
+        e["ms_per_frame"] = e[best_tag]["ms_per_frame"]
+    res["predicted_efficiency_round5_arrangement"] = eff(slowest["torch_distributed_owner"])     # Python orchestration over torch.distributed, style levels dealt out whole
     res["predicted_ms_per_frame"] = round(worst, 3)
     res["predicted_MPs"] = round(Hf * Wf / 1e6 / worst * 1e3, 1)
     if scaling == "strong":

@@ -14,7 +14,6 @@ constexpr int LEVEL_HALO[6] = {0, 2, 10, 24, 72, 160};
 constexpr int CUM_HALO[6] = {0, 6, 16, 40, 112, 272};
 constexpr int STYLE_HALO[6] = {0, 1, 4, 12, 32, 80};
 constexpr int AUTO_EXCHANGE_BELOW = 2560;
-constexpr int STYLE_STRIPS_MIN_COLS_PER_RANK = 64;
 
 // owned column range of every rank: origins are multiples of 16, the last strip takes the remainder (sharded.py strip_bounds)
 bool strip_bounds(int W, int world, std::vector<int>& xs) {
@@ -36,10 +35,13 @@ int resolve_halo_mode(int halo_mode, int world, const std::vector<int>& xs) {
   return halo_mode;
 }
 
+// AUTO = OWNER: measured at 2, 4 and 8 ranks (profiles/r06_style_arrangement_per_level_join.txt) dealing the levels out whole beats cutting the style into
+// strips by 0.5-1.3 ms per rank frame although rank 0 then carries 45.6 % of the style FLOPs: every style-side matrix square root occupies an XCD that the
+// content lane's one-workgroup-per-CU kernels then wait for, and the all-reduce arrangements (strips, replicate) run five of them on EVERY rank.
 int resolve_style_mode(int style_mode, int world, int Ws) {
+  (void)Ws;
   if (world == 1) return WCT_STYLE_REPLICATE;
-  if (style_mode == WCT_STYLE_AUTO) return Ws >= STYLE_STRIPS_MIN_COLS_PER_RANK * world ? WCT_STYLE_STRIPS : WCT_STYLE_REPLICATE;
-  return style_mode;
+  return style_mode == WCT_STYLE_AUTO ? WCT_STYLE_OWNER : style_mode;
 }
 
 inline int feat_channels(const wct_ctx* ctx, int level) { return ctx->mod[WCT_KIND_ENC][level].layers.back().d.cout; }

@@ -33,7 +33,9 @@ coupling is (n, SUM x, SUM x x^T) of the content feature map (util_wct.py:68-70)
       "owner"      level L's style statistics are computed whole by rank (5 - L) mod world on its side stream and broadcast
                    (C*C + C fp64 values per level, 132 KB at C = 128); rank 0 carries level 5 = 45.6 % of the style FLOPs;
       "replicate"  every rank repeats all five levels (no communication; styles too narrow to cut);
-      "auto"       strips when the style is at least 64 columns per rank wide, else replicate;
+      "auto"       = "owner": measured at 2, 4 and 8 ranks (profiles/r06_style_arrangement_per_level_join.txt) it beats "strips" by 0.5-1.3 ms per
+                   rank frame -- every style-side matrix square root occupies an XCD that the content lane's persistent kernels then wait
+                   for, and strips / replicate run five of them on EVERY rank where owner runs at most three on one;
   * the colouring map (M, b): every rank now holds the same global content moments (the all-reduce returns identical bits
     everywhere) and the same style statistics, and the solver is deterministic, so every rank solves for itself and folds
     the SAME matrices into its decoder -- two collectives per level.  `broadcast_map=True` keeps the other arrangement
@@ -59,8 +61,6 @@ import torch
 LEVEL_HALO = {5: 160, 4: 72, 3: 24, 2: 10, 1: 2}
 #: the ENCODER's receptive field alone (style strips: 70 / 30 / 10 / 4 / 1 columns, rounded up to a multiple of 2^(L-1))
 STYLE_HALO = {5: 80, 4: 32, 3: 12, 2: 4, 1: 1}
-#: style_mode "auto": strips from this many style columns per rank
-STYLE_STRIPS_MIN_COLS_PER_RANK = 64
 #: cumulative halo needed at the INPUT of level L (multiples of 2^(L-1); A_L - LEVEL_HALO[L] >= A_{L-1})
 CUM_HALO = {5: 272, 4: 112, 3: 40, 2: 16, 1: 6}
 #: strips narrower than this take the neighbour exchange under halo_mode="auto"
@@ -121,7 +121,7 @@ class ShardedStylizer:
         if self.world == 1:
             style_mode = "replicate"
         elif style_mode == "auto":
-            style_mode = "strips" if Ws >= STYLE_STRIPS_MIN_COLS_PER_RANK * self.world else "replicate"
+            style_mode = "owner"
         self.style_mode = style_mode
         self.style_bounds = strip_bounds(Ws, self.world) if style_mode == "strips" else None
         self.H, self.W, self.Hs, self.Ws = H, W_total, Hs, Ws

@@ -236,7 +236,9 @@ int wct_level_sharded(wct_ctx* ctx, int level, const float* content, int H, int 
  *                        rank takes the level's matrix square root on its side stream right behind it.  Per-rank style work = 1/nranks (+ margins);
  *   WCT_STYLE_OWNER      level L's style side is computed whole by rank (5 - L) mod nranks and broadcast (C*C + C doubles per level);
  *   WCT_STYLE_REPLICATE  every rank computes all five levels (no communication; tiny styles);
- *   WCT_STYLE_AUTO       strips when the style is at least 64 columns per rank wide, else replicate.
+ *   WCT_STYLE_AUTO       = owner.  Measured at 2, 4 and 8 ranks (profiles/r06_style_arrangement_per_level_join.txt): owner beats strips by 0.5-1.3 ms per
+ *                        rank frame although its rank 0 carries 45.6 % of the style FLOPs -- each style-side matrix square root occupies an XCD the
+ *                        content kernels then wait for, and strips / replicate run five of them on every rank, owner at most three.
  * WCT_SHARD_BROADCAST_MAP: rank 0 alone solves for the colouring map and broadcasts (M [C*C], b [C]) doubles per level; default: every
  * rank solves for itself (the all-reduce returns identical bits everywhere and the solver is deterministic).
  *

@@ -236,13 +236,13 @@ def test_config4_eight_strips_device_buffers_in_process():
     synced, _ = standins.run_in_process(8, make, content, style, sync_every=True, halo_mode="auto", style_mode="owner")
     assert torch.equal(got, synced)
     del synced
-    # the default arrangement since round 6: the STYLE cut into eight 256-column strips as well, and the frame as ONE library call per rank
-    strips, groups = standins.run_in_process(8, make, content, style, halo_mode="auto")
+    # round 6: the STYLE cut into eight 256-column strips as well (style_mode "strips"), and the frame as ONE library call per rank
+    strips, groups = standins.run_in_process(8, make, content, style, halo_mode="auto", style_mode="strips")
     es = float((strips - ref).abs().max() / ref.abs().max())
     print("[cfg4 8 strips, style in strips too] rel_err=%.3e  vs owner-mode job %.3e" % (es, float((strips - got).abs().max() / ref.abs().max())))
     assert es < 1e-3 and all(grp.calls == {"all_reduce": 5, "broadcast": 0, "p2p": 4} for grp in groups)
     del got, ref
-    ccas, groups = standins.run_in_process(8, make, content, style, halo_mode="auto", c_cascade=True)
+    ccas, groups = standins.run_in_process(8, make, content, style, halo_mode="auto", style_mode="strips", c_cascade=True)
     assert torch.equal(ccas, strips) and all(grp.calls == {"all_reduce": 5, "broadcast": 0, "p2p": 4} for grp in groups)
 
 
@@ -281,8 +281,11 @@ def test_config4_geometry_vs_reference(tmp_path, oracle):
     inproc, groups = standins.run_in_process(8, make, content, style, halo_mode="auto", style_mode="owner")
     assert all(grp.calls == {"all_reduce": 5, "broadcast": 5, "p2p": 4} for grp in groups)
     ri = compare_to_fixture(inproc.cpu().numpy()[0], g16)
-    # (d) the same job as ONE library call per rank (wct_stylize_sharded), the style cut into strips too: the round-6 default path
+    # (d) the same job as ONE library call per rank (wct_stylize_sharded, style levels dealt out whole: the round-6 default path) ...
     ccas, groups = standins.run_in_process(8, make, content, style, halo_mode="auto", c_cascade=True)
+    assert all(grp.calls == {"all_reduce": 5, "broadcast": 5, "p2p": 4} for grp in groups) and torch.equal(ccas, inproc)
+    # ... and with the style cut into strips too
+    ccas, groups = standins.run_in_process(8, make, content, style, halo_mode="auto", style_mode="strips", c_cascade=True)
     assert all(grp.calls == {"all_reduce": 5, "broadcast": 0, "p2p": 4} for grp in groups)
     rc = compare_to_fixture(ccas.cpu().numpy()[0], g16)
     print("\n[G16 cfg4 geometry vs REFERENCE] C cascade, style strips: %.3e (p99.99 %.3e)" % (rc["max"], rc["lattice_p9999"]))
@@ -325,7 +328,7 @@ def test_config4_geometry_natural_image_vs_reference(oracle):
     assert eng.saturation_count() == 0
     py, _ = standins.run_in_process(8, make, content, style, halo_mode="auto", style_mode="owner")
     rp = compare_to_fixture(py.cpu().numpy()[0], g17)
-    cc, groups = standins.run_in_process(8, make, content, style, halo_mode="auto", c_cascade=True)
+    cc, groups = standins.run_in_process(8, make, content, style, halo_mode="auto", style_mode="strips", c_cascade=True)
     assert all(grp.calls == {"all_reduce": 5, "broadcast": 0, "p2p": 4} for grp in groups)
     rc = compare_to_fixture(cc.cpu().numpy()[0], g17)
     oracle.set_num_threads(min(os.cpu_count() or 1, 32))
@@ -582,7 +585,7 @@ def test_bench_two_ranks_on_one_gpu(extra, name):
     par = line["parity"]
     assert all(v["c_cascade_bitwise_equals_torch_distributed"] for v in par["first_contact"].values()) and "g16" in par["first_contact"]
     assert par["timed_frame_strips_vs_untiled_same_gpu"] <= par["limit"] and par["g16_cfg4_geometry"]["ok"] and par["g16_cfg4_geometry"]["hip_vs_reference"] <= 1e-3
-    assert "wct_stylize_sharded" in line["config"]["collectives"] and "style side: strips" in line["config"]["workload"]
+    assert "wct_stylize_sharded" in line["config"]["collectives"] and "style side: owner" in line["config"]["workload"]
     if name == "cfg4":
         assert line["scaling"] == "strong" and line["config"]["content_total"] == "10240x4096"
         assert "halo: exchange" in line["config"]["workload"]

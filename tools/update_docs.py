@@ -49,8 +49,8 @@ lines.append("* `--mode original`, 1920×1080 (BASELINE configs[2], generated we
 for k, name in (("cfg4_rank_sim", "10240×4096 in 8 strips"), ("cfg2x8_rank_sim", "8 × 3840 columns (weak)")):
     rs = p.get(k, {})
     if rs:
-        lines.append("* One rank's share of the 8-GPU job, timed on one GPU (%s): %s ms per frame → %s predicted%s (compute + orchestration only; no link time, no skew)." % (
-            name, g(rs.get("predicted_ms_per_frame"), "%.2f"), ("%s× one GPU" % g(rs.get("predicted_speedup_vs_1gpu"), "%.2f")) if rs.get("predicted_speedup_vs_1gpu") else ("%s efficiency" % g(rs.get("predicted_efficiency"), "%.3f")), " (round 5's arrangement on the same box: %s efficiency)" % g(rs.get("predicted_efficiency_round5_arrangement"), "%.3f") if rs.get("predicted_efficiency_round5_arrangement") else ""))
+        lines.append("* One rank's share of the 8-GPU job, timed on one GPU (%s): slowest rank of the best arrangement (`%s`) %s ms per frame → %s predicted%s (compute + orchestration only; no link time, no skew)." % (
+            name, rs.get("arrangement"), g(rs.get("predicted_ms_per_frame"), "%.2f"), ("%s× one GPU" % g(rs.get("predicted_speedup_vs_1gpu"), "%.2f")) if rs.get("predicted_speedup_vs_1gpu") else ("%s efficiency" % g(rs.get("predicted_efficiency"), "%.3f")), " (round 5's arrangement on the same box: %s efficiency)" % g(rs.get("predicted_efficiency_round5_arrangement"), "%.3f") if rs.get("predicted_efficiency_round5_arrangement") else ""))
         for r, e in sorted((rs.get("ranks") or {}).items()):
             for tag, what in (("torch_distributed_owner", "round 5's arrangement: Python orchestration, style levels dealt out whole"),
                               ("torch_distributed", "Python orchestration over torch.distributed, style in strips"),
