@@ -102,7 +102,9 @@ int wct_range_flag_f64(wct_ctx* ctx, double* flag_dev);
  * full-resolution ends, SP16 intermediates, level 1 without relu1_1 in HBM, f16x3 or exact-fp32 first conv of the un-pruned
  * encoders); results agree to fp32 round-off or bitwise (tests/test_hip_parity.py).  "eig_skip" (N: after N solves the matrix
  * functions are SKIPPED and stale results reused) is a timing experiment that produces wrong pictures by design: it is refused
- * unless the environment variable WCT_DEBUG is set.  Environment variables WCT_* are honoured only when WCT_DEBUG is set. */
+ * unless the environment variable WCT_DEBUG is set; so is "shard_emulate" (100 * ranks + rank: a context holding a ONE-rank communicator runs
+ * wct_stylize_sharded with the geometry of one rank of a larger job, its peers being itself -- what one rank of the job executes, with
+ * other numbers; 0: off).  Environment variables WCT_* are honoured only when WCT_DEBUG is set. */
 int wct_debug_set(wct_ctx* ctx, const char* key, double value);
 /* Health counters of the context (no reference counterpart): "nscoop_solves" = single-launch C = 128 matrix-function solves enqueued,
  * "nscoop_aborts" = those that aborted into the Jacobi net (watchdog / placement; synchronises the context), "nscoop_off" = bit mask
