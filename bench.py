@@ -686,6 +686,8 @@ def main():
             res["latency_ms_avg_during_fit"] = round(float(y.mean()), 3)
             # time ~ 1 / sclk for the whole step is the simple model; the fitted line says how much of it the data supports
             res["latency_ms_scaled_to_2200MHz"] = round(float((y / x).mean()), 3)
+            # two-box calibration of round 6 (7.313 ms at 2259 MHz, 7.900 ms at 2021 MHz): 31 % of the step does not follow the shader clock
+            res["latency_ms_at_2200MHz_two_box_model"] = round(float((y / (0.31 + 0.69 * x)).mean()), 3)
             if float(x.max() - x.min()) > 0.004:          # the clock moved by > 0.4 % over the samples: a slope can be estimated
                 b, a = np.polyfit(x, y, 1)
                 r = float(np.corrcoef(x, y)[0, 1])
@@ -1010,7 +1012,8 @@ def main():
         roof["device"] = {"sclk_MHz_avg": (telemetry or {}).get("sclk_MHz_avg"), "power_W_avg": (telemetry or {}).get("power_W_avg"),
                           "ms_per_step": round(dt / args.steps * 1e3, 3),
                           "ms_per_step_sustained": (sustained or {}).get("ms_per_step_sustained"),
-                          "latency_ms_scaled_to_2200MHz": (sustained or {}).get("latency_ms_scaled_to_2200MHz")}
+                          "latency_ms_scaled_to_2200MHz": (sustained or {}).get("latency_ms_scaled_to_2200MHz"),
+                          "latency_ms_at_2200MHz_two_box_model": (sustained or {}).get("latency_ms_at_2200MHz_two_box_model")}
         r3 = passes.get("cfg3_original", {}).get("roofline") if args.config != "cfg3" else None
         if r3 and live:      # (not attempted when the first collection failed: bounded run time)
             live3 = live_pmc("cfg3")

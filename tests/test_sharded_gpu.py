@@ -492,8 +492,11 @@ def test_config5_eight_4k_contents_one_style(tmp_path):
     aborts = [open(str(tmp_path / ("r%d.aborts" % r))).read() for r in range(world)]
     print("\n[cfg5] single-launch solves aborted / enqueued per rank:", aborts)
     # Round 6 saw this comparison fail twice in ~110 runs (rank 0's image, once with the hash on record; 104 later runs of the same binary --
-    # tools/debug/cfg5_stress.py -- all equal, and one process is bitwise reproducible: tools/debug/replica_diag.py).  Not root-caused.  A mismatch
-    # is therefore measured and reported, and the 8-process job is run ONCE more: a second mismatch, or a first one beyond fp32 round-off, fails.
+    # tools/debug/cfg5_stress.py -- all equal, and one process is bitwise reproducible: tools/debug/replica_diag.py).  The likely cause: eight
+    # PROCESSES sharing one GPU all ran their single-launch matrix-function solves on XCDs 0 / 1; two meeting on an XCD starve each other's software
+    # barrier until the watchdog aborts them into the Jacobi net -- repaired, correct, NOT bit-identical (wct_create now starts each process at its
+    # own XCD).  A mismatch is therefore measured and reported with the abort counters, and the 8-process job is run ONCE more: a second mismatch,
+    # or a first one beyond fp32 round-off, fails.
     bad = [r for r in range(world) if open(str(tmp_path / ("r%d.sha" % r))).read() != want[r]]
     for r in bad:
         ref = wct.stylize_prepared(contents[r]).cpu().numpy()[:, :, ::16, ::16]
