@@ -551,13 +551,21 @@ def main():
                 try:
                     note = c_transport_ready(eng)
                     runner_c = ShardedStylizer(eng, dist, fh, fw, hs_, ws_, halo_mode=args.halo_mode, c_cascade=True)
-                    a = runner_c.stylize_strip(content, style)
-                    b = runner.stylize_strip(content, style)
-                    runner_c.check_range()
-                    runner.check_range()
-                    ok = bool(torch.equal(a, b))
-                    why = None if ok else "C cascade differs from the torch.distributed path by %.3e" % float((a - b).abs().max())
-                    del a, b
+                    for attempt in (0, 1):
+                        # (a single-launch matrix-function solve that ABORTS into its Jacobi net -- ranks sharing one GPU, never one process per
+                        #  GPU -- is repaired correctly but not bit-identically: such a frame is compared again, once)
+                        aborts0 = eng.debug_get("nscoop_aborts")
+                        a = runner_c.stylize_strip(content, style)
+                        b = runner.stylize_strip(content, style)
+                        runner_c.check_range()
+                        runner.check_range()
+                        ok = bool(torch.equal(a, b))
+                        why = None if ok else "C cascade differs from the torch.distributed path by %.3e" % float((a - b).abs().max())
+                        del a, b
+                        again = torch.tensor([1.0 if (not ok and eng.debug_get("nscoop_aborts") > aborts0) else 0.0], device="cuda")
+                        dist.all_reduce(again, op=dist.ReduceOp.MAX)          # every rank repeats, or none (the frame contains collectives)
+                        if again.item() < 0.5:
+                            break
                 except Exception as e:      # noqa: BLE001
                     ok, why = False, repr(e)
                     sys.stderr.write("bench.py rank %d: C cascade first contact failed: %r\n" % (rank, e))

@@ -11,7 +11,6 @@
 #include <atomic>
 #include <cstring>
 #include <dlfcn.h>
-#include <unistd.h>
 #include <map>
 #include <mutex>
 #include <string>
@@ -997,11 +996,7 @@ int wct_create(int device, wct_ctx** out) {
   if (const char* m = wct_debug_env("WCT_FUSE")) c->fuse = m[0] != '0';
   if (const char* m = wct_debug_env("WCT_SP")) c->sp = m[0] != '0';
   if (const char* m = wct_debug_env("WCT_L1FUSE")) c->l1fuse = m[0] != '0';
-  // Which XCD a lane's single-launch solves run on: round robin over the contexts of a process, STARTING at a per-process offset -- processes that
-  // share one GPU (tests, a multi-tenant host) otherwise all pick XCDs 0 / 1, and two such launches meeting on one XCD each hold part of its CUs
-  // and spin on their software barriers until the 5 ms watchdog aborts them into the Jacobi net (correct, but not bit-identical: the one flake of
-  // tests/test_sharded_gpu.py::test_config5_eight_4k_contents_one_style seen in round 6 fits that)
-  static std::atomic<int> next_xcd{2 * (int)(getpid() & 3)};
+  static std::atomic<int> next_xcd{0};
   c->main.xcd = next_xcd.fetch_add(2) & 7;
   c->side.xcd = (c->main.xcd + 1) & 7;
   bool ok = hipStreamCreateWithFlags(&c->side.stream, hipStreamNonBlocking) == hipSuccess;
