@@ -722,7 +722,9 @@ def test_c_cascade_with_rccl_inside_single_rank():
       * the C cascade at world 1 is BITWISE the Python orchestration of the split-level entries and within tolerance of the untiled frame;
       * with WCT_DEBUG set, debug key "shard_emulate" gives the context the GEOMETRY of rank 3 (interior) and rank 0 (edge) of an 8-rank job
         (bench.py passes.cfg4_rank_sim): crops, style strip, five all-reduces and four grouped ncclSend / ncclRecv exchanges really run on
-        RCCL with the rank as its own neighbour; the owned strip comes back finite with the owned width; without WCT_DEBUG the key is refused."""
+        RCCL with the rank as its own neighbour; the owned strip comes back finite with the owned width; without WCT_DEBUG the key is refused;
+      * that emulated frame -- ncclAllReduce, ncclBroadcast, grouped ncclSend / ncclRecv and both lanes' kernels -- is captured into ONE HIP graph
+        and replayed on the same buffers with another strip: bitwise the direct call (the call never synchronises the host or allocates)."""
     code = r"""
 import os, sys, types
 sys.path[:0] = [%r, %r]
@@ -771,6 +773,31 @@ for r in (3, 0, 7):
     out = eng.stylize_sharded(frame[:, :, in0:in1].contiguous(), style8, Wf, in0, in1, halo_mode='auto', style_mode='strips')
     eng.sync()
     assert tuple(out.shape) == (1, 3, Hf, 320) and bool(torch.isfinite(out).all()), (r, tuple(out.shape))
+# ... and the call is capturable into ONE HIP graph, RCCL launches included (no host synchronisation, no allocation after the first call of a size):
+# rank 3's frame captured once, replayed on the same buffers with another strip -- bitwise the direct call both times
+eng.debug_set('shard_emulate', 803)
+own0, own1, in0, in1, mode = eng.shard_geometry(Wf, 8, 3, 'auto')
+s1, s2 = frame[:, :, in0:in1].contiguous(), torch.rand((3, Hf, in1 - in0), device='cuda', generator=g)
+buf = torch.empty(3 * Hf * 320, device='cuda')
+want1 = eng.stylize_sharded(s1, style8, Wf, in0, in1, out=buf).clone()
+want2 = eng.stylize_sharded(s2, style8, Wf, in0, in1, out=buf).clone()
+strip = s1.clone()
+eng.stylize_sharded(strip, style8, Wf, in0, in1, out=buf)
+torch.cuda.synchronize()
+cap = torch.cuda.Stream()
+with torch.cuda.stream(cap):
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=cap):
+        eng.stylize_sharded(strip, style8, Wf, in0, in1, out=buf)
+buf.zero_()
+graph.replay()
+torch.cuda.synchronize()
+assert torch.equal(buf.view(-1)[:want1.numel()], want1.view(-1)), 'graph replay 1 differs'
+strip.copy_(s2)
+graph.replay()
+torch.cuda.synchronize()
+assert torch.equal(buf.view(-1)[:want2.numel()], want2.view(-1)), 'graph replay 2 (new strip, same graph) differs'
+del graph
 eng.debug_set('shard_emulate', 0)
 assert eng.comm_info() == (1, 0)
 eng.comm_destroy()
