@@ -328,20 +328,29 @@ class ShardedStylizer:
             f0 = (own[0] - lo) >> sh                                   # owned feature columns
             f1 = -1 if own[1] >= W_cur else (own[1] - lo) >> sh        # last strip: to the (floored) end
             if self.c_collectives:
-                # the level's style statistics first (import is all the solver needs), then the whole level in one call
-                if self.world > 1 and owner_mode:
-                    if rank == owner(L):
-                        stats = e.style_export(L)
-                    else:
-                        stats = torch.empty(e.style_stats_count(L), dtype=torch.float64, device=img.device)
-                    dist.broadcast(stats, src=owner(L))
-                    if rank != owner(L):
-                        e.style_import(L, stats)
+                # the whole level in one call; its style statistics were broadcast one level AHEAD (level 5's up front): the export makes the
+                # caller's stream wait for the owner's style lane, so issued right in front of its own level it would order that level's
+                # content encoder behind the style side on the owner rank and give the overlap away
+                def share_stats(lvl):
+                    if self.world > 1 and owner_mode:
+                        if rank == owner(lvl):
+                            stats = e.style_export(lvl)
+                        else:
+                            stats = torch.empty(e.style_stats_count(lvl), dtype=torch.float64, device=img.device)
+                        dist.broadcast(stats, src=owner(lvl))
+                        if rank != owner(lvl):
+                            e.style_import(lvl, stats)
+                if L == 5:
+                    share_stats(5)
                 h = H_in >> sh
                 flag = torch.empty(1, dtype=torch.float64, device=img.device) if range_flag is not None else None
                 img = e.level_sharded(L, img, f0, f1, float(h * (W_cur >> sh)), self.alpha, flag)
                 if flag is not None:
                     flags.append(flag)
+                if L > 1:
+                    if hasattr(dist, "set_level"):
+                        dist.set_level(L - 1)
+                    share_stats(L - 1)
                 W_cur = (W_cur >> sh) << sh
                 hi = lo + int(img.shape[-1])
                 own = (own[0], min(own[1], W_cur))
