@@ -51,8 +51,12 @@ def _shard_worker(rank, world, port, H, W, halo_mode, bmap, out_path, style_hw=(
             g = torch.Generator(device="cuda").manual_seed(11)
             content = torch.rand((3, H, W), device="cuda", generator=g)
             style = torch.rand((3,) + tuple(style_hw), device="cuda", generator=g)
-        if c_coll or c_cascade:      # the collectives inside the library, on its own RCCL communicator (wct_level_sharded / wct_stylize_sharded)
-            wct.comm_init(dist)
+        if c_coll or c_cascade:      # the collectives inside the library (wct_level_sharded / wct_stylize_sharded): on its own RCCL communicator, or --
+            if backend == "nccl":    # ranks sharing one GPU over gloo -- through the torch.distributed transport adapter (test infrastructure)
+                wct.comm_init(dist)
+            else:
+                from tools.sharded_standins import dist_transport
+                wct.comm_attach_collectives(*dist_transport(dist), world, rank)
             wct.comm_selftest()
         sh = ShardedStylizer(wct, dist, H, W, style_hw[0], style_hw[1], halo_mode=halo_mode, broadcast_map=bmap, style_mode=style_mode,
                              c_cascade=c_cascade, c_collectives=(bool(c_coll) if (c_coll or c_cascade) else None))
@@ -165,6 +169,22 @@ def test_c_cascade_bitwise_equals_python_orchestration(world, H, W, halo_mode, b
     assert torch.equal(got, synced)
     ref = make().stylize(content, style)
     assert rel_err(got.cpu().numpy(), ref.cpu().numpy()) < 5e-4
+
+
+@pytest.mark.parametrize("world,H,W,halo_mode,bmap,smode", [(3, 144, 1168, "exchange", True, "owner"), (4, 208, 2560, "recompute", False, "strips"),
+                                                            (8, 96, 2560, "exchange", False, "owner")])
+def test_c_cascade_multi_process_equals_python_orchestration(tmp_path, world, H, W, halo_mode, bmap, smode):
+    """The library's cascade in a MULTI-PROCESS job (one process per rank, as deployed; here the ranks share the one GPU and the library's transport
+    table is the torch.distributed adapter over gloo, host-staged): bitwise the Python orchestration of the same job over the same process group
+    (gloo sums the ranks' terms in one order for both), selftest included -- 3, 4 and 8 ranks, neighbour exchange, (M, b) broadcast, style strips."""
+    import torch.multiprocessing as mp
+    outs = []
+    for c_cascade in (False, True):
+        out = str(tmp_path / ("c%d.npz" % c_cascade))
+        mp.spawn(_shard_worker, args=(world, _free_port(), H, W, halo_mode, bmap, out, (200, 333), "rand", "gloo", False, smode, c_cascade), nprocs=world, join=True)
+        outs.append(np.load(out))
+    assert np.array_equal(outs[0]["got"], outs[1]["got"])
+    assert rel_err(outs[1]["got"], outs[1]["ref"]) < 5e-4
 
 
 def test_c_cascade_refuses_what_it_cannot_run():
