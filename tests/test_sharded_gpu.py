@@ -187,6 +187,29 @@ def test_c_cascade_multi_process_equals_python_orchestration(tmp_path, world, H,
     assert rel_err(outs[1]["got"], outs[1]["ref"]) < 5e-4
 
 
+@pytest.mark.parametrize("world,halo_mode,smode", [(2, "recompute", "owner"), (3, "exchange", "strips")])
+def test_c_cascade_mode_original(world, halo_mode, smode):
+    """--mode original (feature maps up to 512 channels wide: the deflated multi-launch solves, which read one flag back per solve) through the library's
+    cascade -- round 5's wct_level_sharded refused that mode -- bitwise the Python orchestration of the split-level entries, and the untiled frame within
+    the tolerance the conditioned generated weights allow (model_zoo.synth_weights_conditioned, the set G15's strict gate uses)."""
+    import torch
+    from wct_hip import WCT, model_zoo
+    from tools import sharded_standins as standins
+    w = model_zoo.synth_weights_conditioned("original", 15)
+    make = lambda: WCT(types.SimpleNamespace(mode="original", alpha=1.0), weights=w)     # noqa: E731
+    g = torch.Generator(device="cuda").manual_seed(21)
+    H, W = 112, 160 * world + 304
+    content = torch.rand((3, H, W), device="cuda", generator=g)
+    style = torch.rand((3, 128, 176), device="cuda", generator=g)
+    kw = dict(halo_mode=halo_mode, style_mode=smode)
+    want, gp = standins.run_in_process(world, make, content, style, **kw)
+    got, gc = standins.run_in_process(world, make, content, style, c_cascade=True, **kw)
+    assert torch.equal(got, want), float((got - want).abs().max())
+    assert [x.calls for x in gc] == [x.calls for x in gp]
+    ref = make().stylize(content, style)
+    assert tuple(got.shape) == tuple(ref.shape) and rel_err(got.cpu().numpy(), ref.cpu().numpy()) < 2e-3
+
+
 def test_c_cascade_random_geometries():
     """tools/debug/cascade_fuzz.py: sixteen random jobs (2..8 ranks, odd frame sizes and widths that floor pooling shrinks, random style sizes, every
     halo / style / map arrangement, alpha 1 and 0.6) through the library's cascade and through the Python orchestration: bitwise equal, the same
