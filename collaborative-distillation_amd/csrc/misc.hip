@@ -466,6 +466,30 @@ __global__ __launch_bounds__(256) void copy_block_kernel(const float* __restrict
 }
 }  // namespace
 
+// up to three such blocks of the same height in ONE launch (the neighbour exchange: both edge blocks packed together; received left margin | owned
+// columns | received right margin assembled together): the blocks are a few columns wide, so the launches, not the bytes, are what they cost
+namespace {
+__global__ __launch_bounds__(256) void copy_blocks_kernel(CopySegs g, long rows) {
+  const long w0 = g.width[0], w1 = g.width[1], w2 = g.width[2], wsum = w0 + w1 + w2, total = rows * wsum;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long r = i / wsum;
+    long c = i - r * wsum;
+    const int k = c < w0 ? 0 : (c < w0 + w1 ? 1 : 2);
+    c -= k == 0 ? 0 : (k == 1 ? w0 : w0 + w1);
+    g.dst[k][r * g.dst_pitch[k] + c] = g.src[k][r * g.src_pitch[k] + c];
+  }
+}
+}  // namespace
+
+hipError_t launch_copy_blocks(const CopySegs& g, long rows, hipStream_t s) {
+  const long wsum = (long)g.width[0] + g.width[1] + g.width[2];
+  if (rows <= 0 || wsum <= 0) return hipSuccess;
+  const long total = rows * wsum;
+  const unsigned blocks = (unsigned)std::min<long>((total + 255) / 256, 256L * 64);
+  hipLaunchKernelGGL(copy_blocks_kernel, dim3(blocks), dim3(256), 0, s, g, rows);
+  return hipGetLastError();
+}
+
 hipError_t launch_copy_block(const float* src, long src_pitch, float* dst, long dst_pitch, long rows, int width, hipStream_t s) {
   if (rows <= 0 || width <= 0) return hipSuccess;
   const long total = rows * width;

@@ -131,6 +131,7 @@ struct wct_ctx {
   // how the context talks to its peers (wct_comm_init / _attach: RCCL on `comm`; wct_comm_attach_collectives: the caller's transport)
   wct_collectives coll{};
   bool coll_set = false, coll_rccl = false;
+  bool quiet_readback = false;
   bool shard_emulate = false;   // MEASUREMENT ONLY (debug key "shard_emulate"): comm_ranks / comm_rank are an emulated job's, the real communicator has ONE rank
   // wct_stylize_sharded: the level's cropped input, the decoded strip, the next level's assembled input (exchange mode), the four edge blocks
   // (send left | send right | recv left | recv right), the rank's style strip, a level's style statistics in transit, (M | b) in transit
@@ -199,6 +200,7 @@ struct DevGuard {
 // the saturation counter follows every compute entry point to pinned host memory on the caller's stream (4 bytes, no sync):
 // wct_range_poll then reports a clamp of any COMPLETED call without stalling the pipeline
 int range_readback(wct_ctx* ctx) {
+  if (ctx->quiet_readback) return WCT_OK;   // inside wct_stylize_sharded: the split-level entries it calls do not each mirror the counters, the call does once
   // 16 bytes: the saturation counter, its snapshot, and the two lanes' aborted single-launch solves (coop_health reads those)
   if (ctx->sat_host) HIPCHK(ctx, hipMemcpyAsync(ctx->sat_host, ctx->sat_dev, 4 * sizeof(unsigned), hipMemcpyDeviceToHost, ctx->main.stream));
   return WCT_OK;

@@ -131,6 +131,8 @@ hipError_t launch_resize_u8(const uint8_t* in, int H, int W, int oH, int oW, con
 // ---- pitched block copy of floats (rows x width; the sharded cascade's level crops, halo packing and assembly: a planar 3 x H x W image is
 //      3H rows of pitch W)
 hipError_t launch_copy_block(const float* src, long src_pitch, float* dst, long dst_pitch, long rows, int width, hipStream_t s);
+struct CopySegs { const float* src[3]; float* dst[3]; long src_pitch[3], dst_pitch[3]; int width[3]; };   // width 0: segment unused
+hipError_t launch_copy_blocks(const CopySegs& g, long rows, hipStream_t s);
 
 // ---- layout
 hipError_t launch_nhwc_to_nchw(const float* in, float* out, int C, int npix, hipStream_t s);

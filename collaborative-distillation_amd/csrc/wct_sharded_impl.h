@@ -172,6 +172,7 @@ int wct_comm_selftest(wct_ctx* ctx) {
   const int n = ctx->comm_ranks, r = ctx->comm_rank, N = 1024;
   hipStream_t st = ctx->main.stream;
   wct_collectives& co = ctx->coll;
+  struct Quiet { wct_ctx* c; explicit Quiet(wct_ctx* c_) : c(c_) { c->quiet_readback = true; } ~Quiet() { c->quiet_readback = false; } } quiet(ctx);   // ONE readback, at the end
   if (int rc = ensure(ctx, ctx->shStats, (size_t)6 * N * sizeof(double))) return rc;
   double* d = reinterpret_cast<double*>(ctx->shStats.p);
   std::vector<double> h((size_t)6 * N), back((size_t)6 * N);
@@ -366,7 +367,7 @@ int wct_stylize_sharded(wct_ctx* ctx, const float* content_ext, int H, int W_tot
     } else if (world > 1) {
       COLLCHK(ctx, "all-reduce (content moments)", co.all_reduce_sum_f64(co.user, pk, cc + C + 1, st));
     }
-    if (range_total) HIPCHK(ctx, hipMemcpyAsync(range_total, pk + C + cc, sizeof(double), hipMemcpyDeviceToDevice, st));
+    if (range_total && level == 1) HIPCHK(ctx, hipMemcpyAsync(range_total, pk + C + cc, sizeof(double), hipMemcpyDeviceToDevice, st));   // the counter is cumulative
     if (j.style_mode == WCT_STYLE_OWNER && world > 1 && (!j.bmap || owner(level) != 0)) {
       // the level's style statistics travel from their owner to every solver (all ranks, or rank 0 alone with a broadcast map)
       size_t ns = 0;
@@ -418,14 +419,15 @@ int wct_stylize_sharded(wct_ctx* ctx, const float* content_ext, int H, int W_tot
       const float* owned = out + (own0 - lo);
       wct_p2p ops[4];
       int n = 0;
-      if (rank > 0) {
-        HIPCHK(ctx, launch_copy_block(owned, Wo, sendL, send_w, rows, send_w, st));
-        ops[n++] = wct_p2p{rank - 1, 1, sendL, (size_t)rows * send_w * sizeof(float)};
+      {
+        // both edge blocks packed in one launch
+        CopySegs g{};
+        if (rank > 0) { g.src[0] = owned; g.src_pitch[0] = Wo; g.dst[0] = sendL; g.dst_pitch[0] = send_w; g.width[0] = send_w; }
+        if (rank + 1 < world) { g.src[1] = owned + (my_w - send_w); g.src_pitch[1] = Wo; g.dst[1] = sendR; g.dst_pitch[1] = send_w; g.width[1] = send_w; }
+        HIPCHK(ctx, launch_copy_blocks(g, rows, st));
       }
-      if (rank + 1 < world) {
-        HIPCHK(ctx, launch_copy_block(owned + (my_w - send_w), Wo, sendR, send_w, rows, send_w, st));
-        ops[n++] = wct_p2p{rank + 1, 1, sendR, (size_t)rows * send_w * sizeof(float)};
-      }
+      if (rank > 0) ops[n++] = wct_p2p{rank - 1, 1, sendL, (size_t)rows * send_w * sizeof(float)};
+      if (rank + 1 < world) ops[n++] = wct_p2p{rank + 1, 1, sendR, (size_t)rows * send_w * sizeof(float)};
       if (left_w) ops[n++] = wct_p2p{rank - 1, 0, recvL, (size_t)rows * left_w * sizeof(float)};
       if (right_w) ops[n++] = wct_p2p{rank + 1, 0, recvR, (size_t)rows * right_w * sizeof(float)};
       if (ctx->shard_emulate)
@@ -433,9 +435,14 @@ int wct_stylize_sharded(wct_ctx* ctx, const float* content_ext, int H, int W_tot
       if (n) COLLCHK(ctx, "neighbour exchange (send / recv)", co.sendrecv(co.user, ops, n, st));
       float* next = reinterpret_cast<float*>(ctx->shNext.p);
       const int Wn = left_w + my_w + right_w;
-      if (left_w) HIPCHK(ctx, launch_copy_block(recvL, left_w, next, Wn, rows, left_w, st));
-      HIPCHK(ctx, launch_copy_block(owned, Wo, next + left_w, Wn, rows, my_w, st));
-      if (right_w) HIPCHK(ctx, launch_copy_block(recvR, right_w, next + left_w + my_w, Wn, rows, right_w, st));
+      {
+        // received left margin | owned columns | received right margin: the next level's input, one launch
+        CopySegs g{};
+        g.src[0] = recvL; g.src_pitch[0] = left_w; g.dst[0] = next; g.dst_pitch[0] = Wn; g.width[0] = left_w;
+        g.src[1] = owned; g.src_pitch[1] = Wo; g.dst[1] = next + left_w; g.dst_pitch[1] = Wn; g.width[1] = my_w;
+        g.src[2] = recvR; g.src_pitch[2] = right_w; g.dst[2] = next + left_w + my_w; g.dst_pitch[2] = Wn; g.width[2] = right_w;
+        HIPCHK(ctx, launch_copy_blocks(g, rows, st));
+      }
       cur = next;
       lo = own0 - left_w;
       hi = lo + Wn;
@@ -445,6 +452,7 @@ int wct_stylize_sharded(wct_ctx* ctx, const float* content_ext, int H, int W_tot
   HIPCHK(ctx, launch_copy_block(cur + (own0 - lo), hi - lo, out_owned, Wo, (long)3 * Hc, Wo, st));
   if (Ho_out) *Ho_out = Hc;
   if (Wo_out) *Wo_out = Wo;
+  ctx->quiet_readback = false;
   return range_readback(ctx);
 }
 
