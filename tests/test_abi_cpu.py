@@ -133,3 +133,47 @@ def test_experiment_scripts_reference_live_switches():
     r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "experiments", "audit.py")], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout
 
+
+
+def test_c_host_of_the_sharded_cascade_compiles_and_links(tmp_path):
+    """a NON-Python host drives one rank of the multi-GPU job through the C ABI alone.  That host, as plain C99, compiles
+    against include/wct_hip.h (prototypes checked by the compiler) and links against libwct_hip.so; without a GPU it runs as far as wct_create's
+    error and the pure geometry function, whose answers for BASELINE configs[3] (10240 columns, 8 ranks) are checked."""
+    import subprocess
+    src = tmp_path / "host.c"
+    src.write_text(r'''
+#include <stdio.h>
+#include "wct_hip.h"
+static int dummy_ar(void* u, double* b, size_t n, void* s) { (void)u; (void)b; (void)n; (void)s; return 0; }
+static int dummy_bc(void* u, void* b, size_t n, int r, void* s) { (void)u; (void)b; (void)n; (void)r; (void)s; return 0; }
+static int dummy_sr(void* u, const wct_p2p* o, int n, void* s) { (void)u; (void)o; (void)n; (void)s; return 0; }
+int run_rank(wct_ctx* ctx, int nranks, int rank, const unsigned char* id, const float* content_ext, const float* style, float* out_owned) {
+  int own0, own1, in0, in1, mode, Ho, Wo;
+  if (wct_comm_load(NULL) != WCT_OK || wct_comm_init(ctx, nranks, rank, id) != WCT_OK || wct_comm_selftest(ctx) != WCT_OK) return -1;
+  if (wct_shard_geometry(10240, nranks, rank, WCT_HALO_AUTO, &own0, &own1, &in0, &in1, &mode) != WCT_OK) return -2;
+  return wct_stylize_sharded(ctx, content_ext, 4096, 10240, in0, in1, style, 2048, 2048, 1.0f, WCT_HALO_AUTO, WCT_STYLE_AUTO, 0, out_owned, &Ho, &Wo, NULL);
+}
+int main(void) {
+  wct_collectives t = {NULL, dummy_ar, dummy_bc, dummy_sr};
+  int own0, own1, in0, in1, mode, n, r;
+  (void)t;
+  if (wct_shard_geometry(10240, 8, 3, WCT_HALO_AUTO, &own0, &own1, &in0, &in1, &mode) != WCT_OK) return 1;
+  printf("%d %d %d %d %d\n", own0, own1, in0, in1, mode);
+  if (wct_shard_geometry(400, 4, 0, WCT_HALO_EXCHANGE, &own0, &own1, &in0, &in1, &mode) == WCT_OK) return 2;   /* strips too narrow to exchange */
+  if (wct_comm_info(NULL, &n, &r) == WCT_OK) return 3;
+  printf("version %d library '%s'\n", wct_version(), wct_comm_library());
+  return 0;
+}
+''')
+    exe = tmp_path / "host"
+    _build()
+    from wct_hip import lib
+    libdir = os.path.dirname(lib.LIB_PATH)
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(REPO, "include"), str(src), "-o", str(exe),
+                        "-L", libdir, "-lwct_hip", "-Wl,-rpath," + libdir], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    env = dict(os.environ, LD_LIBRARY_PATH=os.pathsep.join([libdir, "/opt/rocm/lib", os.environ.get("LD_LIBRARY_PATH", "")]))
+    r = subprocess.run([str(exe)], capture_output=True, text=True, env=env, timeout=120)
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr[-2000:])
+    assert r.stdout.splitlines()[0] == "3840 5120 3680 5280 2"          # rank 3 of 8: owns [3840, 5120), is given +-160 columns, exchange mode
+    assert "version 1 library ''" in r.stdout
