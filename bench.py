@@ -583,7 +583,10 @@ def main():
                                                                    "limit": 1e-5, "rank0_note": why}
                 first_contact_dev[0] = 0.0
                 if agreed:
-                    runner, used = runner_c, note
+                    # the TIMED path: the same cascade with the single-GPU fold (WCT_SHARD_FAST_FOLD: no (M, b) and no assemble launch on the critical
+                    # path; fp32 round-off from the form checked above) -- what the parity leg then holds against the untiled frame, which folds the same way
+                    runner = ShardedStylizer(eng, dist, fh, fw, hs_, ws_, halo_mode=args.halo_mode, c_cascade=True, fast_fold=True)
+                    used = note + "; fast fold"
                 else:
                     used += " -- the library's cascade was NOT used: " + (why or "another rank's first-contact check failed")
             collectives_used[0] = used
@@ -1127,7 +1130,7 @@ def rank_sim(wct, style, Hf, Wf, strip_of, ms_one_gpu, scaling, world=8, ranks=(
                 os.environ["WCT_DEBUG"] = "1"
                 wct.debug_set("shard_emulate", 100 * world + r)
             try:
-                sh = ShardedStylizer(wct, grp, Hf, Wf, hs, ws, halo_mode="auto", c_collectives=False, style_mode=smode, c_cascade=c_cas)
+                sh = ShardedStylizer(wct, grp, Hf, Wf, hs, ws, halo_mode="auto", c_collectives=False, style_mode=smode, c_cascade=c_cas, fast_fold=c_cas)
                 res["halo_mode"] = sh.halo_mode
                 x0, x1 = sh.input_columns()
                 strip = strip_of(x0, x1)

@@ -385,20 +385,40 @@ int wct_stylize_sharded(wct_ctx* ctx, const float* content_ext, int H, int W_tot
       if (rank != owner(level) && (!j.bmap || rank == 0))
         if (int rc = wct_style_import(ctx, level, stats)) return rc;
     }
-    double *M, *b;
-    if (j.bmap) {
-      M = reinterpret_cast<double*>(ctx->shMb.p);
-      b = M + cc;
-      if (rank == 0)
-        if (int rc = wct_content_solve(ctx, level, n_total, pk, pk + C, alpha, M, b)) return rc;
-      COLLCHK(ctx, "broadcast (M, b)", co.broadcast(co.user, M, (cc + C) * sizeof(double), 0, st));
-    } else {
-      if (int rc = mb_view(ctx, &M, &b)) return rc;
-      if (int rc = wct_content_solve(ctx, level, n_total, pk, pk + C, alpha, M, b)) return rc;
-    }
     float* out = reinterpret_cast<float*>(ctx->shOut.p);
     int Ho = 0, Wo = 0;
-    if (int rc = wct_content_decode(ctx, level, M, b, out, &Ho, &Wo)) return rc;
+    // WCT_SHARD_FAST_FOLD: the single-GPU cascade's fold (content_side): (W cov_s^1/2) from the style lane times cov_c^-1/2 from the content solve straight
+    // into the decoder's first conv -- no T, M, b and no assemble launch on the critical path; where the decoder allows it (cin <= 128, f16x3 mode) and
+    // every rank folds for itself.  fp32 round-off from the (M, b) form below (tests/test_hip_parity.py test_fast_fold_matches_the_map_based_fold).
+    const bool fast = (flags & WCT_SHARD_FAST_FOLD) && !j.bmap && ctx->conv_mode == 1 && ctx->fold_ready[level] && fast_fold_level(ctx, level);
+    if (fast) {
+      SumsView sv;
+      if (int rc = sums_view(ctx, ctx->main, sv)) return rc;
+      if (int rc = eig_impl(ctx, ctx->main, C, n_total, pk, pk + C, 1, ctx->eigC, sv.info)) return rc;
+      HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_style[level], 0));
+      ConvDesc first;
+      if (int rc = fold_fast_impl(ctx, level, alpha, first)) return rc;
+      if (l1_fused(ctx, level)) {
+        if (int rc = l1_decode_impl(ctx, level, reinterpret_cast<const float*>(ctx->l1img.p), ctx->cur_H, ctx->cur_W, first, out)) return rc;
+      } else {
+        if (int rc = decode_impl(ctx, level, reinterpret_cast<float*>(ctx->featC.p), ctx->cur_h, ctx->cur_w, &first, out)) return rc;
+      }
+      Ho = ctx->cur_h << sh;
+      Wo = ctx->cur_w << sh;
+    } else {
+      double *M, *b;
+      if (j.bmap) {
+        M = reinterpret_cast<double*>(ctx->shMb.p);
+        b = M + cc;
+        if (rank == 0)
+          if (int rc = wct_content_solve(ctx, level, n_total, pk, pk + C, alpha, M, b)) return rc;
+        COLLCHK(ctx, "broadcast (M, b)", co.broadcast(co.user, M, (cc + C) * sizeof(double), 0, st));
+      } else {
+        if (int rc = mb_view(ctx, &M, &b)) return rc;
+        if (int rc = wct_content_solve(ctx, level, n_total, pk, pk + C, alpha, M, b)) return rc;
+      }
+      if (int rc = wct_content_decode(ctx, level, M, b, out, &Ho, &Wo)) return rc;
+    }
     // floor-mode pooling may have dropped trailing columns / rows of the full image
     Wc = (Wc >> sh) << sh;
     Hc = Ho;

@@ -57,6 +57,7 @@ class WctCollectives(ctypes.Structure):
 HALO_MODES = {"auto": 0, "recompute": 1, "exchange": 2}
 STYLE_MODES = {"auto": 0, "owner": 1, "strips": 2, "replicate": 3}
 SHARD_BROADCAST_MAP = 1
+SHARD_FAST_FOLD = 2
 
 
 class WctError(RuntimeError):

@@ -92,7 +92,7 @@ def ext_bounds(own: Tuple[int, int], W: int, halo: int) -> Tuple[int, int]:
 class ShardedStylizer:
     def __init__(self, engine, dist, H: int, W_total: int, Hs: int, Ws: int, rank: Optional[int] = None,
                  world: Optional[int] = None, alpha: float = 1.0, broadcast_map: bool = False, halo_mode: str = "auto",
-                 c_collectives: Optional[bool] = None, style_mode: str = "auto", c_cascade: bool = False):
+                 c_collectives: Optional[bool] = None, style_mode: str = "auto", c_cascade: bool = False, fast_fold: bool = False):
         self.e, self.dist = engine, dist
         self.broadcast_map = broadcast_map
         # c_collectives: a level's encode -> all-reduce -> solve -> decode chain as ONE library call on the engine's own RCCL communicator
@@ -101,6 +101,11 @@ class ShardedStylizer:
         # c_cascade: the WHOLE frame as one library call (wct_stylize_sharded); opt-in, needs the engine's communicator as well.
         has = bool(getattr(engine, "has_comm", False))
         self.c_cascade = bool(c_cascade)
+        # fast_fold (c_cascade only): the single-GPU cascade's fold without (M, b) on the critical path (WCT_SHARD_FAST_FOLD); fp32 round-off from the
+        # default form, so no longer bit-identical to this file's split-level orchestration
+        self.fast_fold = bool(fast_fold)
+        if self.fast_fold and not self.c_cascade:
+            raise ValueError("fast_fold is an option of the library's cascade (c_cascade=True)")
         self.c_collectives = (has and not broadcast_map and not self.c_cascade) if c_collectives is None else bool(c_collectives)
         if self.c_collectives and (not has or broadcast_map):
             raise ValueError("c_collectives needs engine.comm_init(dist) and broadcast_map=False")
@@ -262,7 +267,7 @@ class ShardedStylizer:
         x0, x1 = self.input_columns()
         flag = torch.empty(1, dtype=torch.float64, device=content_ext.device) if range_flag is not None else None
         out = self.e.stylize_sharded(content_ext, style, self.W, x0, x1, alpha=self.alpha, halo_mode=self.halo_mode, style_mode=self.style_mode,
-                                     broadcast_map=self.broadcast_map, range_total=flag)
+                                     broadcast_map=self.broadcast_map, range_total=flag, fast_fold=self.fast_fold)
         if flag is not None:
             self._note_range(flag)
         return out

@@ -562,7 +562,7 @@ class WCT:
     @torch.no_grad()
     def stylize_sharded(self, content_ext: torch.Tensor, style: torch.Tensor, W_total: int, in0: int, in1: int, alpha: Optional[float] = None,
                         halo_mode: str = "auto", style_mode: str = "auto", broadcast_map: bool = False,
-                        range_total: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                        range_total: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, fast_fold: bool = False) -> torch.Tensor:
         """The WHOLE column-sharded cascade in ONE library call (wct_stylize_sharded): this rank's strip + level-5 margin in
         (columns [in0, in1) of the W_total-wide content, see shard_geometry), its owned columns of the stylised image out
         ([1, 3, H', own_w']).  Geometry, crops, the style side (strips / owner / replicate), the per-level all-reduce, the optional
@@ -581,7 +581,7 @@ class WCT:
         ho, wo = c_int(), c_int()
         self._stream()
         self._chk(self._lib.wct_stylize_sharded(self._ctx, c.data_ptr(), H, int(W_total), int(in0), int(in1), s.data_ptr(), int(s.shape[1]), int(s.shape[2]),
-                                                alpha, _lib.HALO_MODES[halo_mode], _lib.STYLE_MODES[style_mode], _lib.SHARD_BROADCAST_MAP if broadcast_map else 0,
+                                                alpha, _lib.HALO_MODES[halo_mode], _lib.STYLE_MODES[style_mode], (_lib.SHARD_BROADCAST_MAP if broadcast_map else 0) | (_lib.SHARD_FAST_FOLD if fast_fold else 0),
                                                 out.data_ptr(), byref(ho), byref(wo), range_total.data_ptr() if range_total is not None else None))
         self._style_keep = s
         return out.view(-1)[: 3 * ho.value * wo.value].view(1, 3, ho.value, wo.value)

@@ -273,6 +273,9 @@ typedef struct wct_collectives {
 #define WCT_STYLE_STRIPS 2
 #define WCT_STYLE_REPLICATE 3
 #define WCT_SHARD_BROADCAST_MAP 1   /* flags */
+#define WCT_SHARD_FAST_FOLD 2       /* the single-GPU cascade's fold -- (W cov_s^1/2) cov_c^-1/2 straight into the decoder's first conv, no (M, b) on the
+                                       critical path -- where the decoder allows it and every rank folds for itself; fp32 round-off from the (M, b) form,
+                                       which stays the default because wct_hip/sharded.py's split-level orchestration is bit-identical to it */
 int wct_comm_attach_collectives(wct_ctx* ctx, const wct_collectives* coll, int nranks, int rank);
 /* nranks / rank of the communicator or transport the context holds (0 / 0: none) */
 int wct_comm_info(const wct_ctx* ctx, int* nranks, int* rank);

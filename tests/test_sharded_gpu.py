@@ -210,6 +210,30 @@ def test_c_cascade_mode_original(world, halo_mode, smode):
     assert tuple(got.shape) == tuple(ref.shape) and rel_err(got.cpu().numpy(), ref.cpu().numpy()) < 2e-3
 
 
+@pytest.mark.parametrize("world,H,W,halo_mode,smode", [(3, 144, 1168, "exchange", "owner"), (4, 208, 2560, "recompute", "strips")])
+def test_c_cascade_fast_fold(world, H, W, halo_mode, smode):
+    """WCT_SHARD_FAST_FOLD: the library's cascade folding the way the single-GPU cascade does ((W cov_s^1/2) cov_c^-1/2 straight into the decoder's first
+    conv, no (M, b) on the critical path) -- what bench.py times for N > 1.  fp32 round-off from the default (M, b) form (<= 1e-4 after five levels, the
+    bound of test_fast_fold_matches_the_map_based_fold), reproducible bit for bit, and at least as close to the untiled frame (which folds the same way)."""
+    import torch
+    from wct_hip import WCT, model_zoo
+    from tools import sharded_standins as standins
+    w = model_zoo.load_npz_weights(os.path.join(PKG, "weights", "16x.npz"))
+    make = lambda: WCT(types.SimpleNamespace(mode="16x", alpha=1.0), weights=w)     # noqa: E731
+    g = torch.Generator(device="cuda").manual_seed(11)
+    content = torch.rand((3, H, W), device="cuda", generator=g)
+    style = torch.rand((3, 300, 260), device="cuda", generator=g)
+    kw = dict(halo_mode=halo_mode, style_mode=smode, c_cascade=True)
+    base, _ = standins.run_in_process(world, make, content, style, **kw)
+    fast, gf = standins.run_in_process(world, make, content, style, fast_fold=True, **kw)
+    again, _ = standins.run_in_process(world, make, content, style, fast_fold=True, **kw)
+    assert torch.equal(fast, again)          # deterministic (the two folds differ in fp64 association BEFORE the weights are rounded to fp32: usually the same bits)
+    ref = make().stylize(content, style).cpu().numpy()
+    e_fast, e_base = rel_err(fast.cpu().numpy(), ref), rel_err(base.cpu().numpy(), ref)
+    print("\n[fast fold, %d ranks] fast vs (M, b) form %.2e; vs untiled: fast %.2e, (M, b) form %.2e" % (world, rel_err(fast.cpu().numpy(), base.cpu().numpy()), e_fast, e_base))
+    assert rel_err(fast.cpu().numpy(), base.cpu().numpy()) < 1e-4 and e_fast < 5e-4
+
+
 def test_c_cascade_random_geometries():
     """tools/debug/cascade_fuzz.py: sixteen random jobs (2..8 ranks, odd frame sizes and widths that floor pooling shrinks, random style sizes, every
     halo / style / map arrangement, alpha 1 and 0.6) through the library's cascade and through the Python orchestration: bitwise equal, the same
@@ -635,7 +659,7 @@ def test_bench_two_ranks_on_one_gpu(extra, name):
     par = line["parity"]
     assert all(v["c_cascade_equals_torch_distributed"] and v["rank0_max_rel_deviation"] == 0.0 for v in par["first_contact"].values()) and "g16" in par["first_contact"]
     assert par["timed_frame_strips_vs_untiled_same_gpu"] <= par["limit"] and par["g16_cfg4_geometry"]["ok"] and par["g16_cfg4_geometry"]["hip_vs_reference"] <= 1e-3
-    assert "wct_stylize_sharded" in line["config"]["collectives"] and "style side: owner" in line["config"]["workload"]
+    assert "wct_stylize_sharded" in line["config"]["collectives"] and "fast fold" in line["config"]["collectives"] and "style side: owner" in line["config"]["workload"]
     if name == "cfg4":
         assert line["scaling"] == "strong" and line["config"]["content_total"] == "10240x4096"
         assert "halo: exchange" in line["config"]["workload"]
